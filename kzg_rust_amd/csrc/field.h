@@ -1,0 +1,313 @@
+// field.h -- Fp (381-bit) and Fr (255-bit) Montgomery arithmetic for gfx950, unsaturated 29-bit limbs.
+//
+// Why 29-bit limbs: measured on MI355X (profiles/r01_valu_issue_rates.txt) v_mad_u64_u32 issues at
+// the same rate as any other VALU op, so the cost of a field product is its instruction COUNT.
+// With limbs < 2^29 every column sum of a Montgomery product (<= 28 terms < 2^58 each) fits a 64-bit
+// accumulator, so each limb product is exactly ONE v_mad_u64_u32 with no carry handling: an Fp product
+// is 2*14*14 = 392 mads + ~100 shift/mask ops, versus ~1350 instructions for saturated 32-bit limbs
+// (288 mads + carry/zero-extension traffic).  Fp: 14 limbs (R = 2^406), Fr: 9 limbs (R = 2^261).
+//
+// Every value is kept CANONICAL (limbs < 2^29, value < modulus) so equality is limb equality.
+// Reference counterpart: the blst_fp / blst_fr types behind src/utils.rs, src/kzg.rs;
+// blst's 64-bit-limb R = 2^384 / 2^256 layout is deliberately not reproduced.
+//
+// Everything is KZG_HD (host+device): the same source is unit-tested with g++ on the CPU build box
+// (tests/native/hd_probe.cpp) before it runs on a GPU.  The product ships only device instantiations.
+#pragma once
+#include <stdint.h>
+#include "consts_gen.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KZG_HD __host__ __device__ __forceinline__
+#define KZG_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define KZG_HD inline __attribute__((always_inline))
+#define KZG_HD_NOINLINE __attribute__((noinline))
+#endif
+
+namespace kzg {
+
+constexpr int LB = KZG_LIMB_BITS;                 // 29
+constexpr uint32_t LMASK = (1u << LB) - 1u;
+constexpr int NFP = KZG_FP_LIMBS;                 // 14
+constexpr int NFR = KZG_FR_LIMBS;                 // 9
+
+struct Fp { uint32_t l[NFP]; };
+struct Fr { uint32_t l[NFR]; };
+
+// ---------------------------------------------------------------------------------- limb helpers
+// r = a - b over N 29-bit limbs (mod 2^(29N)); returns 1 if a < b
+template <int N> KZG_HD uint32_t ul_sub(uint32_t *r, const uint32_t *a, const uint32_t *b) {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t d = a[i] - b[i] - borrow;
+        borrow = d >> 31;
+        r[i] = d & LMASK;
+    }
+    return borrow;
+}
+template <int N> KZG_HD bool ul_is_zero(const uint32_t *a) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) t |= a[i];
+    return t == 0;
+}
+template <int N> KZG_HD bool ul_eq(const uint32_t *a, const uint32_t *b) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) t |= a[i] ^ b[i];
+    return t == 0;
+}
+// a + b mod m  (a, b canonical)
+template <int N> KZG_HD void mod_add(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *m) {
+    // d = a + b - m with a signed carry chain; if it went negative add m back
+    uint32_t d[N];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        int32_t t = (int32_t)(a[i] + b[i] - m[i]) + c;
+        c = t >> LB;
+        d[i] = (uint32_t)t & LMASK;
+    }
+    const uint32_t neg = (uint32_t)c;      // 0 or 0xffffffff
+    uint32_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t t = d[i] + (m[i] & neg) + cc;
+        cc = t >> LB;
+        r[i] = t & LMASK;
+    }
+}
+// a - b mod m
+template <int N> KZG_HD void mod_sub(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *m) {
+    uint32_t d[N];
+    const uint32_t neg = 0u - ul_sub<N>(d, a, b);
+    uint32_t cc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t t = d[i] + (m[i] & neg) + cc;
+        cc = t >> LB;
+        r[i] = t & LMASK;
+    }
+}
+// Montgomery product r = a*b/2^(29N) mod m.  a, b: limbs < 2^29, a*b < m*2^(29N).  inv = -m^-1 mod 2^29.
+// Column accumulators: acc[j] collects a[j']*b[i] and q_i*m[j'] for the current weight; after each outer
+// step the (now zero mod 2^29) lowest column is shifted out.  No carries until the final sweep.
+template <int N> KZG_HD void mont_mul(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *m, const uint32_t inv) {
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t bi = b[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] += (uint64_t)a[j] * bi;
+        const uint32_t q = ((uint32_t)acc[0] * inv) & LMASK;
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] += (uint64_t)q * m[j];
+        const uint64_t carry = acc[0] >> LB;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    uint32_t t[N];
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        c += acc[j];
+        t[j] = (uint32_t)c & LMASK;
+        c >>= LB;
+    }
+    // t < m + a*b/R; one conditional subtraction makes it canonical
+    uint32_t s[N];
+    const uint32_t br = ul_sub<N>(s, t, m);
+#pragma unroll
+    for (int j = 0; j < N; j++) r[j] = br ? t[j] : s[j];
+}
+// 32-bit word array (little-endian words, NW of them) -> N 29-bit limbs
+template <int N, int NW> KZG_HD void words_to_limbs(uint32_t *l, const uint32_t *w) {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int bit = LB * k, wi = bit >> 5, sh = bit & 31;
+        uint32_t lo = wi < NW ? w[wi] : 0u;
+        uint32_t hi = (wi + 1) < NW ? w[wi + 1] : 0u;
+        uint32_t v = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+        l[k] = v & LMASK;
+    }
+}
+// N 29-bit limbs -> NW 32-bit words (value must fit)
+template <int N, int NW> KZG_HD void limbs_to_words(uint32_t *w, const uint32_t *l) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const int bit = 32 * i, k = bit / LB, sh = bit % LB;     // word i starts inside limb k at offset sh
+        uint32_t v = k < N ? (l[k] >> sh) : 0u;
+        if ((k + 1) < N) v |= l[k + 1] << (LB - sh);             // LB - sh in [1,29]
+        if ((k + 2) < N && (2 * LB - sh) < 32) v |= l[k + 2] << (2 * LB - sh);
+        w[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- Fp
+#define KZG_FP_CONSTS const uint32_t FP_MOD[NFP] = FP_MOD_INIT;
+KZG_HD Fp fp_zero() { Fp r; for (int i = 0; i < NFP; i++) r.l[i] = 0; return r; }
+KZG_HD Fp fp_one() { const uint32_t c[NFP] = FP_ONE_INIT; Fp r; for (int i = 0; i < NFP; i++) r.l[i] = c[i]; return r; }
+KZG_HD void fp_add(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mod_add<NFP>(r.l, a.l, b.l, FP_MOD); }
+KZG_HD void fp_sub(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mod_sub<NFP>(r.l, a.l, b.l, FP_MOD); }
+KZG_HD void fp_dbl(Fp &r, const Fp &a) { KZG_FP_CONSTS mod_add<NFP>(r.l, a.l, a.l, FP_MOD); }
+KZG_HD void fp_neg(Fp &r, const Fp &a) { Fp z = fp_zero(); fp_sub(r, z, a); }
+KZG_HD bool fp_is_zero(const Fp &a) { return ul_is_zero<NFP>(a.l); }
+KZG_HD bool fp_eq(const Fp &a, const Fp &b) { return ul_eq<NFP>(a.l, b.l); }
+#if defined(KZG_FP_MUL_NOINLINE)
+KZG_HD_NOINLINE void fp_mul(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }
+#else
+KZG_HD void fp_mul(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }
+#endif
+KZG_HD void fp_sqr(Fp &r, const Fp &a) { fp_mul(r, a, a); }
+KZG_HD void fp_select(Fp &r, bool take_b, const Fp &a, const Fp &b) {
+#pragma unroll
+    for (int i = 0; i < NFP; i++) r.l[i] = take_b ? b.l[i] : a.l[i];
+}
+// canonical integer value (not Montgomery) as limbs
+KZG_HD void fp_from_mont(uint32_t out[NFP], const Fp &a) {
+    KZG_FP_CONSTS
+    uint32_t one[NFP];
+#pragma unroll
+    for (int i = 0; i < NFP; i++) one[i] = i == 0 ? 1u : 0u;
+    mont_mul<NFP>(out, a.l, one, FP_MOD, FP_INVW);
+}
+KZG_HD void fp_to_mont(Fp &r, const uint32_t in[NFP]) {
+    KZG_FP_CONSTS
+    const uint32_t R2[NFP] = FP_R2_INIT;
+    mont_mul<NFP>(r.l, in, R2, FP_MOD, FP_INVW);
+}
+// a^e, e given as 12 plain 32-bit words (<= 384 bits), square-and-multiply MSB first.
+// Rolled loop on purpose: a single fp_mul body in the instruction stream.
+KZG_HD void fp_pow(Fp &r, const Fp &a, const uint32_t *e) {
+    Fp acc = fp_one();
+    bool started = false;
+    for (int i = 383; i >= 0; i--) {
+        if (started) fp_sqr(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) {
+            if (started) fp_mul(acc, acc, a); else { acc = a; started = true; }
+        }
+    }
+    r = acc;
+}
+KZG_HD void fp_inv(Fp &r, const Fp &a) { const uint32_t e[12] = FP_EXP_INV_INIT; fp_pow(r, a, e); }
+// sqrt for p = 3 mod 4: a^((p+1)/4); false if a is not a square
+KZG_HD bool fp_sqrt(Fp &r, const Fp &a) {
+    const uint32_t e[12] = FP_EXP_SQRT_INIT;
+    Fp s, chk; fp_pow(s, a, e); fp_sqr(chk, s);
+    r = s;
+    return fp_eq(chk, a);
+}
+// ZCash sign bit: canonical value > (p-1)/2
+KZG_HD bool fp_is_lex_largest(const Fp &a) {
+    const uint32_t half[NFP] = FP_HALF_INIT;
+    uint32_t v[NFP], t[NFP];
+    fp_from_mont(v, a);
+    return ul_sub<NFP>(t, half, v) != 0;    // half - v borrows  <=>  v > half
+}
+// 48 big-endian bytes -> Fp.  Returns false if the integer is >= p.  mask_top3 clears the 3 flag bits.
+KZG_HD bool fp_from_be48(Fp &r, const uint8_t *in, bool mask_top3) {
+    KZG_FP_CONSTS
+    uint32_t w[12], v[NFP], t[NFP];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const uint8_t *p = in + 4 * (11 - i);
+        w[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    }
+    if (mask_top3) w[11] &= 0x1fffffffu;
+    words_to_limbs<NFP, 12>(v, w);
+    bool ok = ul_sub<NFP>(t, v, FP_MOD) != 0;     // v < p
+    fp_to_mont(r, v);
+    return ok;
+}
+KZG_HD void fp_to_be48(uint8_t *out, const Fp &a) {
+    uint32_t v[NFP], w[12];
+    fp_from_mont(v, a);
+    limbs_to_words<NFP, 12>(w, v);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        uint8_t *p = out + 4 * (11 - i);
+        p[0] = (uint8_t)(w[i] >> 24); p[1] = (uint8_t)(w[i] >> 16); p[2] = (uint8_t)(w[i] >> 8); p[3] = (uint8_t)w[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------- Fr
+#define KZG_FR_CONSTS const uint32_t FR_MOD[NFR] = FR_MOD_INIT;
+KZG_HD Fr fr_zero() { Fr r; for (int i = 0; i < NFR; i++) r.l[i] = 0; return r; }
+KZG_HD Fr fr_one() { const uint32_t c[NFR] = FR_ONE_INIT; Fr r; for (int i = 0; i < NFR; i++) r.l[i] = c[i]; return r; }
+KZG_HD void fr_add(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_add<NFR>(r.l, a.l, b.l, FR_MOD); }
+KZG_HD void fr_sub(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_sub<NFR>(r.l, a.l, b.l, FR_MOD); }
+KZG_HD void fr_mul(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
+KZG_HD void fr_sqr(Fr &r, const Fr &a) { fr_mul(r, a, a); }
+KZG_HD bool fr_is_zero(const Fr &a) { return ul_is_zero<NFR>(a.l); }
+KZG_HD bool fr_eq(const Fr &a, const Fr &b) { return ul_eq<NFR>(a.l, b.l); }
+KZG_HD void fr_select(Fr &r, bool take_b, const Fr &a, const Fr &b) {
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = take_b ? b.l[i] : a.l[i];
+}
+// canonical integer as 8 plain 32-bit words
+KZG_HD void fr_to_words(uint32_t w[8], const Fr &a) {
+    KZG_FR_CONSTS
+    uint32_t one[NFR], v[NFR];
+#pragma unroll
+    for (int i = 0; i < NFR; i++) one[i] = i == 0 ? 1u : 0u;
+    mont_mul<NFR>(v, a.l, one, FR_MOD, FR_INVW);
+    limbs_to_words<NFR, 8>(w, v);
+}
+// any 256-bit integer (8 words) -> Montgomery residue mod r.  The product by R^2 reduces it:
+// v < 2^256 < 2^261 and R2 < r  =>  v*R2 < r*2^261, within mont_mul's contract.
+// (hash_to_bls_field, utils.rs:250-258, relies on exactly this reduction in blst_fr_from_scalar.)
+KZG_HD void fr_from_words(Fr &r, const uint32_t w[8]) {
+    KZG_FR_CONSTS
+    const uint32_t R2[NFR] = FR_R2_INIT;
+    uint32_t v[NFR];
+    words_to_limbs<NFR, 8>(v, w);
+    mont_mul<NFR>(r.l, v, R2, FR_MOD, FR_INVW);
+}
+// value (8 words) < r ?
+KZG_HD bool fr_words_canonical(const uint32_t w[8]) {
+    KZG_FR_CONSTS
+    uint32_t v[NFR], t[NFR];
+    words_to_limbs<NFR, 8>(v, w);
+    return ul_sub<NFR>(t, v, FR_MOD) != 0;
+}
+KZG_HD void fr_inv(Fr &r, const Fr &a) {
+    const uint32_t e[8] = FR_EXP_INV_INIT;
+    Fr acc = a;   // bit 254 of r-2 is set
+    for (int i = 253; i >= 0; i--) {
+        fr_sqr(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) fr_mul(acc, acc, a);
+    }
+    r = acc;
+}
+// 32 big-endian bytes <-> 8 little-endian words
+KZG_HD void be32_to_words(uint32_t w[8], const uint8_t *in) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *p = in + 4 * (7 - i);
+        w[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    }
+}
+KZG_HD void words_to_be32(uint8_t *out, const uint32_t w[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint8_t *p = out + 4 * (7 - i);
+        p[0] = (uint8_t)(w[i] >> 24); p[1] = (uint8_t)(w[i] >> 16); p[2] = (uint8_t)(w[i] >> 8); p[3] = (uint8_t)w[i];
+    }
+}
+// bytes_to_bls_field (utils.rs:262-275): false if the value is >= r
+KZG_HD bool fr_from_be32_checked(Fr &r, const uint8_t *in) {
+    uint32_t w[8]; be32_to_words(w, in);
+    bool ok = fr_words_canonical(w);
+    fr_from_words(r, w);
+    return ok;
+}
+KZG_HD void fr_to_be32(uint8_t *out, const Fr &a) { uint32_t w[8]; fr_to_words(w, a); words_to_be32(out, w); }
+
+}  // namespace kzg

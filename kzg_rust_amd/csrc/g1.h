@@ -1,0 +1,166 @@
+// g1.h -- BLS12-381 G1 (E: y^2 = x^3 + 4 over Fp): Jacobian group law, ZCash (de)compression,
+// subgroup check, scalar multiplication.  Host+device (see field.h).
+// Reference counterparts (all blst calls; blst itself is not in /root/reference):
+//   blst_p1_add_or_double / blst_p1_cneg   utils.rs:166-167, 339      -> g1_add, g1_add_mixed, g1_neg
+//   blst_p1_mult (nbits = 256)             utils.rs:126-140           -> g1_mul_words
+//   blst_p1_uncompress / blst_p1_in_g1     utils.rs:282-310           -> g1_decompress, g1_in_subgroup
+//   blst_p1_compress                       utils.rs:221-227           -> g1_compress_affine
+// Affine points use (0,0) for the point at infinity ((0,0) is not on the curve); Jacobian uses z = 0.
+#pragma once
+#include "field.h"
+
+#if defined(KZG_MID_INLINE)
+#define KZG_G1_MID KZG_HD
+#else
+#define KZG_G1_MID KZG_HD_NOINLINE
+#endif
+
+namespace kzg {
+
+struct G1Affine { Fp x, y; };
+struct G1Jac { Fp x, y, z; };
+
+KZG_HD G1Jac g1_inf() { G1Jac r; r.x = fp_zero(); r.y = fp_zero(); r.z = fp_zero(); return r; }
+KZG_HD G1Affine g1a_inf() { G1Affine r; r.x = fp_zero(); r.y = fp_zero(); return r; }
+KZG_HD bool g1_is_inf(const G1Jac &a) { return fp_is_zero(a.z); }
+KZG_HD bool g1a_is_inf(const G1Affine &a) { return fp_is_zero(a.x) && fp_is_zero(a.y); }
+KZG_HD void g1_neg(G1Jac &r, const G1Jac &a) { r.x = a.x; r.z = a.z; fp_neg(r.y, a.y); }
+KZG_HD void g1a_neg(G1Affine &r, const G1Affine &a) { r.x = a.x; fp_neg(r.y, a.y); }
+KZG_HD void g1_from_affine(G1Jac &r, const G1Affine &a) {
+    bool inf = g1a_is_inf(a);
+    r.x = a.x; r.y = a.y;
+    Fp one = fp_one(), zero = fp_zero();
+    fp_select(r.z, inf, one, zero);
+}
+
+// 2P, a = 0 (dbl-2009-l): 2M + 5S.  P = infinity stays infinity (z3 = 2 y z = 0).
+KZG_G1_MID void g1_dbl(G1Jac &r, const G1Jac &p) {
+    Fp A, B, C, D, E, F, t;
+    fp_sqr(A, p.x);
+    fp_sqr(B, p.y);
+    fp_sqr(C, B);
+    fp_add(t, p.x, B); fp_sqr(t, t); fp_sub(t, t, A); fp_sub(t, t, C); fp_dbl(D, t);
+    fp_dbl(E, A); fp_add(E, E, A);
+    fp_sqr(F, E);
+    fp_mul(t, p.y, p.z);          // before x,y are overwritten (r may alias p)
+    Fp X3, Y3;
+    fp_sub(X3, F, D); fp_sub(X3, X3, D);
+    fp_sub(D, D, X3); fp_mul(Y3, E, D);
+    fp_dbl(C, C); fp_dbl(C, C); fp_dbl(C, C);
+    fp_sub(r.y, Y3, C);
+    r.x = X3;
+    fp_dbl(r.z, t);
+}
+
+// Complete Jacobian + affine addition (add-or-double semantics, infinity-aware).
+KZG_G1_MID void g1_add_mixed(G1Jac &r, const G1Jac &a, const G1Affine &b) {
+    if (g1a_is_inf(b)) { r = a; return; }
+    if (g1_is_inf(a)) { g1_from_affine(r, b); return; }
+    Fp Z1Z1, U2, S2, H, R, HH, HHH, V, t;
+    fp_sqr(Z1Z1, a.z);
+    fp_mul(U2, b.x, Z1Z1);
+    fp_mul(S2, b.y, a.z); fp_mul(S2, S2, Z1Z1);
+    fp_sub(H, U2, a.x);
+    fp_sub(R, S2, a.y);
+    if (fp_is_zero(H)) {
+        if (fp_is_zero(R)) { G1Jac d = a; g1_dbl(r, d); } else { r = g1_inf(); }
+        return;
+    }
+    fp_sqr(HH, H); fp_mul(HHH, H, HH); fp_mul(V, a.x, HH);
+    Fp X3, Y3;
+    fp_sqr(X3, R); fp_sub(X3, X3, HHH); fp_sub(X3, X3, V); fp_sub(X3, X3, V);
+    fp_sub(t, V, X3); fp_mul(Y3, R, t);
+    fp_mul(t, a.y, HHH); fp_sub(Y3, Y3, t);
+    fp_mul(r.z, a.z, H);
+    r.x = X3; r.y = Y3;
+}
+
+// Complete Jacobian + Jacobian addition.
+KZG_G1_MID void g1_add(G1Jac &r, const G1Jac &a, const G1Jac &b) {
+    if (g1_is_inf(a)) { r = b; return; }
+    if (g1_is_inf(b)) { r = a; return; }
+    Fp Z1Z1, Z2Z2, U1, U2, S1, S2, H, R, HH, HHH, V, t;
+    fp_sqr(Z1Z1, a.z); fp_sqr(Z2Z2, b.z);
+    fp_mul(U1, a.x, Z2Z2); fp_mul(U2, b.x, Z1Z1);
+    fp_mul(S1, a.y, b.z); fp_mul(S1, S1, Z2Z2);
+    fp_mul(S2, b.y, a.z); fp_mul(S2, S2, Z1Z1);
+    fp_sub(H, U2, U1);
+    fp_sub(R, S2, S1);
+    if (fp_is_zero(H)) {
+        if (fp_is_zero(R)) { G1Jac d = a; g1_dbl(r, d); } else { r = g1_inf(); }
+        return;
+    }
+    fp_sqr(HH, H); fp_mul(HHH, H, HH); fp_mul(V, U1, HH);
+    Fp X3, Y3, Z3;
+    fp_sqr(X3, R); fp_sub(X3, X3, HHH); fp_sub(X3, X3, V); fp_sub(X3, X3, V);
+    fp_sub(t, V, X3); fp_mul(Y3, R, t);
+    fp_mul(t, S1, HHH); fp_sub(Y3, Y3, t);
+    fp_mul(Z3, a.z, b.z); fp_mul(Z3, Z3, H);
+    r.x = X3; r.y = Y3; r.z = Z3;
+}
+
+KZG_G1_MID void g1_to_affine(G1Affine &r, const G1Jac &a) {
+    if (g1_is_inf(a)) { r = g1a_inf(); return; }
+    Fp zi, zi2, zi3;
+    fp_inv(zi, a.z); fp_sqr(zi2, zi); fp_mul(zi3, zi2, zi);
+    fp_mul(r.x, a.x, zi2); fp_mul(r.y, a.y, zi3);
+}
+
+// [k]P, k given as 8 little-endian 32-bit words, processing `nwords` words MSB first (double-and-add).
+KZG_HD void g1_mul_words(G1Jac &r, const G1Affine &p, const uint32_t *k, int nwords) {
+    G1Jac acc = g1_inf();
+    for (int w = nwords - 1; w >= 0; w--) {
+        uint32_t x = k[w];
+        for (int b = 0; b < 32; b++) {
+            g1_dbl(acc, acc);
+            if (x >> 31) g1_add_mixed(acc, acc, p);
+            x <<= 1;
+        }
+    }
+    r = acc;
+}
+
+// [r]P == infinity: the predicate blst_p1_in_g1 decides (utils.rs:303).
+KZG_HD bool g1_in_subgroup(const G1Affine &p) {
+    const uint32_t rw[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    G1Jac t;
+    g1_mul_words(t, p, rw, 8);
+    return g1_is_inf(t);
+}
+
+// ZCash compressed encoding of an affine point ((0,0) = infinity)
+KZG_HD void g1_compress_affine(uint8_t *out, const G1Affine &p) {
+    if (g1a_is_inf(p)) {
+        for (int i = 0; i < 48; i++) out[i] = 0;
+        out[0] = 0xc0;
+        return;
+    }
+    fp_to_be48(out, p.x);
+    out[0] |= (uint8_t)(0x80 | (fp_is_lex_largest(p.y) ? 0x20 : 0));
+}
+
+// Decode 48 compressed bytes.  Returns 0 ok, 1 bad encoding, 2 not on curve (blst_p1_uncompress rules:
+// compression bit required; infinity must be exactly 0xc0 00..00; x < p; x^3+4 must be a square).
+KZG_HD int g1_decompress(G1Affine &r, const uint8_t *in) {
+    const uint8_t b0 = in[0];
+    if (!(b0 & 0x80)) return 1;
+    if (b0 & 0x40) {
+        uint32_t acc = b0 & 0x3f;
+        for (int i = 1; i < 48; i++) acc |= in[i];
+        if (acc) return 1;
+        r = g1a_inf();
+        return 0;
+    }
+    Fp x, y, y2;
+    if (!fp_from_be48(x, in, true)) return 1;
+    const uint32_t b4[NFP] = FP_B_INIT;
+    Fp four; for (int i = 0; i < NFP; i++) four.l[i] = b4[i];
+    fp_sqr(y2, x); fp_mul(y2, y2, x); fp_add(y2, y2, four);
+    if (!fp_sqrt(y, y2)) return 2;
+    bool want_large = (b0 & 0x20) != 0;
+    if (fp_is_lex_largest(y) != want_large) fp_neg(y, y);
+    r.x = x; r.y = y;
+    return 0;
+}
+
+}  // namespace kzg

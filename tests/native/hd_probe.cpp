@@ -1,0 +1,77 @@
+// Host build (g++) of the DEVICE math headers under kzg_rust_amd/csrc, exposed through a tiny C ABI so
+// that tests/test_device_math_host.py can compare them with the CPU oracle on the build box (no GPU).
+// Test infrastructure only: this file is never part of libkzg355.so.
+#include "../../kzg_rust_amd/csrc/field.h"
+#include "../../kzg_rust_amd/csrc/tower.h"
+#include "../../kzg_rust_amd/csrc/g1.h"
+#include "../../kzg_rust_amd/csrc/pairing.h"
+#include "../../kzg_rust_amd/csrc/sha256.h"
+#include <vector>
+using namespace kzg;
+extern "C" {
+int hd_fp_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
+    Fp x, y, r;
+    if (!fp_from_be48(x, a, false) || !fp_from_be48(y, b, false)) return 1;
+    switch (op) {
+        case 0: fp_add(r, x, y); break; case 1: fp_sub(r, x, y); break; case 2: fp_mul(r, x, y); break;
+        case 3: fp_inv(r, x); break; case 4: if (!fp_sqrt(r, x)) return 2; break;
+        case 5: fp_neg(r, x); break; case 6: fp_dbl(r, x); break;
+        case 7: { out[0] = fp_is_lex_largest(x); return 0; }
+        default: return 1;
+    }
+    fp_to_be48(out, r); return 0;
+}
+int hd_fr_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
+    Fr x, y, r; uint32_t w[8];
+    be32_to_words(w, a); fr_from_words(x, w); be32_to_words(w, b); fr_from_words(y, w);
+    switch (op) {
+        case 0: fr_add(r, x, y); break; case 1: fr_sub(r, x, y); break; case 2: fr_mul(r, x, y); break;
+        case 3: fr_inv(r, x); break;
+        case 4: { be32_to_words(w, a); out[0] = fr_words_canonical(w); return 0; }
+        default: return 1;
+    }
+    fr_to_be32(out, r); return 0;
+}
+// 0 ok / 1 bad encoding / 2 not on curve / 3 not in subgroup ; out = recompressed point
+int hd_g1_validate(uint8_t *out, const uint8_t *in, int check_subgroup) {
+    G1Affine p; int rc = g1_decompress(p, in);
+    if (rc) return rc;
+    if (check_subgroup && !g1a_is_inf(p) && !g1_in_subgroup(p)) return 3;
+    g1_compress_affine(out, p); return 0;
+}
+// out = [k]P + Q (Q optional), compressed; k = 32 big-endian bytes
+int hd_g1_mul_add(uint8_t *out, const uint8_t *p, const uint8_t *k_be, const uint8_t *q) {
+    G1Affine pa, qa, ra; G1Jac r; uint32_t w[8];
+    if (g1_decompress(pa, p)) return 1;
+    be32_to_words(w, k_be);
+    g1_mul_words(r, pa, w, 8);
+    if (q) { if (g1_decompress(qa, q)) return 1; g1_add_mixed(r, r, qa); }
+    g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
+}
+// out = P + Q using the Jacobian+Jacobian routine (both lifted with a non-trivial z)
+int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
+    G1Affine pa, qa, ra; G1Jac pj, qj, r;
+    if (g1_decompress(pa, p) || g1_decompress(qa, q)) return 1;
+    g1_from_affine(pj, pa); g1_from_affine(qj, qa);
+    // re-randomise z: (x z^2, y z^3, z) with z = 5 (Montgomery form of some element: use pa.x+1 if nonzero)
+    Fp z = fp_one(); fp_add(z, z, z); fp_add(z, z, fp_one());
+    if (!g1_is_inf(pj)) { Fp z2, z3; fp_sqr(z2, z); fp_mul(z3, z2, z); fp_mul(pj.x, pj.x, z2); fp_mul(pj.y, pj.y, z3); pj.z = z; }
+    g1_add(r, pj, qj);
+    g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
+}
+int hd_g2_decompress(const uint8_t *in) { G2Affine q; return g2_decompress(q, in); }
+// e(p1,q1) == e(p2,q2) via precomputed lines: ML(q1,-p1) * ML(q2,p2)
+int hd_pairings_verify(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {
+    G1Affine a, b; G2Affine qa, qb;
+    if (g1_decompress(a, p1) || g1_decompress(b, p2) || g2_decompress(qa, q1) || g2_decompress(qb, q2)) return 1;
+    std::vector<LineCoeff> l1(N_LINES), l2(N_LINES);
+    Fp12 f;
+    G1Affine an; g1a_neg(an, a); if (g1a_is_inf(a)) an = a;
+    if (g2a_is_inf(qa)) an = g1a_inf(); else precompute_lines(l1.data(), qa);
+    if (g2a_is_inf(qb)) b = g1a_inf(); else precompute_lines(l2.data(), qb);
+    miller_loop_pair(f, l1.data(), an, l2.data(), b);
+    *ok = final_exp_is_one(f) ? 1 : 0;
+    return 0;
+}
+void hd_sha256(uint8_t *out, const uint8_t *msg, uint64_t len) { sha256_bytes(out, msg, len); }
+}
