@@ -1,0 +1,136 @@
+/*
+ * kzg355.h -- C ABI of libkzg355.so, the MI355X-native (HIP / gfx950) KZG-4844 engine.
+ *
+ * This is the drop-in boundary for the hot path of pawanjay176/kzg_rust: every entry point below
+ * replaces one associated function of `pub struct Kzg` (reference src/kzg.rs:983-1079) -- i.e. it sits
+ * one level ABOVE the 35 blst `extern "C"` symbols the reference binds today,
+ * because per-field-op FFI is too fine-grained for a GPU.  Bytes in, bytes out: no blst limb layouts,
+ * no torch types, plain pointers and sizes.  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * `impl Kzg` forwards a maintainer would add.
+ *
+ * Status codes mirror `enum Error` (src/kzg.rs:10-22).  The reference's tests only distinguish
+ * Ok / Err (src/lib.rs:47-50), so Ok-vs-Err and the returned bytes / bool are exact; the particular
+ * non-zero code is best effort.  Outputs are written only on KZG355_OK.
+ *
+ * Ownership: the caller owns every buffer; the library copies in and retains nothing after return.
+ * kzg355_settings is created by a load function, destroyed by kzg355_free_trusted_setup, immutable in
+ * between, and may be used from several host threads at once (each call takes a private workspace +
+ * HIP stream from a pool inside the handle) -- the reference takes `&KzgSettings` everywhere.
+ *
+ * There is NO CPU fallback: every function fails with KZG355_NO_DEVICE if no HIP device is usable.
+ */
+#ifndef KZG355_H
+#define KZG355_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZG355_BYTES_PER_FIELD_ELEMENT 32   /* src/consts.rs:5  */
+#define KZG355_BYTES_PER_COMMITMENT 48      /* src/consts.rs:8  */
+#define KZG355_BYTES_PER_PROOF 48           /* src/consts.rs:11 */
+#define KZG355_FIELD_ELEMENTS_PER_BLOB 4096 /* src/consts.rs:13 */
+#define KZG355_BYTES_PER_BLOB 131072        /* src/consts.rs:16 */
+#define KZG355_BYTES_PER_G1 48              /* src/consts.rs:31 */
+#define KZG355_BYTES_PER_G2 96              /* src/consts.rs:34 */
+#define KZG355_NUM_G2_POINTS 65             /* src/consts.rs:37 */
+#define KZG355_BYTES_PER_RECORD 160         /* C(48) | z(32) | y(32) | proof(48): one r-transcript record, utils.rs:454-463 */
+
+enum {
+    KZG355_OK = 0,
+    KZG355_BADARGS = 1,               /* Error::BadArgs            kzg.rs:13 */
+    KZG355_INTERNAL = 2,              /* Error::InternalError      kzg.rs:15 */
+    KZG355_INVALID_BYTES_LENGTH = 3,  /* Error::InvalidBytesLength kzg.rs:17 */
+    KZG355_INVALID_HEX = 4,           /* Error::InvalidHexFormat   kzg.rs:19 */
+    KZG355_INVALID_TRUSTED_SETUP = 5, /* Error::InvalidTrustedSetup kzg.rs:21 */
+    KZG355_NO_DEVICE = 6              /* no usable HIP device / HIP runtime error (no reference counterpart) */
+};
+
+typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings` (kzg.rs:28-40) */
+
+/* ---- trusted setup ---------------------------------------------------------------------------- */
+/* Kzg::load_trusted_setup (kzg.rs:1005 -> 45-78 -> 833-899).  g1: n1*48 bytes, g2: n2*96 bytes, compressed,
+ * Lagrange form, file order.  n1 != 4096 or n2 != 65 -> INVALID_TRUSTED_SETUP; bad point / monomial form -> BADARGS.
+ * Builds the device-resident tables (roots of unity, bit-reversed G1 table and its per-window multiples,
+ * Miller-loop line tables of the two G2 points the verify path uses). */
+int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
+/* Kzg::load_trusted_setup_file (kzg.rs:995 -> 906-979): "4096\n65\n" + hex lines. */
+int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out);
+/* Drop for KzgSettings. */
+void kzg355_free_trusted_setup(kzg355_settings *s);
+
+/* ---- the reference's seven operations, host buffers in / out ---------------------------------- */
+/* Kzg::blob_to_kzg_commitment (kzg.rs:1013 -> 401-406). blob: 131072 bytes. */
+int kzg355_blob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const kzg355_settings *s);
+/* Kzg::compute_kzg_proof (kzg.rs:1021 -> 446-457): returns proof and y = p(z). */
+int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uint8_t *blob, const uint8_t z_bytes[32], const kzg355_settings *s);
+/* Kzg::compute_blob_kzg_proof (kzg.rs:1030 -> 533-544). */
+int kzg355_compute_blob_kzg_proof(uint8_t proof_out[48], const uint8_t *blob, const uint8_t commitment[48], const kzg355_settings *s);
+/* Kzg::verify_kzg_proof (kzg.rs:1039 -> 429-443). */
+int kzg355_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_t z_bytes[32], const uint8_t y_bytes[32], const uint8_t proof[48], const kzg355_settings *s);
+/* Kzg::verify_blob_kzg_proof (kzg.rs:1050 -> 547-569). */
+int kzg355_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t commitment[48], const uint8_t proof[48], const kzg355_settings *s);
+/* Kzg::verify_blob_kzg_proof_batch (kzg.rs:1066 -> 637-693).  The Rust slices `&[Blob]`, `&[KzgCommitment]`,
+ * `&[KzgProof]` carry their own lengths; the shim passes all three so that the reference's length check
+ * (kzg.rs:644-651 -> BadArgs) is made on this side of the boundary too.  blobs: n_blobs*131072 contiguous bytes
+ * (the shim gathers the `Box`ed blobs into one staging buffer).  n == 0 -> ok = true (kzg.rs:653-655). */
+int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,
+                                       const uint8_t *proofs, size_t n_proofs, const kzg355_settings *s);
+
+/* ---- throughput extensions (same semantics, many independent units per call) ------------------ */
+/* n independent blob_to_kzg_commitment calls.  status[i] per blob (may be NULL); returns first non-OK status. */
+int kzg355_blob_to_kzg_commitment_many(uint8_t *out /* n*48 */, int *status /* n or NULL */, const uint8_t *blobs, size_t n, const kzg355_settings *s);
+/* n independent compute_blob_kzg_proof calls. */
+int kzg355_compute_blob_kzg_proof_many(uint8_t *out /* n*48 */, int *status, const uint8_t *blobs, const uint8_t *commitments, size_t n, const kzg355_settings *s);
+/* `groups` independent verify_blob_kzg_proof_batch calls of n_per_group blobs each, executed by ONE set of kernel
+ * launches.  ok[g] / status[g] are per group.  Inputs are group-major contiguous. */
+int kzg355_verify_blob_kzg_proof_batch_many(bool *ok /* groups */, int *status /* groups */, const uint8_t *blobs, const uint8_t *commitments,
+                                            const uint8_t *proofs, size_t n_per_group, size_t groups, const kzg355_settings *s);
+
+/* ---- device-resident inputs (what bench.py times: blobs already in HBM) ----------------------- */
+/* As above, but d_* are DEVICE pointers (hipMalloc / torch tensors .data_ptr()) on the settings' device.
+ * ok / status are host pointers.  Synchronous: returns when the verdicts are on the host. */
+int kzg355_verify_blob_kzg_proof_batch_many_device(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                                   const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *s);
+int kzg355_blob_to_kzg_commitment_many_device(uint8_t *out /* host n*48 */, int *status /* host n or NULL */, const uint8_t *d_blobs, size_t n,
+                                              const kzg355_settings *s);
+int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                              size_t n, const kzg355_settings *s);
+
+/* ---- sharded verification (one process per GPU; the exchange between the two stages is the caller's
+ *      all-gather of the 160-byte records, e.g. torch.distributed over RCCL) --------------------------- */
+/* Stage 1, per rank, over its contiguous shard of every batch: `groups` batches, n_local blobs of each (group-major:
+ * blob (g, i) at index g*n_local + i).  Validates C_i / proof_i, blob -> field elements, Fiat-Shamir challenge z_i
+ * (kzg.rs:298-339), y_i = p_i(z_i) (kzg.rs:346-389).  Writes the records C_i|z_i|y_i|proof_i -- byte for byte the body of
+ * the r-transcript (utils.rs:454-463) -- to d_records (device, same indexing), and per-batch status (KZG355_OK or
+ * KZG355_BADARGS) to status[g] (host).  Returns the first non-OK status. */
+int kzg355_verify_shard_records_device(uint8_t *d_records /* groups*n_local*160, device */, int *status /* groups, host */,
+                                       const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, size_t n_local,
+                                       size_t groups, const kzg355_settings *s);
+/* Stage 2, replicated on every rank, over ALL gathered records (device): `groups` batches of n records each
+ * (group-major).  r-powers (utils.rs:426-474), the three linear combinations and the pairing check (kzg.rs:579-627).
+ * n == 1 reproduces the single-blob path (kzg.rs:658); n == 0 is an error like kzg.rs:588-592. */
+int kzg355_verify_records_device(bool *ok /* groups */, int *status /* groups */, const uint8_t *d_records /* groups*n*160, device */,
+                                 size_t n, size_t groups, const kzg355_settings *s);
+
+/* ---- introspection ---------------------------------------------------------------------------- */
+/* Device ordinal the handle lives on, and average duration in milliseconds of the most recent launch of a named
+ * kernel family on that handle ("verify_eval", "msm_bucket", ...), measured with HIP events on the launch stream;
+ * returns a negative number if that kernel has not run.  Used by bench.py for the roofline line. */
+int kzg355_settings_device(const kzg355_settings *s);
+double kzg355_last_kernel_ms(const kzg355_settings *s, const char *kernel_family);
+/* Accumulated HIP-event time and launch count of a kernel family since timing was enabled / last reset. 0 on success. */
+int kzg355_kernel_ms_stats(const kzg355_settings *s, const char *kernel_family, double *total_ms, long *launches);
+void kzg355_reset_kernel_stats(kzg355_settings *s);
+/* Enable (1) / disable (0) per-kernel HIP-event timing on the handle (off by default: it adds event records). */
+void kzg355_set_kernel_timing(kzg355_settings *s, int enabled);
+const char *kzg355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZG355_H */

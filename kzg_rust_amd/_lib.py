@@ -1,0 +1,80 @@
+"""Loader for libkzg355.so (the HIP engine).  There is deliberately no fallback: if the shared library
+is missing or cannot be loaded, importing fails loudly -- the product path never routes through a CPU
+implementation."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkzg355.so")
+
+
+class KzgLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise KzgLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C kzg_rust_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as
+    # /opt/rocm).  If torch is going to be used in this process (device tensors handed to the *_device entry points,
+    # torch.distributed for the sharded path) it must be imported BEFORE libkzg355.so so that both bind to the same
+    # runtime; loading ours first leaves torch unable to see the GPU.  Pure C / Rust consumers simply get /opt/rocm.
+    if os.environ.get("KZG355_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise KzgLibraryMissing(f"cannot load {LIB_PATH}: {e}") from e
+    vp, sz, u8p, ip = C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int)
+    bp = C.POINTER(C.c_bool)
+    sigs = {
+        "kzg355_load_trusted_setup": [u8p, sz, u8p, sz, C.POINTER(vp)],
+        "kzg355_load_trusted_setup_file": [u8p, C.POINTER(vp)],
+        "kzg355_blob_to_kzg_commitment": [u8p, u8p, vp],
+        "kzg355_compute_kzg_proof": [u8p, u8p, u8p, u8p, vp],
+        "kzg355_compute_blob_kzg_proof": [u8p, u8p, u8p, vp],
+        "kzg355_verify_kzg_proof": [bp, u8p, u8p, u8p, u8p, vp],
+        "kzg355_verify_blob_kzg_proof": [bp, u8p, u8p, u8p, vp],
+        "kzg355_verify_blob_kzg_proof_batch": [bp, u8p, sz, u8p, sz, u8p, sz, vp],
+        "kzg355_blob_to_kzg_commitment_many": [u8p, ip, u8p, sz, vp],
+        "kzg355_compute_blob_kzg_proof_many": [u8p, ip, u8p, u8p, sz, vp],
+        "kzg355_verify_blob_kzg_proof_batch_many": [bp, ip, u8p, u8p, u8p, sz, sz, vp],
+        "kzg355_verify_blob_kzg_proof_batch_many_device": [bp, ip, vp, vp, vp, sz, sz, vp],
+        "kzg355_blob_to_kzg_commitment_many_device": [u8p, ip, vp, sz, vp],
+        "kzg355_compute_blob_kzg_proof_many_device": [u8p, ip, vp, vp, sz, vp],
+        "kzg355_verify_shard_records_device": [vp, ip, vp, vp, vp, sz, sz, vp],
+        "kzg355_verify_records_device": [bp, ip, vp, sz, sz, vp],
+        "kzg355_kernel_ms_stats": [vp, u8p, C.POINTER(C.c_double), C.POINTER(C.c_long)],
+        "kzg355_settings_device": [vp],
+        "kzg355_set_kernel_timing": [vp, C.c_int],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.kzg355_free_trusted_setup.argtypes = [vp]
+    lib.kzg355_free_trusted_setup.restype = None
+    lib.kzg355_set_kernel_timing.restype = None
+    lib.kzg355_reset_kernel_stats.argtypes = [vp]
+    lib.kzg355_reset_kernel_stats.restype = None
+    lib.kzg355_last_kernel_ms.argtypes = [vp, u8p]
+    lib.kzg355_last_kernel_ms.restype = C.c_double
+    lib.kzg355_version.restype = C.c_char_p
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "kzg355_load_trusted_setup", "kzg355_load_trusted_setup_file", "kzg355_free_trusted_setup",
+    "kzg355_blob_to_kzg_commitment", "kzg355_compute_kzg_proof", "kzg355_compute_blob_kzg_proof",
+    "kzg355_verify_kzg_proof", "kzg355_verify_blob_kzg_proof", "kzg355_verify_blob_kzg_proof_batch",
+    "kzg355_blob_to_kzg_commitment_many", "kzg355_compute_blob_kzg_proof_many", "kzg355_verify_blob_kzg_proof_batch_many",
+    "kzg355_verify_blob_kzg_proof_batch_many_device", "kzg355_blob_to_kzg_commitment_many_device",
+    "kzg355_compute_blob_kzg_proof_many_device", "kzg355_verify_shard_records_device", "kzg355_verify_records_device",
+    "kzg355_settings_device", "kzg355_last_kernel_ms", "kzg355_set_kernel_timing", "kzg355_version",
+    "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
+]

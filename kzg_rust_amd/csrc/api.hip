@@ -1,0 +1,626 @@
+// api.hip -- host side of libkzg355.so: the C ABI of include/kzg355.h on top of the HIP kernels.
+// Mirrors the control flow of the reference's `impl Kzg` forwards and the functions behind them
+// (src/kzg.rs:401-693, 833-979): argument checks and early exits happen here, all arithmetic on the device.
+// There is no CPU fallback: without a usable HIP device every entry point returns KZG355_NO_DEVICE.
+#include "../../include/kzg355.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace kzg;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            if (getenv("KZG355_DEBUG")) fprintf(stderr, "kzg355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return KZG355_NO_DEVICE;                                                                   \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return KZG355_OK;
+        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return KZG355_NO_DEVICE; }
+        cap = want;
+        return KZG355_OK;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return KZG355_OK;
+        if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return KZG355_NO_DEVICE; }
+        cap = want;
+        return KZG355_OK;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Per-call scratch: a private stream plus grow-on-demand device buffers.  One workspace serves one call at a time;
+// concurrent host threads get different workspaces from the pool in the settings handle.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small;
+    PinBuf h_ok, h_err, h_out;
+    hipEvent_t ev[32];
+    bool ev_ok = false;
+    ~Workspace() {
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small}) b->release();
+        h_ok.release(); h_err.release(); h_out.release();
+        if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace
+
+struct kzg355_settings {
+    int device = 0;
+    DeviceTables t{};
+    DevBuf roots, msm_table, lines, lines_inf, g1_first2;
+    std::mutex mu;
+    std::vector<Workspace *> pool;
+    bool timing = false;
+    struct KStat { double last = -1, total = 0; long count = 0; };
+    std::map<std::string, KStat> last_ms;
+};
+
+namespace {
+
+Workspace *ws_acquire(kzg355_settings *s) {
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->pool.empty()) { Workspace *w = s->pool.back(); s->pool.pop_back(); return w; }
+    }
+    Workspace *w = new Workspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    bool ok = true;
+    for (auto &e : w->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    w->ev_ok = ok;
+    if (!ok) { delete w; return nullptr; }
+    return w;
+}
+void ws_release(kzg355_settings *s, Workspace *w) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->pool.push_back(w);
+}
+struct WsGuard {
+    kzg355_settings *s; Workspace *w;
+    WsGuard(const kzg355_settings *cs) : s(const_cast<kzg355_settings *>(cs)), w(nullptr) {
+        if (s && hipSetDevice(s->device) == hipSuccess) w = ws_acquire(s);
+    }
+    ~WsGuard() { if (w) ws_release(s, w); }
+};
+
+// Optional per-kernel-family timing with HIP events on the launch stream (kzg355_set_kernel_timing).
+struct Timed {
+    kzg355_settings *s; Workspace *w; std::vector<std::pair<std::string, int>> marks; int n = 0;
+    Timed(kzg355_settings *s_, Workspace *w_) : s(s_), w(w_) {}
+    void begin(const char *name) {
+        if (!s->timing || n + 2 > 32) return;
+        hipEventRecord(w->ev[n], w->stream); marks.push_back({name, n}); n++;
+    }
+    void end() {
+        if (!s->timing || marks.empty() || n >= 32) return;
+        hipEventRecord(w->ev[n], w->stream); n++;
+    }
+    void collect() {   // call after the stream has been synchronised
+        if (!s->timing) return;
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (auto &m : marks) {
+            float ms = 0;
+            if (m.second + 1 < n && hipEventElapsedTime(&ms, w->ev[m.second], w->ev[m.second + 1]) == hipSuccess) {
+                auto &k = s->last_ms[m.first]; k.last = ms; k.total += ms; k.count++;
+            }
+        }
+    }
+};
+
+int status_from_err(int err) {
+    if (err == 0) return KZG355_OK;
+    return KZG355_BADARGS;   // validate_kzg_g1 / bytes_to_bls_field failures are Error::BadArgs (utils.rs:268, 292, 304)
+}
+
+// ---- stage drivers (all asynchronous on w->stream) -------------------------------------------------
+int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total,
+               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err) {
+    int rc;
+    if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
+    tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
+    tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream); tm.end();
+    tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
+    return KZG355_OK;
+}
+int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_records, int npg, int groups, int check_zy, const G1Affine *d_pts,
+               int *d_err, int *d_ok) {
+    int rc;
+    const size_t n_total = (size_t)npg * groups;
+    if ((rc = w->scal_a.ensure(32 * n_total))) return rc;
+    if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
+    if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
+    if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
+    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
+    tm.begin("lincomb"); launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->pair_pts.as<G1Affine>(), w->stream); tm.end();
+    tm.begin("pairing"); launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream); tm.end();
+    return KZG355_OK;
+}
+
+int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, size_t npg, size_t groups,
+                            const kzg355_settings *cs) {
+    if (!cs || !ok) return KZG355_BADARGS;
+    if (groups == 0) return KZG355_OK;
+    if (npg == 0) {   // kzg.rs:653-655
+        for (size_t g = 0; g < groups; g++) { ok[g] = true; if (status) status[g] = KZG355_OK; }
+        return KZG355_OK;
+    }
+    if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    const int n_total = (int)(npg * groups), G = (int)groups;
+    int rc;
+    if ((rc = w->records.ensure((size_t)RECORD_BYTES * n_total))) return rc;
+    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * (size_t)n_total))) return rc;
+    if ((rc = w->err.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->ok.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->h_ok.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * (size_t)G))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
+    Timed tm(s, w);
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, (int)npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
+    if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), (int)npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (int i = 0; i < G; i++) {
+        int st = status_from_err(w->h_err.as<int>()[i]);
+        if (status) status[i] = st;
+        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
+        else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
+int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes) {
+    int rc = dst.ensure(bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, w->stream));
+    return KZG355_OK;
+}
+
+// MSM over digits already on the device -> 48-byte outputs on the host
+int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, uint8_t *out_host) {
+    int rc;
+    if ((rc = w->partials.ensure(sizeof(G1Jac) * (size_t)n * MSM_WINDOWS))) return rc;
+    if ((rc = w->out48.ensure(48 * (size_t)n))) return rc;
+    if ((rc = w->h_out.ensure(48 * (size_t)n))) return rc;
+    tm.begin("msm_bucket"); launch_msm_bucket(w->digits.as<uint8_t>(), s->t, n, w->partials.as<G1Jac>(), w->stream); tm.end();
+    tm.begin("msm_finalize"); launch_msm_finalize(w->partials.as<G1Jac>(), n, w->out48.as<uint8_t>(), w->stream); tm.end();
+    HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 48 * (size_t)n, hipMemcpyDeviceToHost, w->stream));
+    (void)out_host;
+    return KZG355_OK;
+}
+
+int commit_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, size_t n, const kzg355_settings *cs) {
+    if (!cs || !out) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    int rc;
+    if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
+    if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
+    Timed tm(s, w);
+    tm.begin("digits"); launch_digits_from_blobs(d_blobs, (int)n, w->digits.as<uint8_t>(), w->err.as<int>(), w->stream); tm.end();
+    if ((rc = msm_to_host(s, w, tm, (int)n, out))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (size_t i = 0; i < n; i++) {
+        int st = status_from_err(w->h_err.as<int>()[i]);
+        if (status) status[i] = st;
+        if (st == KZG355_OK) memcpy(out + 48 * i, w->h_out.as<uint8_t>() + 48 * i, 48);
+        else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
+// proofs for n blobs at challenge points already in w->z (Montgomery); err accumulates per blob
+int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, int n) {
+    int rc;
+    if ((rc = w->y.ensure(sizeof(Fr) * (size_t)n))) return rc;
+    if ((rc = w->q.ensure(sizeof(Fr) * (size_t)n * N_FE))) return rc;
+    if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
+    tm.begin("quotient"); launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<Fr>(), w->err.as<int>(), w->stream); tm.end();
+    tm.begin("digits"); launch_digits_from_fr(w->q.as<Fr>(), n, w->digits.as<uint8_t>(), w->stream); tm.end();
+    return msm_to_host(s, w, tm, n, nullptr);
+}
+
+int blob_proof_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs) {
+    if (!cs || !out) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    int rc;
+    if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
+    if ((rc = w->z.ensure(sizeof(Fr) * n))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
+    Timed tm(s, w);
+    // compute_challenge validates the commitment (kzg.rs:321-323); one "group" per blob so errors stay per blob
+    tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end();
+    tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream); tm.end();
+    if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (size_t i = 0; i < n; i++) {
+        int st = status_from_err(w->h_err.as<int>()[i]);
+        if (status) status[i] = st;
+        if (st == KZG355_OK) memcpy(out + 48 * i, w->h_out.as<uint8_t>() + 48 * i, 48);
+        else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
+int hexval(int ch) { return ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1; }
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montgomery, fixed-base Pippenger, precomputed-line pairing)"; }
+
+int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out) {
+    if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
+    if (n1 != (size_t)N_FE || n2 != (size_t)N_G2) return KZG355_INVALID_TRUSTED_SETUP;   // kzg.rs:49-62 (843: BadArgs)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
+    int dev = 0;
+    if (const char *e = getenv("KZG355_DEVICE")) dev = atoi(e);
+    else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    HIPCHK(hipSetDevice(dev));
+    kzg355_settings *s = new kzg355_settings();
+    s->device = dev;
+    DevBuf g1b, g2b, err;
+    int rc = KZG355_OK;
+    auto fail = [&](int code) { g1b.release(); g2b.release(); err.release(); kzg355_free_trusted_setup(s); return code; };
+    if ((rc = s->roots.ensure(sizeof(Fr) * N_FE))) return fail(rc);
+    if ((rc = s->msm_table.ensure(sizeof(G1Affine) * (size_t)N_FE * MSM_WINDOWS))) return fail(rc);
+    if ((rc = s->lines.ensure(sizeof(LineCoeff) * 3 * N_LINES))) return fail(rc);
+    if ((rc = s->lines_inf.ensure(sizeof(int) * 3))) return fail(rc);
+    if ((rc = s->g1_first2.ensure(sizeof(G1Affine) * 2))) return fail(rc);
+    if ((rc = g1b.ensure(48 * n1))) return fail(rc);
+    if ((rc = g2b.ensure(96 * n2))) return fail(rc);
+    if ((rc = err.ensure(sizeof(int)))) return fail(rc);
+    s->t.roots = s->roots.as<Fr>();
+    s->t.msm_table = s->msm_table.as<G1Affine>();
+    s->t.lines = s->lines.as<LineCoeff>();
+    s->t.lines_inf = s->lines_inf.as<int>();
+    s->t.g1_first2 = s->g1_first2.as<G1Affine>();
+    if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_NO_DEVICE);
+    int herr = 0;
+    if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
+    g1b.release(); g2b.release(); err.release();
+    *out = s;
+    return KZG355_OK;
+}
+
+int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out) {
+    if (!path || !out) return KZG355_BADARGS;
+    FILE *f = fopen(path, "r");
+    if (!f) return KZG355_INVALID_TRUSTED_SETUP;                 // kzg.rs:907-909
+    char line[1024];
+    auto read_count = [&](size_t *v) {
+        if (!fgets(line, sizeof line, f)) return false;
+        char *end = nullptr;
+        unsigned long x = strtoul(line, &end, 10);
+        if (end == line) return false;
+        while (*end == ' ' || *end == '\t' || *end == '\r' || *end == '\n') end++;
+        if (*end) return false;
+        *v = x;
+        return true;
+    };
+    size_t n1 = 0, n2 = 0;
+    if (!read_count(&n1) || n1 != (size_t)N_FE) { fclose(f); return KZG355_INVALID_TRUSTED_SETUP; }   // kzg.rs:916-932
+    if (!read_count(&n2) || n2 != (size_t)N_G2) { fclose(f); return KZG355_INVALID_TRUSTED_SETUP; }   // kzg.rs:934-950
+    std::vector<uint8_t> g1(48 * n1), g2(96 * n2);
+    int rc = KZG355_OK;
+    for (size_t i = 0; i < n1 + n2 && rc == KZG355_OK; i++) {
+        const size_t want = i < n1 ? 48 : 96;
+        uint8_t *dst = i < n1 ? &g1[48 * i] : &g2[96 * (i - n1)];
+        if (!fgets(line, sizeof line, f)) { rc = KZG355_INVALID_TRUSTED_SETUP; break; }                // kzg.rs:957-959
+        char *p = line; size_t len = strlen(p);
+        while (len && (p[len - 1] == '\n' || p[len - 1] == '\r' || p[len - 1] == ' ' || p[len - 1] == '\t')) p[--len] = 0;
+        if (len >= 2 && p[0] == '0' && p[1] == 'x') { p += 2; len -= 2; }                                // hex_to_bytes kzg.rs:82-86
+        if (len % 2) { rc = KZG355_INVALID_HEX; break; }
+        if (len != 2 * want) { rc = KZG355_BADARGS; break; }
+        for (size_t k = 0; k < want; k++) {
+            const int hi = hexval(p[2 * k]), lo = hexval(p[2 * k + 1]);
+            if (hi < 0 || lo < 0) { rc = KZG355_INVALID_HEX; break; }
+            dst[k] = (uint8_t)(hi * 16 + lo);
+        }
+    }
+    fclose(f);
+    if (rc != KZG355_OK) return rc;
+    return kzg355_load_trusted_setup(g1.data(), n1, g2.data(), n2, out);
+}
+
+void kzg355_free_trusted_setup(kzg355_settings *s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    for (Workspace *w : s->pool) delete w;
+    s->pool.clear();
+    s->roots.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
+    delete s;
+}
+
+int kzg355_settings_device(const kzg355_settings *s) { return s ? s->device : -1; }
+void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
+double kzg355_last_kernel_ms(const kzg355_settings *cs, const char *family) {
+    kzg355_settings *s = const_cast<kzg355_settings *>(cs);
+    if (!s || !family) return -1.0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->last_ms.find(family);
+    return it == s->last_ms.end() ? -1.0 : it->second.last;
+}
+int kzg355_kernel_ms_stats(const kzg355_settings *cs, const char *family, double *total_ms, long *launches) {
+    kzg355_settings *s = const_cast<kzg355_settings *>(cs);
+    if (!s || !family || !total_ms || !launches) return KZG355_BADARGS;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->last_ms.find(family);
+    if (it == s->last_ms.end()) { *total_ms = 0; *launches = 0; return KZG355_OK; }
+    *total_ms = it->second.total; *launches = it->second.count;
+    return KZG355_OK;
+}
+void kzg355_reset_kernel_stats(kzg355_settings *s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->last_ms.clear();
+}
+
+// ---- device-resident entry points ---------------------------------------------------------------------
+int kzg355_verify_blob_kzg_proof_batch_many_device(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                                   const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *s) {
+    return verify_many_device_impl(ok, status, d_blobs, d_commitments, d_proofs, n_per_group, groups, s);
+}
+int kzg355_blob_to_kzg_commitment_many_device(uint8_t *out, int *status, const uint8_t *d_blobs, size_t n, const kzg355_settings *s) {
+    return commit_many_device_impl(out, status, d_blobs, n, s);
+}
+int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments, size_t n,
+                                              const kzg355_settings *s) {
+    return blob_proof_many_device_impl(out, status, d_blobs, d_commitments, n, s);
+}
+
+int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                       const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
+    if (!cs || !status) return KZG355_BADARGS;
+    for (size_t i = 0; i < groups; i++) status[i] = KZG355_OK;
+    if (n_local == 0 || groups == 0) return KZG355_OK;
+    if (n_local * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    int rc;
+    if ((rc = w->err.ensure(sizeof(int) * groups))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
+    Timed tm(s, w);
+    // any error poisons its batch, as the `?`s at kzg.rs:673-682 do for the call
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, nullptr, w->err.as<int>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (size_t i = 0; i < groups; i++) {
+        status[i] = status_from_err(w->h_err.as<int>()[i]);
+        if (status[i] != KZG355_OK && first == KZG355_OK) first = status[i];
+    }
+    return first;
+}
+
+int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
+    if (!cs || !ok) return KZG355_BADARGS;
+    if (groups == 0) return KZG355_OK;
+    if (n == 0) return KZG355_BADARGS;                           // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
+    if (n * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    int rc;
+    const int G = (int)groups;
+    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * n * groups))) return rc;
+    if ((rc = w->err.ensure(sizeof(int) * groups))) return rc;
+    if ((rc = w->ok.ensure(sizeof(int) * groups))) return rc;
+    if ((rc = w->h_ok.ensure(sizeof(int) * groups))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
+    Timed tm(s, w);
+    tm.begin("points_from_records"); launch_points_from_records(d_records, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
+    if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (int i = 0; i < G; i++) {
+        int st = status_from_err(w->h_err.as<int>()[i]);
+        if (status) status[i] = st;
+        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
+        else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
+// ---- host-buffer entry points (the drop-in surface) ------------------------------------------------------
+int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
+                                            size_t n_per_group, size_t groups, const kzg355_settings *cs) {
+    if (!cs || !ok) return KZG355_BADARGS;
+    const size_t n = n_per_group * groups;
+    if (n == 0) return verify_many_device_impl(ok, status, nullptr, nullptr, nullptr, n_per_group, groups, cs);
+    if (!blobs || !commitments || !proofs) return KZG355_BADARGS;
+    // stage the inputs in a workspace of their own; the compute call below takes a second one from the pool
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    Workspace *w = g.w;
+    int rc;
+    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
+    if ((rc = stage_to_device(w, w->commitments, commitments, 48 * n))) return rc;
+    if ((rc = stage_to_device(w, w->proofs, proofs, 48 * n))) return rc;
+    HIPCHK(hipStreamSynchronize(w->stream));
+    return verify_many_device_impl(ok, status, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), n_per_group, groups, cs);
+}
+
+int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,
+                                       const uint8_t *proofs, size_t n_proofs, const kzg355_settings *s) {
+    if (!s || !ok) return KZG355_BADARGS;
+    if (n_blobs != n_commitments || n_commitments != n_proofs) return KZG355_BADARGS;   // kzg.rs:644-651
+    if (n_blobs == 0) { *ok = true; return KZG355_OK; }                                   // kzg.rs:653-655
+    // n == 1 is the single-blob path in the reference (kzg.rs:658-660); the batch equation with r^0 = 1 is the same check
+    bool r = false; int st = KZG355_OK;
+    int rc = kzg355_verify_blob_kzg_proof_batch_many(&r, &st, blobs, commitments, proofs, n_blobs, 1, s);
+    if (rc == KZG355_OK) *ok = r;
+    return rc;
+}
+
+int kzg355_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t commitment[48], const uint8_t proof[48], const kzg355_settings *s) {
+    return kzg355_verify_blob_kzg_proof_batch(ok, blob, 1, commitment, 1, proof, 1, s);   // kzg.rs:547-569
+}
+
+int kzg355_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_t z_bytes[32], const uint8_t y_bytes[32], const uint8_t proof[48],
+                            const kzg355_settings *cs) {
+    if (!cs || !ok || !commitment || !z_bytes || !y_bytes || !proof) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    uint8_t rec[RECORD_BYTES];
+    memcpy(rec, commitment, 48); memcpy(rec + 48, z_bytes, 32); memcpy(rec + 80, y_bytes, 32); memcpy(rec + 112, proof, 48);
+    int rc;
+    if ((rc = w->records.ensure(RECORD_BYTES))) return rc;
+    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2))) return rc;
+    if ((rc = w->err.ensure(sizeof(int)))) return rc;
+    if ((rc = w->ok.ensure(sizeof(int)))) return rc;
+    if ((rc = w->h_ok.ensure(sizeof(int)))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int)))) return rc;
+    HIPCHK(hipMemcpyAsync(w->records.p, rec, RECORD_BYTES, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
+    Timed tm(s, w);
+    const uint8_t *d_rec = w->records.as<uint8_t>();
+    // bytes_to_kzg_commitment / bytes_to_kzg_proof (kzg.rs:436, 439): full validation incl. subgroup
+    tm.begin("validate_points"); launch_validate_points(d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
+    // z, y canonical checks (kzg.rs:437-438) happen in k_rpowers (check_zy = 1)
+    if ((rc = run_stage2(s, w, tm, d_rec, 1, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int st = status_from_err(w->h_err.as<int>()[0]);
+    if (st == KZG355_OK) *ok = w->h_ok.as<int>()[0] != 0;
+    return st;
+}
+
+int kzg355_blob_to_kzg_commitment_many(uint8_t *out, int *status, const uint8_t *blobs, size_t n, const kzg355_settings *cs) {
+    if (!cs || !out) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (!blobs) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    Workspace *w = g.w;
+    int rc;
+    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
+    HIPCHK(hipStreamSynchronize(w->stream));
+    return commit_many_device_impl(out, status, w->blobs.as<uint8_t>(), n, cs);
+}
+int kzg355_blob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const kzg355_settings *s) {
+    int st = KZG355_OK;
+    uint8_t tmp[48];
+    int rc = kzg355_blob_to_kzg_commitment_many(tmp, &st, blob, 1, s);
+    if (rc == KZG355_OK) memcpy(out, tmp, 48);
+    return rc;
+}
+
+int kzg355_compute_blob_kzg_proof_many(uint8_t *out, int *status, const uint8_t *blobs, const uint8_t *commitments, size_t n, const kzg355_settings *cs) {
+    if (!cs || !out) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (!blobs || !commitments) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    Workspace *w = g.w;
+    int rc;
+    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
+    if ((rc = stage_to_device(w, w->commitments, commitments, 48 * n))) return rc;
+    HIPCHK(hipStreamSynchronize(w->stream));
+    return blob_proof_many_device_impl(out, status, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), n, cs);
+}
+int kzg355_compute_blob_kzg_proof(uint8_t proof_out[48], const uint8_t *blob, const uint8_t commitment[48], const kzg355_settings *s) {
+    int st = KZG355_OK;
+    uint8_t tmp[48];
+    int rc = kzg355_compute_blob_kzg_proof_many(tmp, &st, blob, commitment, 1, s);
+    if (rc == KZG355_OK) memcpy(proof_out, tmp, 48);
+    return rc;
+}
+
+int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uint8_t *blob, const uint8_t z_bytes[32], const kzg355_settings *cs) {
+    if (!cs || !proof_out || !y_out || !blob || !z_bytes) return KZG355_BADARGS;
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g.s; Workspace *w = g.w;
+    int rc;
+    if ((rc = stage_to_device(w, w->blobs, blob, BLOB_BYTES))) return rc;
+    if ((rc = stage_to_device(w, w->small, z_bytes, 32))) return rc;
+    if ((rc = w->err.ensure(sizeof(int)))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int)))) return rc;
+    if ((rc = w->z.ensure(sizeof(Fr)))) return rc;
+    if ((rc = w->records.ensure(64))) return rc;
+    if ((rc = w->h_ok.ensure(64))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
+    Timed tm(s, w);
+    launch_fr_from_bytes(w->small.as<uint8_t>(), 1, w->z.as<Fr>(), w->err.as<int>(), w->stream);       // kzg.rs:452
+    if ((rc = prove_common(s, w, tm, w->blobs.as<uint8_t>(), 1))) return rc;
+    launch_fr_to_bytes(w->y.as<Fr>(), 1, w->records.as<uint8_t>(), w->stream);                         // kzg.rs:455
+    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->records.p, 32, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int st = status_from_err(w->h_err.as<int>()[0]);
+    if (st == KZG355_OK) { memcpy(proof_out, w->h_out.p, 48); memcpy(y_out, w->h_ok.p, 32); }
+    return st;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -20,10 +20,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define KZG_HD __host__ __device__ __forceinline__
-#define KZG_HD_NOINLINE __host__ __device__ __noinline__
+#define KZG_HD_NOINLINE inline __host__ __device__ __attribute__((noinline))
 #else
 #define KZG_HD inline __attribute__((always_inline))
-#define KZG_HD_NOINLINE __attribute__((noinline))
+#define KZG_HD_NOINLINE inline __attribute__((noinline))
 #endif
 
 namespace kzg {

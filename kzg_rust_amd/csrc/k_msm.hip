@@ -1,0 +1,168 @@
+// k_msm.hip -- fixed-base Pippenger MSM over the 4096 trusted-setup G1 points: the kernel family behind
+// blob_to_kzg_commitment / compute_*_proof (reference src/utils.rs:367-410 g1_lincomb_fast ->
+// blst_p1s_mult_pippenger, called from src/kzg.rs:397 and :524).
+//
+// Because the base points are constants of the trusted setup, load_trusted_setup stores
+// table[w][i] = 2^(8w) * g1_values[i] (affine), so  sum_i s_i P_i = sum_w sum_i d_{w,i} * table[w][i]
+// with signed 8-bit digits d in [-127,128]: no doublings on the hot path, every window is independent.
+//   k_digits_*     scalar -> 32 biased digit bytes, stored window-major so a window's 4096 digits are contiguous
+//   k_msm_bucket   one 128-thread workgroup per (blob, window): LDS counting sort of the 4096 digits by |d|,
+//                  thread b accumulates bucket b+1 (mixed Jacobian+affine adds, table rows gathered from L2/HBM),
+//                  weights it by (b+1) and the workgroup tree-reduces the 128 weighted buckets through LDS
+//   k_msm_finalize one workgroup per blob: sum the 32 window partials, to affine, ZCash-compress (48 bytes)
+// The result is the same group element blst's Pippenger returns, hence the same 48 bytes (utils.rs:221-227).
+#define KZG_FP_MUL_NOINLINE 1
+#include "kernels.h"
+
+namespace kzg {
+
+__device__ __forceinline__ uint32_t bswap32m(uint32_t x) { return __builtin_bswap32(x); }
+
+// s + K, K = sum_{w<31} 127 * 256^w  (digit e_w = byte w of the sum; d_w = e_w - 127 for w < 31, d_31 = e_31)
+KZG_HD void recode_words(uint32_t out[8], const uint32_t s[8]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t k = i < 7 ? 0x7f7f7f7fu : 0x007f7f7fu;
+        c += (uint64_t)s[i] + k;
+        out[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+__device__ __forceinline__ void store_digits(uint8_t *digits, int blob, int i, const uint32_t e[8]) {
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++)
+        digits[((size_t)blob * MSM_WINDOWS + w) * N_FE + i] = (uint8_t)(e[w >> 2] >> (8 * (w & 3)));
+}
+
+// thread per field element of every blob: canonical check (blob_to_polynomial, kzg.rs:282-291) + recode.
+// The scalar IS the canonical integer of the field element (utils.rs:390-392 converts Montgomery -> scalar; here it
+// never left integer form).
+__global__ void __launch_bounds__(256) k_digits_from_blobs(const uint8_t *blobs, int n, uint8_t *digits, int *err) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * N_FE) return;
+    const int blob = (int)(gid / N_FE), i = (int)(gid % N_FE);
+    const uint4 *p = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob + 32 * (size_t)i);
+    uint4 a = p[0], b = p[1];
+    uint32_t w[8], e[8];
+    w[7] = bswap32m(a.x); w[6] = bswap32m(a.y); w[5] = bswap32m(a.z); w[4] = bswap32m(a.w);
+    w[3] = bswap32m(b.x); w[2] = bswap32m(b.y); w[1] = bswap32m(b.z); w[0] = bswap32m(b.w);
+    if (!fr_words_canonical(w)) atomicOr(&err[blob], ERR_NONCANONICAL_FR);
+    recode_words(e, w);
+    store_digits(digits, blob, i, e);
+}
+
+// same from Montgomery-form field elements (the quotient polynomial of the proof path, kzg.rs:524)
+__global__ void __launch_bounds__(256) k_digits_from_fr(const Fr *scalars, int n, uint8_t *digits) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * N_FE) return;
+    const int blob = (int)(gid / N_FE), i = (int)(gid % N_FE);
+    uint32_t w[8], e[8];
+    fr_to_words(w, scalars[gid]);
+    recode_words(e, w);
+    store_digits(digits, blob, i, e);
+}
+
+constexpr int MSM_THREADS = MSM_BUCKETS;   // 128: one lane per bucket
+
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digits, const G1Affine *table, G1Jac *partials) {
+    __shared__ uint16_t sorted[N_FE];
+    __shared__ int cnt[MSM_BUCKETS + 1], start[MSM_BUCKETS + 1], cursor[MSM_BUCKETS + 1];
+    __shared__ G1Jac red[MSM_THREADS];
+    const int bw = blockIdx.x;                       // blob * 32 + window
+    const int w = bw % MSM_WINDOWS, tid = threadIdx.x;
+    for (int b = tid; b <= MSM_BUCKETS; b += MSM_THREADS) cnt[b] = 0;
+    __syncthreads();
+    // 32 consecutive digits per thread, two 16-byte loads (the whole window is one 4 KiB coalesced read)
+    const uint4 *dp = reinterpret_cast<const uint4 *>(digits + (size_t)bw * N_FE + 32 * tid);
+    const uint4 d0 = dp[0], d1 = dp[1];
+    const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const int bias = w == MSM_WINDOWS - 1 ? 0 : 127;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int d = (int)((dw[k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
+        const int bucket = d < 0 ? -d : d;
+        if (bucket) atomicAdd(&cnt[bucket], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int b = 1; b <= MSM_BUCKETS; b++) { start[b] = acc; cursor[b] = acc; acc += cnt[b]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const int d = (int)((dw[k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
+        const int bucket = d < 0 ? -d : d;
+        if (bucket) {
+            const int pos = atomicAdd(&cursor[bucket], 1);
+            sorted[pos] = (uint16_t)((32 * tid + k) | (d < 0 ? 0x8000 : 0));
+        }
+    }
+    __syncthreads();
+    // bucket accumulation: lane b sums the points whose |digit| == b + 1
+    const G1Affine *tw = table + (size_t)w * N_FE;
+    G1Jac acc = g1_inf();
+    {
+        const int b = tid + 1, s0 = start[b], s1 = s0 + cnt[b];
+        for (int j = s0; j < s1; j++) {
+            const uint32_t v = sorted[j];
+            G1Affine p = tw[v & 0x0fff];
+            if (v & 0x8000) fp_neg(p.y, p.y);
+            g1_add_mixed(acc, acc, p);
+        }
+    }
+    // weight by the bucket index (b+1 <= 128: 8-bit double-and-add), then tree-reduce across the workgroup
+    {
+        const uint32_t m = (uint32_t)(tid + 1);
+        G1Jac r = g1_inf();
+        for (int bit = 7; bit >= 0; bit--) {
+            g1_dbl(r, r);
+            if ((m >> bit) & 1) g1_add(r, r, acc);
+        }
+        red[tid] = r;
+    }
+    __syncthreads();
+    for (int s = MSM_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
+        __syncthreads();
+    }
+    if (tid == 0) partials[bw] = red[0];
+}
+
+__global__ void __launch_bounds__(64) k_msm_finalize(const G1Jac *partials, uint8_t *out48) {
+    __shared__ G1Jac red[MSM_WINDOWS];
+    const int blob = blockIdx.x, tid = threadIdx.x;
+    if (tid < MSM_WINDOWS) red[tid] = partials[(size_t)blob * MSM_WINDOWS + tid];
+    __syncthreads();
+    for (int s = MSM_WINDOWS / 2; s > 0; s >>= 1) {
+        if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        G1Affine a; g1_to_affine(a, red[0]);
+        uint8_t b[48]; g1_compress_affine(b, a);              // bytes_from_g1 (utils.rs:221-227)
+        for (int k = 0; k < 48; k++) out48[48 * (size_t)blob + k] = b[k];
+    }
+}
+
+void launch_digits_from_blobs(const uint8_t *d_blobs, int n, uint8_t *d_digits, int *d_err, hipStream_t st) {
+    if (n <= 0) return;
+    const size_t total = (size_t)n * N_FE;
+    hipLaunchKernelGGL(k_digits_from_blobs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_blobs, n, d_digits, d_err);
+}
+void launch_digits_from_fr(const Fr *d_scalars, int n, uint8_t *d_digits, hipStream_t st) {
+    if (n <= 0) return;
+    const size_t total = (size_t)n * N_FE;
+    hipLaunchKernelGGL(k_digits_from_fr, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_digits);
+}
+void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_partials, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_msm_bucket, dim3(n * MSM_WINDOWS), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials);
+}
+void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_msm_finalize, dim3(n), dim3(64), 0, st, d_partials, d_out48);
+}
+
+}  // namespace kzg

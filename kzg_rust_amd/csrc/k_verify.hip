@@ -1,0 +1,349 @@
+// k_verify.hip -- HIP kernels of the verify_blob_kzg_proof_batch path (reference src/kzg.rs:637-693 and
+// 579-627, src/utils.rs:250-342, 426-474), gfx950.
+//
+// Stage 1 (independent per blob -- "HOT LOOP A", kzg.rs:671-683):
+//   k_validate_points   validate_kzg_g1 on C_i and proof_i          (utils.rs:282-310)   1 lane / point
+//   k_challenge         z_i = SHA-256 Fiat-Shamir challenge          (kzg.rs:298-339)     1 lane / blob
+//   k_eval              blob -> Fr (canonical check) and y_i=p_i(z_i) (kzg.rs:282-291, 346-389) 1 workgroup / blob
+// Stage 2 (per batch of n records -- verify_kzg_proof_batch, kzg.rs:579-627):
+//   k_rpowers           r = hash of the transcript, r^i, r^i z_i, sum r^i y_i   (utils.rs:426-474)
+//   k_lincomb           sum r^i proof_i  and  sum r^i C_i + sum r^i z_i proof_i - [sum r^i y_i]G
+//   k_pairing           e(proof_lincomb, [tau]G2) == e(rhs, G2)                 (utils.rs:189-214)
+// The rhs is algebraically the reference's  sum r^i (C_i - [y_i]G) + sum r^i z_i proof_i  (kzg.rs:603-622): same
+// group element, so the same boolean.
+#define KZG_FP_MUL_NOINLINE 1
+#include "kernels.h"
+
+namespace kzg {
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// ------------------------------------------------------------------------------------------------ points
+// thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
+__global__ void __launch_bounds__(64) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+                                                         G1Affine *pts, int *err) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * n_total) return;
+    const bool is_proof = j >= n_total;
+    if (is_proof && !proofs) return;
+    const int i = is_proof ? j - n_total : j;
+    const uint8_t *src = (is_proof ? proofs : commitments) + 48 * (size_t)i;
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = src[k];
+    G1Affine p;
+    int rc = g1_decompress(p, b);
+    if (rc == 0 && !g1a_is_inf(p) && !g1_in_subgroup(p)) rc = 3;     // infinity is accepted (utils.rs:298-301)
+    const int g = i / n_per_group, k = i % n_per_group;
+    if (rc != 0) { atomicOr(&err[g], ERR_BAD_POINT); p = g1a_inf(); }
+    if (pts) pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
+}
+
+// Decompress the C_i / proof_i fields of gathered records (already validated by their owner rank).
+__global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *records, int n_total, int n_per_group, G1Affine *pts, int *err) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * n_total) return;
+    const bool is_proof = j >= n_total;
+    const int i = is_proof ? j - n_total : j;
+    const uint8_t *src = records + (size_t)RECORD_BYTES * i + (is_proof ? 112 : 0);
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = src[k];
+    G1Affine p;
+    const int g = i / n_per_group, k = i % n_per_group;
+    if (g1_decompress(p, b) != 0) { atomicOr(&err[g], ERR_BAD_POINT); p = g1a_inf(); }
+    pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
+}
+
+// ------------------------------------------------------------------------------------------------ challenge
+// One lane per blob: SHA-256 over  "FSBLOBVERIFY_V1_" | u64be(0) | u64be(4096) | blob | commitment  (131,152 bytes,
+// consts.rs:19-22) = 2050 compressions, strictly sequential.  Also assembles the record's C / z / proof fields.
+__global__ void __launch_bounds__(64) k_challenge(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
+                                                   Fr *z_out, uint8_t *records) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
+    const uint8_t *cm = commitments + 48 * (size_t)i;
+    Sha256 s; sha256_init(s);
+    uint32_t w[16];
+    // block 0: domain | 0 | 4096 | blob[0..32)
+    w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
+    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = (uint32_t)N_FE;
+    {
+        uint4 a = blob[0], b = blob[1];
+        w[8] = bswap32(a.x); w[9] = bswap32(a.y); w[10] = bswap32(a.z); w[11] = bswap32(a.w);
+        w[12] = bswap32(b.x); w[13] = bswap32(b.y); w[14] = bswap32(b.z); w[15] = bswap32(b.w);
+    }
+    sha256_block(s, w);
+    // blocks 1..2047: blob[64b-32, 64b+32)
+    for (int b = 1; b < 2048; b++) {
+        const uint4 *p = blob + (4 * b - 2);
+        uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+        w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+        w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+        sha256_block(s, w);
+    }
+    // block 2048: blob[131040, 131072) | commitment[0..32)
+    {
+        const uint4 *p = blob + (4 * 2048 - 2);
+        uint4 v0 = p[0], v1 = p[1];
+        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+        for (int k = 0; k < 8; k++) w[8 + k] = load_be32(cm + 4 * k);
+    }
+    sha256_block(s, w);
+    // block 2049: commitment[32..48) | 0x80 | zeros | bit length
+    for (int k = 0; k < 4; k++) w[k] = load_be32(cm + 32 + 4 * k);
+    w[4] = 0x80000000u;
+    for (int k = 5; k < 14; k++) w[k] = 0;
+    w[14] = 0; w[15] = (uint32_t)((32 + BLOB_BYTES + 48) * 8);
+    sha256_block(s, w);
+    // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
+    uint32_t dw[8]; sha256_digest_to_words(dw, s);
+    Fr z; fr_from_words(z, dw);
+    z_out[i] = z;
+    if (!records) return;
+    uint8_t *rec = records + (size_t)RECORD_BYTES * i;
+    for (int k = 0; k < 48; k++) rec[k] = cm[k];
+    uint8_t zb[32]; fr_to_be32(zb, z);
+    for (int k = 0; k < 32; k++) rec[48 + k] = zb[k];
+    const uint8_t *pr = proofs + 48 * (size_t)i;
+    for (int k = 0; k < 48; k++) rec[112 + k] = pr[k];
+}
+
+// ------------------------------------------------------------------------------------------------ evaluation
+// One 1024-thread workgroup per blob, 4 field elements per thread (element e = k*1024 + tid: consecutive lanes read
+// consecutive 32-byte elements -> fully coalesced 1 KiB wave loads of the blob and of the roots table).
+//   y = (z^4096 - 1)/4096 * sum_i p_i w_i / (z - w_i)                      (kzg.rs:372-387)
+//   z == w_i for some i  ->  y = p_i                                         (kzg.rs:360-362)
+// Each thread inverts the product of its own four denominators (Montgomery's trick inside the thread + one Fermat
+// inversion per thread); the block then tree-reduces the 1024 partial sums through LDS.
+KZG_HD void load_blob_element_words(uint32_t w[8], const uint8_t *blob, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 *p = reinterpret_cast<const uint4 *>(blob + 32 * (size_t)e);
+    uint4 a = p[0], b = p[1];
+    w[7] = bswap32(a.x); w[6] = bswap32(a.y); w[5] = bswap32(a.z); w[4] = bswap32(a.w);
+    w[3] = bswap32(b.x); w[2] = bswap32(b.y); w[1] = bswap32(b.z); w[0] = bswap32(b.w);
+#else
+    be32_to_words(w, blob + 32 * (size_t)e);
+#endif
+}
+
+__global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
+                                                uint8_t *records, int *err) {
+    __shared__ Fr red[1024];
+    __shared__ int hit;
+    const int blob_i = blockIdx.x, tid = threadIdx.x;
+    const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
+    if (tid == 0) hit = -1;
+    __syncthreads();
+    const Fr z = z_in[blob_i];
+    const Fr one = fr_one();
+    Fr dd[4], pp[3];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int e = k * 1024 + tid;
+        uint32_t w[8]; load_blob_element_words(w, blob, e);
+        bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
+        Fr d; fr_sub(d, z, roots[e]);
+        const bool zero = fr_is_zero(d);
+        if (zero) hit = e;                                        // at most one e can match
+        fr_select(dd[k], zero, d, one);
+    }
+    if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
+    fr_mul(pp[0], dd[0], dd[1]);
+    fr_mul(pp[1], pp[0], dd[2]);
+    fr_mul(pp[2], pp[1], dd[3]);
+    Fr inv; fr_inv(inv, pp[2]);
+    Fr sum = fr_zero();
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        Fr ik;                                                    // 1 / dd[k]
+        if (k > 0) { const Fr &prev = (k == 1) ? dd[0] : pp[k - 2]; fr_mul(ik, inv, prev); fr_mul(inv, inv, dd[k]); }
+        else ik = inv;
+        const int e = k * 1024 + tid;
+        uint32_t w[8]; load_blob_element_words(w, blob, e);
+        Fr p; fr_from_words(p, w);
+        Fr t; fr_mul(t, ik, roots[e]); fr_mul(t, t, p);
+        fr_add(sum, sum, t);
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) { Fr a = red[tid], b = red[tid + s]; fr_add(a, a, b); red[tid] = a; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Fr y;
+        if (hit >= 0) {
+            uint32_t w[8]; load_blob_element_words(w, blob, hit);
+            fr_from_words(y, w);
+        } else {
+            const uint32_t inv4096[NFR] = FR_INV4096_INIT;
+            Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
+            Fr zn = z;
+            for (int i = 0; i < 12; i++) fr_sqr(zn, zn);            // z^4096
+            fr_sub(zn, zn, one);
+            fr_mul(y, red[0], k4096);
+            fr_mul(y, y, zn);
+        }
+        if (y_out) y_out[blob_i] = y;
+        if (records) {
+            uint8_t yb[32]; fr_to_be32(yb, y);
+            uint8_t *rec = records + (size_t)RECORD_BYTES * blob_i + 80;
+            for (int k = 0; k < 32; k++) rec[k] = yb[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ r powers
+// One lane per batch.  Transcript: "RCKZGBATCH___V1_" | u64be(4096) | u64be(n) | n records  (utils.rs:439-463).
+// Emits, as plain 256-bit integers (8 LE words): a_i = r^i, b_i = r^i z_i, and c = sum r^i y_i.
+__global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
+                                                 uint32_t *scal_c, int *err) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t *rec = records + (size_t)RECORD_BYTES * n * g;
+    Fr r = fr_one();
+    if (n > 1) {   // for n == 1 only r^0 = 1 is used (the reference takes the single-proof path, kzg.rs:658-660)
+        Sha256 s; sha256_init(s);
+        const uint32_t total_words = 8u + 40u * (uint32_t)n;            // message length / 4
+        const uint32_t nblocks = (total_words * 4u + 9u + 63u) / 64u;
+        const uint64_t bits = (uint64_t)total_words * 32u;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            uint32_t w[16];
+            for (int t = 0; t < 16; t++) {
+                const uint32_t idx = 16u * b + (uint32_t)t;
+                uint32_t v;
+                if (idx < 8u) {
+                    const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)N_FE, 0u, (uint32_t)n};
+                    v = hdr[idx];                                       // "RCKZGBATCH___V1_" | 4096 | n
+                } else if (idx < total_words) v = load_be32(rec + 4 * (size_t)(idx - 8u));
+                else if (idx == total_words) v = 0x80000000u;
+                else if (idx == 16u * nblocks - 2u) v = (uint32_t)(bits >> 32);
+                else if (idx == 16u * nblocks - 1u) v = (uint32_t)bits;
+                else v = 0u;
+                w[t] = v;
+            }
+            sha256_block(s, w);
+        }
+        uint32_t dw[8]; sha256_digest_to_words(dw, s);
+        fr_from_words(r, dw);                                           // hash_to_bls_field (utils.rs:472)
+    }
+    Fr pw = fr_one(), csum = fr_zero();
+    bool bad = false;
+    for (int i = 0; i < n; i++) {
+        uint32_t zw[8], yw[8];
+        be32_to_words(zw, rec + (size_t)RECORD_BYTES * i + 48);
+        be32_to_words(yw, rec + (size_t)RECORD_BYTES * i + 80);
+        if (check_zy) bad = bad || !fr_words_canonical(zw) || !fr_words_canonical(yw);
+        Fr z, y, t; fr_from_words(z, zw); fr_from_words(y, yw);
+        uint32_t *pa = scal_a + 8 * ((size_t)g * n + i), *pb = scal_b + 8 * ((size_t)g * n + i);
+        uint32_t ow[8];
+        fr_to_words(ow, pw); for (int k = 0; k < 8; k++) pa[k] = ow[k];
+        fr_mul(t, pw, z); fr_to_words(ow, t); for (int k = 0; k < 8; k++) pb[k] = ow[k];
+        fr_mul(t, pw, y); fr_add(csum, csum, t);
+        fr_mul(pw, pw, r);
+    }
+    uint32_t ow[8]; fr_to_words(ow, csum);
+    for (int k = 0; k < 8; k++) scal_c[8 * (size_t)g + k] = ow[k];
+    if (bad) atomicOr(&err[g], ERR_NONCANONICAL_FR);
+}
+
+// ------------------------------------------------------------------------------------------------ lincomb
+// One 256-thread workgroup per batch.  Terms (3n + 1 scalar multiplications, each 256-bit double-and-add):
+//   class 0:  a_i * proof_i                                   -> proof_lincomb         (kzg.rs:601)
+//   class 1:  b_i * proof_i,  a_i * C_i,  c * (-G)            -> rhs                   (kzg.rs:603-622)
+// then an LDS tree reduction per class.  Output: (-proof_lincomb, rhs) as affine points for the pairing.
+constexpr int LINCOMB_THREADS = 256;
+__global__ void __launch_bounds__(LINCOMB_THREADS) k_lincomb(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b,
+                                                               const uint32_t *scal_c, int n, G1Affine *pair_pts) {
+    __shared__ G1Jac red[LINCOMB_THREADS];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const G1Affine *gp = pts + (size_t)g * 2 * n;        // [0,n) commitments, [n,2n) proofs
+    G1Jac acc0 = g1_inf(), acc1 = g1_inf();
+    for (int t = tid; t < 3 * n + 1; t += LINCOMB_THREADS) {
+        G1Affine p; uint32_t k[8]; int cls;
+        if (t < n) { p = gp[n + t]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + t) + q]; cls = 0; }
+        else if (t < 2 * n) { p = gp[n + (t - n)]; for (int q = 0; q < 8; q++) k[q] = scal_b[8 * ((size_t)g * n + (t - n)) + q]; cls = 1; }
+        else if (t < 3 * n) { p = gp[t - 2 * n]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + (t - 2 * n)) + q]; cls = 1; }
+        else {
+            const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT;
+            for (int q = 0; q < NFP; q++) { p.x.l[q] = gx[q]; p.y.l[q] = gy[q]; }
+            fp_neg(p.y, p.y);
+            for (int q = 0; q < 8; q++) k[q] = scal_c[8 * (size_t)g + q];
+            cls = 1;
+        }
+        G1Jac m; g1_mul_words(m, p, k, 8);
+        if (cls == 0) g1_add(acc0, acc0, m); else g1_add(acc1, acc1, m);
+    }
+    G1Jac total[2];
+    for (int cls = 0; cls < 2; cls++) {
+        red[tid] = cls == 0 ? acc0 : acc1;
+        __syncthreads();
+        for (int s = LINCOMB_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
+            __syncthreads();
+        }
+        if (tid == 0) total[cls] = red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        G1Affine a0, a1;
+        g1_to_affine(a0, total[0]); g1_to_affine(a1, total[1]);
+        if (!g1a_is_inf(a0)) fp_neg(a0.y, a0.y);             // pairings_verify negates its first G1 argument (utils.rs:198-201)
+        pair_pts[2 * (size_t)g] = a0;
+        pair_pts[2 * (size_t)g + 1] = a1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pairing
+// One lane per batch:  ML([tau]G2, -proof_lincomb) * ML(G2, rhs)  ->  final exponentiation  ->  == 1 ?
+__global__ void __launch_bounds__(64) k_pairing(const G1Affine *pair_pts, const LineCoeff *lines, const int *lines_inf, int groups, int *ok) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
+    if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
+    if (lines_inf[0]) p2 = g1a_inf();
+    Fp12 f;
+    miller_loop_pair(f, lines + 2 * N_LINES, p1, lines, p2);     // lines[2] = setup g2[1] = [tau]G2 ; lines[0] = G2 generator
+    ok[g] = final_exp_is_one(f) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
+                            hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err);
+}
+void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_points_from_records, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_records, n_total, n_per_group, d_pts, d_err);
+}
+void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
+                       hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_challenge, dim3((n_total + 63) / 64), dim3(64), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+}
+void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
+                 hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(1024), 0, st, d_blobs, d_z, t.roots, n_per_group, d_y, d_records, d_err);
+}
+void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
+                    uint32_t *d_scal_c, int *d_err, hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
+}
+void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
+                    int groups, G1Affine *d_pair_pts, hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_lincomb, dim3(groups), dim3(LINCOMB_THREADS), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_pair_pts);
+}
+void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_pairing, dim3((groups + 63) / 64), dim3(64), 0, st, d_pair_pts, t.lines, t.lines_inf, groups, d_ok);
+}
+
+}  // namespace kzg

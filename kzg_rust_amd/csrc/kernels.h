@@ -1,0 +1,70 @@
+// kernels.h -- internal interface between the C-ABI host code (api.hip) and the HIP kernel translation
+// units (k_setup.hip, k_verify.hip, k_msm.hip, k_prove.hip).  Not installed; the public boundary is
+// include/kzg355.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field.h"
+#include "tower.h"
+#include "g1.h"
+#include "pairing.h"
+#include "sha256.h"
+
+namespace kzg {
+
+constexpr int N_FE = 4096;                 // FIELD_ELEMENTS_PER_BLOB (consts.rs:13)
+constexpr int BLOB_BYTES = N_FE * 32;      // consts.rs:16
+constexpr int RECORD_BYTES = 160;          // C | z | y | proof  (utils.rs:454-463)
+constexpr int MSM_WINDOW_BITS = 8;
+constexpr int MSM_WINDOWS = 32;            // 32 x 8 bits cover the 255-bit scalars
+constexpr int MSM_BUCKETS = 128;           // signed digits in [-127, 128]
+constexpr int N_G2 = 65;
+
+// error bits accumulated on the device; any bit => the call returns Err (reference: `?` on each step)
+constexpr int ERR_BAD_POINT = 1;           // validate_kzg_g1 failed (utils.rs:282-310)
+constexpr int ERR_NONCANONICAL_FR = 2;     // bytes_to_bls_field failed (utils.rs:262-275)
+constexpr int ERR_SETUP_POINT = 4;         // load_trusted_setup: bad g1/g2 bytes (kzg.rs:863, 878)
+constexpr int ERR_SETUP_MONOMIAL = 8;      // is_trusted_setup_in_lagrange_form (kzg.rs:823-826)
+
+struct DeviceTables {
+    Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
+    G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)
+    LineCoeff *lines;        // [3][68]: Miller-loop lines of G2_GENERATOR, setup g2[0], setup g2[1]
+    int *lines_inf;          // [3] 1 if that G2 point is the point at infinity
+    G1Affine *g1_first2;     // file-order g1[0], g1[1] (only for the Lagrange-form check)
+};
+
+// ---- k_setup.hip
+void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTables t, int *d_err, hipStream_t st);
+
+// ---- k_verify.hip
+// stage 1 (per blob): validate points, Fiat-Shamir challenge, barycentric evaluation -> 160-byte records
+// d_proofs may be null (commitments only, e.g. compute_blob_kzg_proof's challenge step, kzg.rs:321)
+void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group,
+                            G1Affine *d_pts /* [group][2*npg]: commitments then proofs; may be null */, int *d_err /* per group */,
+                            hipStream_t st);
+void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
+                       Fr *d_z, uint8_t *d_records, hipStream_t st);
+void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
+                 uint8_t *d_records /* y written at +80; may be null */, int *d_err, hipStream_t st);
+// stage 2 (per group of n records): points from records, r-powers, lincomb, pairing
+void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st);
+void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
+                    uint32_t *d_scal_c, int *d_err, hipStream_t st);
+void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
+                    int n_per_group, int groups, G1Affine *d_pair_pts /* [group][2] */, hipStream_t st);
+void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);
+
+// ---- k_msm.hip
+void launch_digits_from_blobs(const uint8_t *d_blobs, int n, uint8_t *d_digits /* [n][32][4096] */, int *d_err /* per blob */, hipStream_t st);
+void launch_digits_from_fr(const Fr *d_scalars /* [n][4096] Montgomery */, int n, uint8_t *d_digits, hipStream_t st);
+void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_partials /* [n][32] */, hipStream_t st);
+void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48 /* [n][48] */, hipStream_t st);
+
+// ---- k_prove.hip
+// quotient polynomial q(X) = (p(X) - y)/(X - z) in evaluation form (kzg.rs:461-523) for n blobs; also y.
+void launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, Fr *d_q /* [n][4096] */, int *d_err, hipStream_t st);
+void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err /* per element, ERR_NONCANONICAL_FR */, hipStream_t st);
+void launch_fr_to_bytes(const Fr *d_in, int n, uint8_t *d_out32, hipStream_t st);
+
+}  // namespace kzg

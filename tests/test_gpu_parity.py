@@ -1,0 +1,150 @@
+"""-m gpu: parity of the HIP engine (through the C ABI of libkzg355.so) with the reference's golden vectors and
+with the CPU oracle.  Everything here runs on cuda:0 of the GPU box; /root/reference is never read."""
+import ctypes as C
+import os
+
+import pytest
+
+from synth import random_blob, random_field_element
+from vector_harness import run_function
+
+pytestmark = pytest.mark.gpu
+
+COUNTS = {"blob_to_kzg_commitment": 10, "compute_kzg_proof": 46, "compute_blob_kzg_proof": 14,
+          "verify_kzg_proof": 92, "verify_blob_kzg_proof": 24, "verify_blob_kzg_proof_batch": 22}
+
+
+@pytest.fixture(scope="module")
+def kz():
+    import kzg_rust_amd
+    return kzg_rust_amd
+
+
+@pytest.fixture(scope="module")
+def settings(kz, setup_bytes):
+    g1, g2 = setup_bytes
+    s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    yield s
+    s.free()
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from gpu_backend import ProductBackend
+    return ProductBackend()
+
+
+@pytest.mark.parametrize("fn", list(COUNTS))
+def test_reference_vectors(fn, golden_vectors, golden_blobs, backend, settings):
+    """The reference's own test loop (src/lib.rs:30-203) over all 208 vectors, product in place of blst."""
+    n, failures = run_function(fn, golden_vectors, backend, settings, golden_blobs)
+    assert n == COUNTS[fn]
+    assert not failures, "\n".join(failures)
+
+
+def test_load_trusted_setup_errors(kz, setup_bytes, tmp_path):
+    g1, g2 = setup_bytes
+    g1l = [g1[48 * i:48 * i + 48] for i in range(4096)]
+    g2l = [g2[96 * i:96 * i + 96] for i in range(65)]
+    with pytest.raises(kz.InvalidTrustedSetup):
+        kz.Kzg.load_trusted_setup(g1l[:-1], g2l)                  # kzg.rs:49-55
+    with pytest.raises(kz.InvalidTrustedSetup):
+        kz.Kzg.load_trusted_setup(g1l, g2l[:-1])                  # kzg.rs:56-62
+    bad = list(g1l); bad[7] = bytes([0x9a]) + b"\xff" * 47         # x >= p
+    with pytest.raises(kz.BadArgs):
+        kz.Kzg.load_trusted_setup(bad, g2l)                       # kzg.rs:863
+    bad2 = list(g2l); bad2[64] = bytes(96)                         # uncompressed flag
+    with pytest.raises(kz.BadArgs):
+        kz.Kzg.load_trusted_setup(g1l, bad2)                      # kzg.rs:878
+    mono = open(os.path.join(os.path.dirname(__file__), "golden", "setup_g1_monomial_first2.bin"), "rb").read()
+    monol = [mono[:48], mono[48:96]] + g1l[2:]
+    with pytest.raises(kz.BadArgs):
+        kz.Kzg.load_trusted_setup(monol, g2l)                     # monomial form rejected, kzg.rs:823-826
+    # file loader (kzg.rs:906-979)
+    path = tmp_path / "ts.txt"
+    path.write_text("4096\n65\n" + "\n".join(x.hex() for x in g1l) + "\n" + "\n".join(x.hex() for x in g2l) + "\n")
+    s = kz.Kzg.load_trusted_setup_file(str(path))
+    s.free()
+    (tmp_path / "bad1.txt").write_text("4095\n65\n")
+    with pytest.raises(kz.InvalidTrustedSetup):
+        kz.Kzg.load_trusted_setup_file(str(tmp_path / "bad1.txt"))
+    (tmp_path / "bad2.txt").write_text("4096\n64\n")
+    with pytest.raises(kz.InvalidTrustedSetup):
+        kz.Kzg.load_trusted_setup_file(str(tmp_path / "bad2.txt"))
+    with pytest.raises(kz.InvalidTrustedSetup):
+        kz.Kzg.load_trusted_setup_file(str(tmp_path / "missing.txt"))
+
+
+N_RANDOM = 8
+
+
+@pytest.fixture(scope="module")
+def random_set(oracle, oracle_settings):
+    blobs = [random_blob(i) for i in range(N_RANDOM)]
+    cs = [oracle.blob_to_kzg_commitment(b, oracle_settings) for b in blobs]
+    ps = [oracle.compute_blob_kzg_proof(b, c, oracle_settings) for b, c in zip(blobs, cs)]
+    return blobs, cs, ps
+
+
+def test_random_commit_and_proof_match_oracle(kz, settings, random_set, oracle, oracle_settings):
+    blobs, cs, ps = random_set
+    got_c = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], settings)
+    assert [c.to_bytes() for c in got_c] == cs
+    got_p = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], settings)
+    assert [p.to_bytes() for p in got_p] == ps
+    for i in range(3):
+        z = random_field_element(i)
+        p, y = kz.Kzg.compute_kzg_proof(kz.Blob(blobs[i]), kz.Bytes32(z), settings)
+        op, oy = oracle.compute_kzg_proof(blobs[i], z, oracle_settings)
+        assert (p.to_bytes(), y.to_bytes()) == (op, oy)
+
+
+def test_random_verify_batch(kz, settings, random_set, oracle, oracle_settings):
+    blobs, cs, ps = random_set
+    B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, settings) is True
+    # swap two proofs: still valid points, wrong statement
+    Pr2 = list(Pr); Pr2[1], Pr2[2] = Pr2[2], Pr2[1]
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr2, settings) is False
+    assert oracle.verify_blob_kzg_proof_batch(blobs, cs, [p.to_bytes() for p in Pr2], oracle_settings) is False
+    for n in (1, 2, 3):
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], Pr[:n], settings) is True
+    with pytest.raises(kz.BadArgs):
+        kz.Kzg.verify_blob_kzg_proof_batch(B, Cm[:-1], Pr, settings)
+    assert kz.Kzg.verify_blob_kzg_proof_batch([], [], [], settings) is True
+    # several independent batches in one launch; one of them wrong, one with an invalid commitment
+    bad_c = list(Cm[:4]); bad_c[0] = kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)
+    res = kz.Kzg.verify_blob_kzg_proof_batch_many([(B[:4], Cm[:4], Pr[:4]), (B[4:], Cm[4:], Pr[4:]), (B[:4], Cm[:4], Pr2[:4]), (B[:4], bad_c, Pr[:4])], settings)
+    assert res[0] is True and res[1] is True and res[2] is False and isinstance(res[3], kz.BadArgs)
+
+
+def test_stage_records_match_oracle(kz, settings, random_set, oracle, oracle_settings):
+    """Stage-by-stage: the 160-byte records (C | z | y | proof) against the oracle's z_i / y_i, then stage 2 on them."""
+    import torch
+    blobs, cs, ps = random_set
+    n = len(blobs)
+    dev = torch.device("cuda", settings.device)
+    t_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    t_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
+    t_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
+    t_rec = torch.zeros(160 * n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = (C.c_int * 1)(-1)
+    L = kz.kzg.lib()
+    rc = L.kzg355_verify_shard_records_device(t_rec.data_ptr(), st, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n, 1, settings.handle)
+    assert rc == 0 and st[0] == 0
+    rec = bytes(t_rec.cpu().numpy())
+    inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+    for i in range(n):
+        r = rec[160 * i:160 * i + 160]
+        assert r[:48] == cs[i] and r[112:] == ps[i]
+        assert r[48:80] == inter["z"][i], f"z[{i}]"
+        assert r[80:112] == inter["y"][i], f"y[{i}]"
+    ok = (C.c_bool * 2)(); st2 = (C.c_int * 2)()
+    assert L.kzg355_verify_records_device(ok, st2, t_rec.data_ptr(), n, 1, settings.handle) == 0 and ok[0] is True
+    # the same records viewed as two batches of n/2 (each half is a valid batch of its own)
+    assert L.kzg355_verify_records_device(ok, st2, t_rec.data_ptr(), n // 2, 2, settings.handle) == 0 and list(ok) == [True, True]
+    # device-resident batched entry point (what bench.py times)
+    okm = (C.c_bool * 2)(); stm = (C.c_int * 2)()
+    rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(okm, stm, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n // 2, 2, settings.handle)
+    assert rc == 0 and list(okm) == [True, True] and list(stm) == [0, 0]
