@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: blobs/sec on verify_blob_kzg_proof_batch (mainnet N=4096, batch = 64 per GPU).
+
+Restates benches/kzg_benches.rs:93-126 (criterion group `verify_blob_kzg_proof_batch`, Throughput::Elements(n)):
+  * inputs (benches/kzg_benches.rs:7-44): 64 random canonical blobs per batch, honest commitments and proofs made with
+    the library itself (untimed setup), so every verification returns true -- asserted for every step;
+  * a STEP is one verify_blob_kzg_proof_batch over one batch: 64 blobs at N=1; at N GPUs one batch of 64*N blobs
+    sharded 64 per rank (BASELINE.json configs[3] / configs[4]);
+  * inputs are resident in HBM when the timed region starts; the engine is called through the C ABI
+    (kzg355_verify_blob_kzg_proof_batch_many_device, or the two stage functions around the all-gather for N > 1).
+The chip is far from filled by one 64-blob batch (the path is latency-bound integer work), so `--concurrent C`
+independent steps are submitted per launch set (default below); K steps are always executed and timed exactly.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_PER_BATCH = 64
+BLOB = 131072
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Algorithmic bytes per blob, per kernel family (DESIGN.md "kernels" table); whole path per SURVEY.md 8(d): 262,240 B/blob.
+PATH_BYTES_PER_BLOB = 131072 + 131072 + 48 + 48
+KERNEL_BYTES_PER_BLOB = {
+    "challenge": 16 + 16 + 131072 + 48 + 32,          # the 131,152-byte transcript in, z out
+    "eval": 131072 + 131072 + 32 + 32,                # blob + roots-of-unity sweep + z in, y out
+    "validate_points": 96,
+    "points_from_records": 96,
+    "rpowers": 160 + 64,
+    "lincomb": 2 * 112 + 64 + 2 * 112 / N_PER_BATCH,
+    "pairing": (2 * 68 * 3 * 2 * 56 + 2 * 112) / N_PER_BATCH,   # two 68-line tables + two points per batch
+}
+FAMILIES = list(KERNEL_BYTES_PER_BLOB)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--concurrent", type=int, default=128, help="independent steps (batches) submitted per launch set")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("KZG355_DEVICE", str(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import kzg_rust_amd as kz
+    from synth import random_blob
+    L = kz.kzg.lib()
+
+    golden = os.path.join(ROOT, "tests", "golden")
+    g1 = open(os.path.join(golden, "trusted_setup_g1.bin"), "rb").read()
+    g2 = open(os.path.join(golden, "trusted_setup_g2.bin"), "rb").read()
+    s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    assert s.device == local_rank
+
+    K, W = args.steps, args.warmup
+    Cc = max(1, min(args.concurrent, max(K, 1)))
+    n_local = N_PER_BATCH
+    # ---- untimed setup: Cc distinct batches per launch set; this rank owns blobs [rank*64, rank*64+64) of each batch
+    n_blobs = Cc * n_local
+    host = bytearray(n_blobs * BLOB)
+    for g in range(Cc):
+        for i in range(n_local):
+            idx = (g * world + rank) * n_local + i
+            host[(g * n_local + i) * BLOB:(g * n_local + i + 1) * BLOB] = random_blob(idx)
+    t_blobs = torch.frombuffer(host, dtype=torch.uint8).to(dev)
+    out = C.create_string_buffer(48 * n_blobs)
+    st = (C.c_int * n_blobs)()
+    rc = L.kzg355_blob_to_kzg_commitment_many_device(out, st, t_blobs.data_ptr(), n_blobs, s.handle)
+    assert rc == 0, rc
+    commitments = out.raw
+    t_c = torch.frombuffer(bytearray(commitments), dtype=torch.uint8).to(dev)
+    rc = L.kzg355_compute_blob_kzg_proof_many_device(out, st, t_blobs.data_ptr(), t_c.data_ptr(), n_blobs, s.handle)
+    assert rc == 0, rc
+    proofs = out.raw
+    t_p = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
+    t_rec = torch.empty(Cc * n_local * 160, dtype=torch.uint8, device=dev)
+    t_all = torch.empty(world * Cc * n_local * 160, dtype=torch.uint8, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+
+    ok = (C.c_bool * Cc)()
+    stg = (C.c_int * Cc)()
+
+    def run_steps(g):
+        """g <= Cc independent steps in one launch set; returns when the verdicts are on the host."""
+        if world == 1:
+            rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
+            assert rc == 0, rc
+        else:
+            rc = L.kzg355_verify_shard_records_device(t_rec.data_ptr(), stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
+            assert rc == 0, rc
+            nloc = g * n_local * 160
+            gathered = t_all[:world * nloc]
+            dist.all_gather_into_tensor(gathered, t_rec[:nloc])          # ONE collective per launch set (RCCL over xGMI)
+            # [rank][batch][64*160] -> [batch][rank][64*160]: records of a batch in transcript order
+            recs = gathered.view(world, g, n_local * 160).permute(1, 0, 2).contiguous()
+            torch.cuda.synchronize()
+            rc = L.kzg355_verify_records_device(ok, stg, recs.data_ptr(), n_local * world, g, s.handle)
+            assert rc == 0, rc
+        assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # single-batch latency (reported, not the metric)
+    run_steps(1)
+    lat = []
+    for _ in range(3):
+        barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
+    latency_ms = sorted(lat)[len(lat) // 2]
+
+    done = 0
+    while done < W:
+        g = min(Cc, W - done); run_steps(g); done += g
+    L.kzg355_reset_kernel_stats(s.handle)
+    s.set_kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    done = 0
+    while done < K:
+        g = min(Cc, K - done); run_steps(g); done += g
+    barrier()
+    dt = time.perf_counter() - t0
+    s.set_kernel_timing(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    blobs_total = K * n_local * world
+    value = blobs_total / dt
+
+    # ---- roofline of the dominant kernel (HIP events recorded on the launch stream during the timed region)
+    stats = {}
+    for fam in FAMILIES:
+        tot, cnt = C.c_double(), C.c_long()
+        L.kzg355_kernel_ms_stats(s.handle, fam.encode(), C.byref(tot), C.byref(cnt))
+        if cnt.value:
+            stats[fam] = (tot.value, cnt.value)
+    roofline = None
+    if stats:
+        dom = max(stats, key=lambda f: stats[f][0])
+        tot_ms, cnt = stats[dom]
+        avg_s = tot_ms / cnt / 1e3
+        blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "pairing", "points_from_records") else blobs_total / cnt
+        achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "avg_launch_ms": round(tot_ms / cnt, 4), "launches": cnt,
+                    "kernel_ms_share": {f: round(v[0], 3) for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0])},
+                    "path_bytes_per_blob": PATH_BYTES_PER_BLOB,
+                    "path_frac_of_hbm_peak": value * PATH_BYTES_PER_BLOB / (world * HBM_PEAK_GBPS * 1e9),
+                    "note": "integer-ALU/latency-bound path: ~1e3 integer ops per byte, HBM fraction is small by construction"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = time_cpu_baseline(commitments, proofs, host, n_local)
+
+    if rank == 0:
+        line = {
+            "metric": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, batch=64)",
+            "value": value, "unit": "blobs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
+            "config": {"workload": "kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch"
+                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-gather of 160-B records"),
+                       "blobs_per_step": n_local * world, "concurrent_steps_per_launch": Cc, "field_elements_per_blob": 4096,
+                       "inputs": "resident in HBM", "latency_ms_single_step": round(latency_ms, 3)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    s.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def time_cpu_baseline(commitments, proofs, host_blobs, n):
+    """The CPU oracle (kind "port": the build's restatement of the reference algorithm, NOT blst) on the host cores of
+    this box: verify_blob_kzg_proof_batch over the same first 64-blob batch, single thread like the reference."""
+    from oracle.oracle import Oracle, build
+    try:
+        build(native=True)
+        o = Oracle(native=True)
+    except Exception:
+        o = Oracle(native=False)
+    golden = os.path.join(ROOT, "tests", "golden")
+    so = o.load_trusted_setup(open(os.path.join(golden, "trusted_setup_g1.bin"), "rb").read(),
+                              open(os.path.join(golden, "trusted_setup_g2.bin"), "rb").read())
+    blobs = [bytes(host_blobs[i * BLOB:(i + 1) * BLOB]) for i in range(n)]
+    cs = [commitments[48 * i:48 * i + 48] for i in range(n)]
+    ps = [proofs[48 * i:48 * i + 48] for i in range(n)]
+    reps, t_total = 0, 0.0
+    while t_total < 10.0 and reps < 200:
+        t0 = time.perf_counter()
+        assert o.verify_blob_kzg_proof_batch(blobs, cs, ps, so) is True
+        t_total += time.perf_counter() - t0
+        reps += 1
+    o.free_trusted_setup(so)
+    return {"value": reps * n / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x verify_blob_kzg_proof_batch(n=64) on the bench's first batch, oracle -O3 -march=native, "
+                      f"{t_total:.1f} s; restatement in portable C, not blst (blst's asm is likely 1.5-3x faster per core)",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -120,8 +120,38 @@ KZG_HD void g1_mul_words(G1Jac &r, const G1Affine &p, const uint32_t *k, int nwo
     r = acc;
 }
 
-// [r]P == infinity: the predicate blst_p1_in_g1 decides (utils.rs:303).
+// [|x|]P for the BLS parameter |x| = 0xd201000000010000 (64 bits, Hamming weight 6); P Jacobian.
+KZG_HD void g1_mul_x_abs(G1Jac &r, const G1Jac &p) {
+    G1Jac acc = p;                       // top bit
+    for (int i = 62; i >= 0; i--) {
+        g1_dbl(acc, acc);
+        if ((BLS_X_ABS >> i) & 1) g1_add(acc, acc, p);
+    }
+    r = acc;
+}
+
+// Subgroup membership (the predicate blst_p1_in_g1 decides, utils.rs:303):  P in G1  <=>  phi(P) == -[x^2]P,
+// phi(x,y) = (beta x, y).  "=>": phi acts on G1 as the eigenvalue -x^2 (checked on the generator by gen_constants.py).
+// "<=": phi^2 + phi + 1 = 0 on E, so phi(P) = [-x^2]P forces [x^4 - x^2 + 1]P = [r]P = infinity, and the r-torsion
+// of E(Fp) is exactly G1.  Two sparse 64-bit multiplications instead of one dense 255-bit one.
 KZG_HD bool g1_in_subgroup(const G1Affine &p) {
+    if (g1a_is_inf(p)) return true;
+    G1Jac pj, t;
+    g1_from_affine(pj, p);
+    g1_mul_x_abs(t, pj);
+    g1_mul_x_abs(t, t);                  // [x^2]P
+    if (g1_is_inf(t)) return false;
+    const uint32_t bc[NFP] = FP_BETA_INIT;
+    Fp beta; for (int i = 0; i < NFP; i++) beta.l[i] = bc[i];
+    Fp z2, z3, lhs, rhs;
+    fp_sqr(z2, t.z); fp_mul(z3, z2, t.z);
+    fp_mul(lhs, p.x, beta); fp_mul(lhs, lhs, z2);      // beta x Z^2 == X
+    if (!fp_eq(lhs, t.x)) return false;
+    fp_mul(lhs, p.y, z3); fp_neg(rhs, t.y);            // y Z^3 == -Y
+    return fp_eq(lhs, rhs);
+}
+// Reference form of the same predicate, kept for the unit tests: [r]P == infinity.
+KZG_HD bool g1_in_subgroup_naive(const G1Affine &p) {
     const uint32_t rw[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
     G1Jac t;
     g1_mul_words(t, p, rw, 8);

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) k_digits_from_fr(const Fr *scalars, int n
 }
 
 constexpr int MSM_THREADS = MSM_BUCKETS;   // 128: one lane per bucket
+constexpr int MSM_LANE_CAP = 64;           // entries one lane accumulates alone (uniform digits: 32 +- 6 per bucket)
 
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digits, const G1Affine *table, G1Jac *partials) {
     __shared__ uint16_t sorted[N_FE];
@@ -100,17 +101,42 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digit
         }
     }
     __syncthreads();
-    // bucket accumulation: lane b sums the points whose |digit| == b + 1
+    // bucket accumulation: lane b sums the points whose |digit| == b + 1 -- but at most MSM_LANE_CAP of them.
+    // Real blobs are far from uniform (31-byte packing leaves the top byte 0, so window 31 only sees digits 0/1, and a
+    // constant blob puts all 4096 points of every window in ONE bucket): entries beyond the cap are summed by the whole
+    // workgroup (strided partial sums + LDS tree) and handed back to the bucket's lane, so no lane walks a long list.
     const G1Affine *tw = table + (size_t)w * N_FE;
     G1Jac acc = g1_inf();
     {
-        const int b = tid + 1, s0 = start[b], s1 = s0 + cnt[b];
-        for (int j = s0; j < s1; j++) {
+        const int b = tid + 1, s0 = start[b];
+        const int c = cnt[b] < MSM_LANE_CAP ? cnt[b] : MSM_LANE_CAP;
+        for (int j = s0; j < s0 + c; j++) {
             const uint32_t v = sorted[j];
             G1Affine p = tw[v & 0x0fff];
             if (v & 0x8000) fp_neg(p.y, p.y);
             g1_add_mixed(acc, acc, p);
         }
+    }
+    for (int b = 1; b <= MSM_BUCKETS; b++) {            // workgroup-uniform loop; normally no bucket qualifies
+        const int extra = cnt[b] - MSM_LANE_CAP;
+        if (extra <= 0) continue;
+        const int base = start[b] + MSM_LANE_CAP;
+        G1Jac part = g1_inf();
+        for (int j = tid; j < extra; j += MSM_THREADS) {
+            const uint32_t v = sorted[base + j];
+            G1Affine p = tw[v & 0x0fff];
+            if (v & 0x8000) fp_neg(p.y, p.y);
+            g1_add_mixed(part, part, p);
+        }
+        __syncthreads();
+        red[tid] = part;
+        __syncthreads();
+        for (int s = MSM_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s && tid + s < extra) { G1Jac x = red[tid], y = red[tid + s]; g1_add(x, x, y); red[tid] = x; }
+            __syncthreads();
+        }
+        if (tid == b - 1) { G1Jac x = red[0]; g1_add(acc, acc, x); }
+        __syncthreads();
     }
     // weight by the bucket index (b+1 <= 128: 8-bit double-and-add), then tree-reduce across the workgroup
     {

@@ -112,12 +112,16 @@ __global__ void __launch_bounds__(64) k_challenge(const uint8_t *blobs, const ui
 }
 
 // ------------------------------------------------------------------------------------------------ evaluation
-// One 1024-thread workgroup per blob, 4 field elements per thread (element e = k*1024 + tid: consecutive lanes read
-// consecutive 32-byte elements -> fully coalesced 1 KiB wave loads of the blob and of the roots table).
-//   y = (z^4096 - 1)/4096 * sum_i p_i w_i / (z - w_i)                      (kzg.rs:372-387)
-//   z == w_i for some i  ->  y = p_i                                         (kzg.rs:360-362)
-// Each thread inverts the product of its own four denominators (Montgomery's trick inside the thread + one Fermat
-// inversion per thread); the block then tree-reduces the 1024 partial sums through LDS.
+// y = p(z) for a polynomial given by its 4096 evaluations at the (bit-reversed) roots of unity (kzg.rs:346-389).
+// The reference evaluates  y = (z^N - 1)/N * sum_i p_i w_i / (z - w_i)  with a 4096-long batch inversion and special-
+// cases z == w_i.  Because  prod_j (z - w_j) = z^N - 1,  the same value is
+//         y = (1/N) * sum_i  p_i w_i * prod_{j != i} (z - w_j)
+// which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m).
+// "Product of all the others" is a scan: one 1024-thread workgroup per blob, 4 elements per thread
+// (element e = k*1024 + tid: consecutive lanes read consecutive 32-byte elements -> coalesced 1 KiB wave loads of the
+// blob and of the roots table); per thread  L_t = d0 d1 d2 d3  and the three-factor complements; across threads an
+// exclusive prefix * suffix product with wave shuffles (6+6 steps) and a 16-entry LDS stage; then a shuffle/LDS sum.
+// ~34 Fr products per thread instead of ~410 (one Fermat inversion per thread) in the first version of this kernel.
 KZG_HD void load_blob_element_words(uint32_t w[8], const uint8_t *blob, int e) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint4 *p = reinterpret_cast<const uint4 *>(blob + 32 * (size_t)e);
@@ -128,66 +132,88 @@ KZG_HD void load_blob_element_words(uint32_t w[8], const uint8_t *blob, int e) {
     be32_to_words(w, blob + 32 * (size_t)e);
 #endif
 }
+__device__ __forceinline__ Fr fr_shfl_up(const Fr &v, int delta) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = __shfl_up(v.l[i], delta, 64);
+    return r;
+}
+__device__ __forceinline__ Fr fr_shfl_down(const Fr &v, int delta) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = __shfl_down(v.l[i], delta, 64);
+    return r;
+}
+__device__ __forceinline__ Fr fr_shfl(const Fr &v, int src) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = __shfl(v.l[i], src, 64);
+    return r;
+}
+// product over the other lanes of the wave: exclusive prefix * exclusive suffix; also returns the wave total
+__device__ __forceinline__ void wave_product_except_self(Fr &excl, Fr &total, const Fr &v, int lane) {
+    const Fr one = fr_one();
+    Fr pre = v, suf = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Fr a = fr_shfl_up(pre, off), b = fr_shfl_down(suf, off), t;
+        fr_mul(t, pre, a); fr_select(pre, lane >= off, pre, t);
+        fr_mul(t, suf, b); fr_select(suf, lane + off < 64, suf, t);
+    }
+    total = fr_shfl(pre, 63);
+    Fr pe = fr_shfl_up(pre, 1), se = fr_shfl_down(suf, 1);
+    fr_select(pe, lane == 0, pe, one);
+    fr_select(se, lane == 63, se, one);
+    fr_mul(excl, pe, se);
+}
 
 __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
                                                 uint8_t *records, int *err) {
-    __shared__ Fr red[1024];
-    __shared__ int hit;
-    const int blob_i = blockIdx.x, tid = threadIdx.x;
+    __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16];
+    const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
-    if (tid == 0) hit = -1;
-    __syncthreads();
     const Fr z = z_in[blob_i];
-    const Fr one = fr_one();
-    Fr dd[4], pp[3];
+    Fr d[4], pw[4];
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int e = k * 1024 + tid;
         uint32_t w[8]; load_blob_element_words(w, blob, e);
         bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
-        Fr d; fr_sub(d, z, roots[e]);
-        const bool zero = fr_is_zero(d);
-        if (zero) hit = e;                                        // at most one e can match
-        fr_select(dd[k], zero, d, one);
+        const Fr om = roots[e];
+        Fr p; fr_from_words(p, w);
+        fr_mul(pw[k], p, om);                                     // p_i * w_i
+        fr_sub(d[k], z, om);                                      // z - w_i
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
-    fr_mul(pp[0], dd[0], dd[1]);
-    fr_mul(pp[1], pp[0], dd[2]);
-    fr_mul(pp[2], pp[1], dd[3]);
-    Fr inv; fr_inv(inv, pp[2]);
-    Fr sum = fr_zero();
-#pragma unroll
-    for (int k = 3; k >= 0; k--) {
-        Fr ik;                                                    // 1 / dd[k]
-        if (k > 0) { const Fr &prev = (k == 1) ? dd[0] : pp[k - 2]; fr_mul(ik, inv, prev); fr_mul(inv, inv, dd[k]); }
-        else ik = inv;
-        const int e = k * 1024 + tid;
-        uint32_t w[8]; load_blob_element_words(w, blob, e);
-        Fr p; fr_from_words(p, w);
-        Fr t; fr_mul(t, ik, roots[e]); fr_mul(t, t, p);
-        fr_add(sum, sum, t);
-    }
-    red[tid] = sum;
+    Fr a, b, L, S, t;
+    fr_mul(a, d[0], d[1]); fr_mul(b, d[2], d[3]); fr_mul(L, a, b);
+    fr_mul(t, d[1], b); fr_mul(S, pw[0], t);                      // complements of d0..d3 inside the thread
+    fr_mul(t, d[0], b); fr_mul(t, pw[1], t); fr_add(S, S, t);
+    fr_mul(t, a, d[3]); fr_mul(t, pw[2], t); fr_add(S, S, t);
+    fr_mul(t, a, d[2]); fr_mul(t, pw[3], t); fr_add(S, S, t);
+    Fr ex, tot;
+    wave_product_except_self(ex, tot, L, lane);
+    if (lane == 0) wave_tot[wid] = tot;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) { Fr a = red[tid], b = red[tid + s]; fr_add(a, a, b); red[tid] = a; }
-        __syncthreads();
+    if (wid == 0) {                                               // product of the other 15 waves' totals, for each wave
+        Fr v = lane < 16 ? wave_tot[lane] : fr_one(), e2, t2;
+        wave_product_except_self(e2, t2, v, lane);
+        if (lane < 16) wave_ex[lane] = e2;
     }
+    __syncthreads();
+    fr_mul(ex, ex, wave_ex[wid]);                                 // prod over all other threads of L
+    fr_mul(S, S, ex);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(S, off); fr_add(S, S, o); }
+    if (lane == 0) wave_sum[wid] = S;
+    __syncthreads();
     if (tid == 0) {
-        Fr y;
-        if (hit >= 0) {
-            uint32_t w[8]; load_blob_element_words(w, blob, hit);
-            fr_from_words(y, w);
-        } else {
-            const uint32_t inv4096[NFR] = FR_INV4096_INIT;
-            Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-            Fr zn = z;
-            for (int i = 0; i < 12; i++) fr_sqr(zn, zn);            // z^4096
-            fr_sub(zn, zn, one);
-            fr_mul(y, red[0], k4096);
-            fr_mul(y, y, zn);
-        }
+        Fr sum = wave_sum[0];
+        for (int i = 1; i < 16; i++) fr_add(sum, sum, wave_sum[i]);
+        const uint32_t inv4096[NFR] = FR_INV4096_INIT;
+        Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
+        Fr y; fr_mul(y, sum, k4096);
         if (y_out) y_out[blob_i] = y;
         if (records) {
             uint8_t yb[32]; fr_to_be32(yb, y);

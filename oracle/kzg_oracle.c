@@ -521,3 +521,38 @@ EXPORT void okzg_g2_gen_mul(uint8_t out[192], const uint8_t k_be[32]) {
     bls_init(); fr_t k; fr_from_be_reduce(&k, k_be); g2_t r = g2_mul_fr(&G2_GENERATOR_J, &k); g2a_t a; g2_to_affine(&a, &r);
     fp_to_be(out, &a.x.c0); fp_to_be(out + 48, &a.x.c1); fp_to_be(out + 96, &a.y.c0); fp_to_be(out + 144, &a.y.c1);
 }
+
+/* ---------------------------------------------------------------- record-level probes for the sharded (multi-GPU) path tests.
+ * A record is C(48) | z(32) | y(32) | proof(48): the per-blob body of the r-transcript (utils.rs:454-463). */
+/* Stage 1 for n blobs (kzg.rs:671-683): returns the first error or OK; records are written only for valid blobs. */
+EXPORT int okzg_shard_records(uint8_t *records, const uint8_t *blobs, const uint8_t *cs, const uint8_t *ps, size_t n, const okzg_settings *s) {
+    fr_t *poly = malloc(N_FE * sizeof(fr_t)); int rc = OK;
+    for (size_t i = 0; i < n && rc == OK; i++) {
+        g1_t tmp; fr_t z, y;
+        rc = validate_kzg_g1(&tmp, cs + 48 * i);
+        if (rc == OK) rc = blob_to_polynomial(poly, blobs + (size_t)BYTES_PER_BLOB * i);
+        if (rc == OK) rc = compute_challenge(&z, blobs + (size_t)BYTES_PER_BLOB * i, cs + 48 * i);
+        if (rc == OK) rc = evaluate_polynomial_in_evaluation_form(&y, poly, &z, s);
+        if (rc == OK) rc = validate_kzg_g1(&tmp, ps + 48 * i);
+        if (rc == OK) {
+            uint8_t *r = records + 160 * i;
+            memcpy(r, cs + 48 * i, 48); fr_to_be(r + 48, &z); fr_to_be(r + 80, &y); memcpy(r + 112, ps + 48 * i, 48);
+        }
+    }
+    free(poly); return rc;
+}
+/* Stage 2 on n gathered records (kzg.rs:579-627). */
+EXPORT int okzg_verify_records(bool *ok, const uint8_t *records, size_t n, const okzg_settings *s) {
+    if (n == 0) return BADARGS;
+    g1_t *cg = malloc(2 * n * sizeof(g1_t)), *pg = cg + n; fr_t *zs = malloc(2 * n * sizeof(fr_t)), *ys = zs + n;
+    int rc = OK;
+    for (size_t i = 0; i < n && rc == OK; i++) {
+        const uint8_t *r = records + 160 * i;
+        rc = validate_kzg_g1(&cg[i], r);
+        if (rc == OK && !fr_from_be_checked(&zs[i], r + 48)) rc = BADARGS;
+        if (rc == OK && !fr_from_be_checked(&ys[i], r + 80)) rc = BADARGS;
+        if (rc == OK) rc = validate_kzg_g1(&pg[i], r + 112);
+    }
+    if (rc == OK) rc = verify_kzg_proof_batch(ok, cg, zs, ys, pg, n, s, NULL);
+    free(cg); free(zs); return rc;
+}

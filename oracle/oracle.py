@@ -62,6 +62,8 @@ class Oracle:
         L.okzg_g2_uncompress_check.argtypes = [u8p]
         L.okzg_pairings_verify.argtypes = [C.POINTER(C.c_bool), u8p, u8p, u8p, u8p]
         L.okzg_g2_gen_mul.argtypes = [u8p, u8p]
+        L.okzg_shard_records.argtypes = [u8p, u8p, u8p, u8p, sz, vp]
+        L.okzg_verify_records.argtypes = [C.POINTER(C.c_bool), u8p, sz, vp]
 
     # ---- settings
     def load_trusted_setup(self, g1_bytes: bytes, g2_bytes: bytes, n1=None, n2=None):
@@ -224,3 +226,19 @@ class Oracle:
         out = C.create_string_buffer(192)
         self.lib.okzg_g2_gen_mul(out, bytes(k_be))
         return out.raw
+
+    # ---- record-level stages (sharded path tests)
+    def shard_records(self, blobs, cs, proofs, s):
+        n = len(blobs)
+        out = C.create_string_buffer(160 * max(n, 1))
+        rc = self.lib.okzg_shard_records(out, b"".join(blobs), b"".join(cs), b"".join(proofs), n, s)
+        if rc:
+            raise OracleError(rc)
+        return out.raw[:160 * n]
+
+    def verify_records(self, records, s):
+        ok = C.c_bool()
+        rc = self.lib.okzg_verify_records(C.byref(ok), bytes(records), len(records) // 160, s)
+        if rc:
+            raise OracleError(rc)
+        return bool(ok.value)

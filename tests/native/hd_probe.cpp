@@ -36,7 +36,11 @@ int hd_fr_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
 int hd_g1_validate(uint8_t *out, const uint8_t *in, int check_subgroup) {
     G1Affine p; int rc = g1_decompress(p, in);
     if (rc) return rc;
-    if (check_subgroup && !g1a_is_inf(p) && !g1_in_subgroup(p)) return 3;
+    if (check_subgroup && !g1a_is_inf(p)) {
+        const bool a = g1_in_subgroup(p), b = g1_in_subgroup_naive(p);
+        if (a != b) return 99;          // endomorphism test and [r]P test must agree
+        if (!a) return 3;
+    }
     g1_compress_affine(out, p); return 0;
 }
 // out = [k]P + Q (Q optional), compressed; k = 32 big-endian bytes

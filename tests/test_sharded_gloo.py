@@ -1,0 +1,115 @@
+"""world_size-2 gloo test (CPU) of the sharded verify orchestration in kzg_rust_amd/sharded.py: partitioning, the single
+all-gather of 160-byte records, gather order (= transcript order), status merging.  The compute stages are played by the
+CPU oracle here (test infrastructure); on the GPU box the same driver runs over HipEngine (tests/test_gpu_parity.py and
+bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_TOTAL = 4        # blobs per batch, 2 per rank
+GROUPS = 3         # batch 0 honest, batch 1 has swapped proofs (false), batch 2 has an invalid commitment on rank 1 (Err)
+
+
+class OracleEngine:
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.o = Oracle()
+        g = os.path.join(ROOT, "tests", "golden")
+        self.s = self.o.load_trusted_setup(open(os.path.join(g, "trusted_setup_g1.bin"), "rb").read(),
+                                           open(os.path.join(g, "trusted_setup_g2.bin"), "rb").read())
+
+    def shard_records(self, blobs, commitments, proofs, n_local, groups):
+        from oracle.oracle import OracleError
+        b, c, p = bytes(blobs.numpy()), bytes(commitments.numpy()), bytes(proofs.numpy())
+        out, st = bytearray(groups * n_local * 160), []
+        for g in range(groups):
+            lo = g * n_local
+            try:
+                rec = self.o.shard_records([b[(lo + i) * 131072:(lo + i + 1) * 131072] for i in range(n_local)],
+                                           [c[(lo + i) * 48:(lo + i + 1) * 48] for i in range(n_local)],
+                                           [p[(lo + i) * 48:(lo + i + 1) * 48] for i in range(n_local)], self.s)
+                out[lo * 160:(lo + n_local) * 160] = rec
+                st.append(0)
+            except OracleError as e:
+                st.append(e.code)
+        return torch.frombuffer(out, dtype=torch.uint8).clone(), st
+
+    def verify_records(self, records, n, groups):
+        from oracle.oracle import OracleError
+        r = bytes(records.numpy())
+        ok, st = [], []
+        for g in range(groups):
+            try:
+                ok.append(self.o.verify_records(r[g * n * 160:(g + 1) * n * 160], self.s)); st.append(0)
+            except OracleError as e:
+                ok.append(False); st.append(e.code)
+        return ok, st
+
+
+def _inputs():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.oracle import Oracle
+    from synth import random_blob
+    o = Oracle()
+    g = os.path.join(ROOT, "tests", "golden")
+    s = o.load_trusted_setup(open(os.path.join(g, "trusted_setup_g1.bin"), "rb").read(), open(os.path.join(g, "trusted_setup_g2.bin"), "rb").read())
+    blobs = [random_blob(500 + i) for i in range(N_TOTAL)]
+    cs = [o.blob_to_kzg_commitment(b, s) for b in blobs]
+    ps = [o.compute_blob_kzg_proof(b, c, s) for b, c in zip(blobs, cs)]
+    return blobs, cs, ps
+
+
+def _worker(rank, world, port, blobs, cs, ps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from kzg_rust_amd.sharded import partition, verify_blob_kzg_proof_batch_sharded
+    lo, hi = partition(N_TOTAL, world)[rank]
+    n_local = hi - lo
+    batches = []
+    for g in range(GROUPS):
+        b, c, p = blobs[lo:hi], list(cs[lo:hi]), list(ps[lo:hi])
+        if g == 1 and rank == 0:
+            p[0], p[1] = p[1], p[0]                        # valid points, wrong statement -> false
+        if g == 2 and rank == 1:
+            c[0] = bytes([0x9A]) + b"\xff" * 47            # x >= p -> Err on rank 1 only
+        batches.append((b, c, p))
+    tb = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[0])), dtype=torch.uint8)
+    tc = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[1])), dtype=torch.uint8)
+    tp = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[2])), dtype=torch.uint8)
+    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, OracleEngine())
+    q.put((rank, ok, st))
+    dist.destroy_process_group()
+
+
+def test_sharded_verify_world2_gloo():
+    blobs, cs, ps = _inputs()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, blobs, cs, ps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, st in res:                                  # identical verdicts on every rank
+        assert ok == [True, False, False], (rank, ok)
+        assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, st)
+
+
+def test_partition():
+    from kzg_rust_amd.sharded import partition
+    assert partition(512, 8)[3] == (192, 256)
+    with pytest.raises(ValueError):
+        partition(10, 4)
