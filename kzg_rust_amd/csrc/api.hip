@@ -76,7 +76,8 @@ struct Workspace {
 struct kzg355_settings {
     int device = 0;
     DeviceTables t{};
-    DevBuf roots, msm_table, lines, lines_inf, g1_first2;
+    DevBuf roots, msm_table, lines, lines_inf, g1_first2, lines_w, frob;
+    bool lane_pairing = false;
     std::mutex mu;
     std::vector<Workspace *> pool;
     bool timing = false;
@@ -160,7 +161,10 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
     tm.begin("lincomb"); launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->pair_pts.as<G1Affine>(), w->stream); tm.end();
-    tm.begin("pairing"); launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream); tm.end();
+    tm.begin("pairing");
+    if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
+    else launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
+    tm.end();
     return KZG355_OK;
 }
 
@@ -320,6 +324,8 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     if ((rc = s->lines.ensure(sizeof(LineCoeff) * 3 * N_LINES))) return fail(rc);
     if ((rc = s->lines_inf.ensure(sizeof(int) * 3))) return fail(rc);
     if ((rc = s->g1_first2.ensure(sizeof(G1Affine) * 2))) return fail(rc);
+    if ((rc = s->lines_w.ensure(sizeof(LineW) * 3 * N_LINES))) return fail(rc);
+    if ((rc = s->frob.ensure(sizeof(FrobTables)))) return fail(rc);
     if ((rc = g1b.ensure(48 * n1))) return fail(rc);
     if ((rc = g2b.ensure(96 * n2))) return fail(rc);
     if ((rc = err.ensure(sizeof(int)))) return fail(rc);
@@ -328,10 +334,20 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     s->t.lines = s->lines.as<LineCoeff>();
     s->t.lines_inf = s->lines_inf.as<int>();
     s->t.g1_first2 = s->g1_first2.as<G1Affine>();
+    s->t.lines_w = s->lines_w.as<LineW>();
+    s->t.frob = s->frob.as<FrobTables>();
+    {
+        static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
+        FrobTables ft;
+        for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
+        if (hipMemcpy(s->frob.p, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    }
+    if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);
     launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr);
+    launch_lines_to_w(s->t, nullptr);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_NO_DEVICE);
     int herr = 0;
     if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_NO_DEVICE);
@@ -387,6 +403,7 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
     s->roots.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
+    s->lines_w.release(); s->frob.release();
     delete s;
 }
 

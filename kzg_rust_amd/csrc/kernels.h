@@ -9,6 +9,7 @@
 #include "g1.h"
 #include "pairing.h"
 #include "sha256.h"
+#include "pairing_coop.h"
 
 namespace kzg {
 
@@ -32,6 +33,8 @@ struct DeviceTables {
     LineCoeff *lines;        // [3][68]: Miller-loop lines of G2_GENERATOR, setup g2[0], setup g2[1]
     int *lines_inf;          // [3] 1 if that G2 point is the point at infinity
     G1Affine *g1_first2;     // file-order g1[0], g1[1] (only for the Lagrange-form check)
+    LineW *lines_w;          // [3][68]: the same lines in the w basis (pairing_coop.h)
+    FrobTables *frob;        // w-basis Frobenius tables
 };
 
 // ---- k_setup.hip
@@ -53,7 +56,11 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
                     uint32_t *d_scal_c, int *d_err, hipStream_t st);
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                     int n_per_group, int groups, G1Affine *d_pair_pts /* [group][2] */, hipStream_t st);
-void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);
+void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
+void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
+
+// ---- k_pairing.hip
+void launch_lines_to_w(DeviceTables t, hipStream_t st);
 
 // ---- k_msm.hip
 void launch_digits_from_blobs(const uint8_t *d_blobs, int n, uint8_t *d_digits /* [n][32][4096] */, int *d_err /* per blob */, hipStream_t st);

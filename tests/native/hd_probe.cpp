@@ -6,6 +6,7 @@
 #include "../../kzg_rust_amd/csrc/g1.h"
 #include "../../kzg_rust_amd/csrc/pairing.h"
 #include "../../kzg_rust_amd/csrc/sha256.h"
+#include "../../kzg_rust_amd/csrc/pairing_coop.h"
 #include <vector>
 using namespace kzg;
 extern "C" {
@@ -75,6 +76,24 @@ int hd_pairings_verify(int *ok, const uint8_t *p1, const uint8_t *q1, const uint
     if (g2a_is_inf(qb)) b = g1a_inf(); else precompute_lines(l2.data(), qb);
     miller_loop_pair(f, l1.data(), an, l2.data(), b);
     *ok = final_exp_is_one(f) ? 1 : 0;
+    return 0;
+}
+// same check through the wave-cooperative pairing (host emulation of the 64 lanes)
+int hd_pairings_verify_coop(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {
+    G1Affine a, b; G2Affine qa, qb;
+    if (g1_decompress(a, p1) || g1_decompress(b, p2) || g2_decompress(qa, q1) || g2_decompress(qb, q2)) return 1;
+    std::vector<LineCoeff> l1(N_LINES), l2(N_LINES);
+    std::vector<LineW> w1(N_LINES), w2(N_LINES);
+    G1Affine an; g1a_neg(an, a); if (g1a_is_inf(a)) an = a;
+    if (g2a_is_inf(qa)) an = g1a_inf(); else precompute_lines(l1.data(), qa);
+    if (g2a_is_inf(qb)) b = g1a_inf(); else precompute_lines(l2.data(), qb);
+    for (int i = 0; i < N_LINES; i++) { line_to_w(w1[i], l1[i]); line_to_w(w2[i], l2[i]); }
+    static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
+    FrobTables ft;
+    for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
+    CoopMem *mem = new CoopMem();
+    *ok = coop_pairing_check(*mem, w1.data(), an, w2.data(), b, ft) ? 1 : 0;
+    delete mem;
     return 0;
 }
 void hd_sha256(uint8_t *out, const uint8_t *msg, uint64_t len) { sha256_bytes(out, msg, len); }

@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "sha256.h", "consts_gen.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "sha256.h", "consts_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
@@ -157,8 +157,11 @@ def test_g2_decompress_and_pairing(hd, oracle, setup_bytes):
     cases = [(aG, q0, aG, q0), (aG, q0, G1_GEN, q0), (aG, q1, G1_GEN, q0), (INF, q0, INF, q1), (INF, q0, G1_GEN, q1),
              (g1[:48], q1, g1[48:96], q0), (g1[48:96], q0, g1[:48], q1)]
     for p1, qa, p2, qb in cases:
+        want = oracle.pairings_verify(p1, qa, p2, qb)
         assert hd.hd_pairings_verify(C.byref(ok), p1, qa, p2, qb) == 0
-        assert bool(ok.value) == oracle.pairings_verify(p1, qa, p2, qb)
+        assert bool(ok.value) == want
+        assert hd.hd_pairings_verify_coop(C.byref(ok), p1, qa, p2, qb) == 0      # wave-cooperative variant
+        assert bool(ok.value) == want
     # bilinearity: e([a]G, [tau]G2) == e([a][tau]... ) cannot be formed without tau; use e(aG, Q) == e(G, Q)^a via
     # e([a]G, Q) == e([a]G, Q) (true) and e([a]G, Q) == e([a+1]G, Q) (false)
     a1G = oracle.g1_mul_add(G1_GEN, ((a + 1) % R).to_bytes(32, "big"))
