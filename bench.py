@@ -4,12 +4,14 @@
 Restates benches/kzg_benches.rs:93-126 (criterion group `verify_blob_kzg_proof_batch`, Throughput::Elements(n)):
   * inputs (benches/kzg_benches.rs:7-44): 64 random canonical blobs per batch, honest commitments and proofs made with
     the library itself (untimed setup), so every verification returns true -- asserted for every step;
-  * a STEP is one verify_blob_kzg_proof_batch over one batch: 64 blobs at N=1; at N GPUs one batch of 64*N blobs
-    sharded 64 per rank (BASELINE.json configs[3] / configs[4]);
-  * inputs are resident in HBM when the timed region starts; the engine is called through the C ABI
-    (kzg355_verify_blob_kzg_proof_batch_many_device, or the two stage functions around the all-gather for N > 1).
-The chip is far from filled by one 64-blob batch (the path is latency-bound integer work), so `--concurrent C`
-independent steps are submitted per launch set (default below); K steps are always executed and timed exactly.
+  * the unit of work is one verify_blob_kzg_proof_batch call over a 64-blob batch (BASELINE.json configs[3]); at N GPUs
+    the batch is 64*N blobs sharded 64 per rank with one all-gather of the 160-byte records (configs[4]);
+  * a STEP is one pass of the hot path (one set of kernel launches) over the step's synthetic input: G independent
+    64-blob batches (`--batches-per-step G`), submitted together through kzg355_verify_blob_kzg_proof_batch_many_device
+    (or the two stage functions around the all-gather for N > 1).  One 64-blob batch is a chain of latency-bound integer
+    kernels that occupies a handful of the chip's 1024 SIMDs, so whole-job throughput needs many batches in flight;
+    `config.latency_ms_single_batch` reports one batch alone.  K steps are executed and timed exactly;
+  * inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and `cpu_baseline` objects.
 """
@@ -44,9 +46,10 @@ FAMILIES = list(KERNEL_BYTES_PER_BLOB)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--concurrent", type=int, default=128, help="independent steps (batches) submitted per launch set")
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=1024,
+                    help="independent 64-blob batches verified by one step (one launch set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -74,17 +77,23 @@ def main():
     s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
     assert s.device == local_rank
 
-    K, W = args.steps, args.warmup
-    Cc = max(1, min(args.concurrent, max(K, 1)))
+    K, W = max(1, args.steps), max(0, args.warmup)
+    Cc = max(1, args.concurrent)
     n_local = N_PER_BATCH
-    # ---- untimed setup: Cc distinct batches per launch set; this rank owns blobs [rank*64, rank*64+64) of each batch
+    # ---- untimed setup: Cc distinct batches per step; this rank owns blobs [rank*64, rank*64+64) of each batch.
+    # Bench recipe (benches/kzg_benches.rs:14-23): random bytes, byte 0 of every 32-byte element forced to 0.  The first
+    # batch comes from the seeded splitmix64 stream of tests/synth.py (it is also the CPU baseline's input); the rest is
+    # drawn on the device from a fixed-seed torch generator.
     n_blobs = Cc * n_local
-    host = bytearray(n_blobs * BLOB)
-    for g in range(Cc):
-        for i in range(n_local):
-            idx = (g * world + rank) * n_local + i
-            host[(g * n_local + i) * BLOB:(g * n_local + i + 1) * BLOB] = random_blob(idx)
-    t_blobs = torch.frombuffer(host, dtype=torch.uint8).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(0x4844 + rank)
+    t_blobs = torch.randint(0, 256, (n_blobs, BLOB // 32, 32), dtype=torch.uint8, device=dev, generator=gen)
+    t_blobs[:, :, 0] = 0
+    host = bytearray(n_local * BLOB)
+    for i in range(n_local):
+        host[i * BLOB:(i + 1) * BLOB] = random_blob(rank * n_local + i)
+    t_blobs = t_blobs.reshape(-1).contiguous()
+    t_blobs[:n_local * BLOB] = torch.frombuffer(host, dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
     out = C.create_string_buffer(48 * n_blobs)
     st = (C.c_int * n_blobs)()
     rc = L.kzg355_blob_to_kzg_commitment_many_device(out, st, t_blobs.data_ptr(), n_blobs, s.handle)
@@ -133,16 +142,14 @@ def main():
         barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
     latency_ms = sorted(lat)[len(lat) // 2]
 
-    done = 0
-    while done < W:
-        g = min(Cc, W - done); run_steps(g); done += g
+    for _ in range(W):
+        run_steps(Cc)
     L.kzg355_reset_kernel_stats(s.handle)
     s.set_kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
-    done = 0
-    while done < K:
-        g = min(Cc, K - done); run_steps(g); done += g
+    for _ in range(K):
+        run_steps(Cc)
     barrier()
     dt = time.perf_counter() - t0
     s.set_kernel_timing(False)
@@ -151,7 +158,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    blobs_total = K * n_local * world
+    blobs_total = K * Cc * n_local * world
     value = blobs_total / dt
 
     # ---- roofline of the dominant kernel (HIP events recorded on the launch stream during the timed region)
@@ -178,7 +185,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = time_cpu_baseline(commitments, proofs, host, n_local)
+        cpu_baseline = time_cpu_baseline(commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
 
     if rank == 0:
         line = {
@@ -188,8 +195,8 @@ def main():
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
             "config": {"workload": "kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch"
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-gather of 160-B records"),
-                       "blobs_per_step": n_local * world, "concurrent_steps_per_launch": Cc, "field_elements_per_blob": 4096,
-                       "inputs": "resident in HBM", "latency_ms_single_step": round(latency_ms, 3)},
+                       "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
+                       "field_elements_per_blob": 4096, "inputs": "resident in HBM", "latency_ms_single_batch": round(latency_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

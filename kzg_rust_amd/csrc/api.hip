@@ -59,12 +59,12 @@ struct PinBuf {
 // concurrent host threads get different workspaces from the pool in the settings handle.
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials;
     PinBuf h_ok, h_err, h_out;
     hipEvent_t ev[32];
     bool ev_ok = false;
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small}) b->release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials}) b->release();
         h_ok.release(); h_err.release(); h_out.release();
         if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
         if (stream) hipStreamDestroy(stream);
@@ -159,8 +159,9 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
+    if ((rc = w->lc_partials.ensure(lincomb_partials_bytes(npg, groups)))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
-    tm.begin("lincomb"); launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->pair_pts.as<G1Affine>(), w->stream); tm.end();
+    tm.begin("lincomb"); launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream); tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
     else launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);

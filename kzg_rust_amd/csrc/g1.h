@@ -158,6 +158,40 @@ KZG_HD bool g1_in_subgroup_naive(const G1Affine &p) {
     return g1_is_inf(t);
 }
 
+// GLV split of a scalar against the endomorphism phi(x,y) = (beta x, y) = [-x^2]:  k = a + b * x^2  (a = k mod x^2,
+// b = k div x^2, both < 2^128 for k < r), hence  [k]P = [a]P + [b](-phi(P)),  -phi(P) = (beta x, -y).
+// Restoring division by the 128-bit constant x^2 = 0xac45a4010001a4020000000100000000.
+KZG_HD void glv_split(uint32_t a[4], uint32_t b[4], const uint32_t k[8]) {
+    const uint32_t X2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;      // remainder, up to 129 bits
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    for (int w = 7; w >= 0; w--) {
+        uint32_t x = k[w];
+        for (int i = 0; i < 32; i++) {
+            r4 = (r4 << 1) | (r3 >> 31); r3 = (r3 << 1) | (r2 >> 31); r2 = (r2 << 1) | (r1 >> 31); r1 = (r1 << 1) | (r0 >> 31);
+            r0 = (r0 << 1) | (x >> 31); x <<= 1;
+            // t = r - X2
+            uint64_t d = (uint64_t)r0 - X2[0]; uint32_t t0 = (uint32_t)d; uint32_t br = (uint32_t)(d >> 63);
+            d = (uint64_t)r1 - X2[1] - br; uint32_t t1 = (uint32_t)d; br = (uint32_t)(d >> 63);
+            d = (uint64_t)r2 - X2[2] - br; uint32_t t2 = (uint32_t)d; br = (uint32_t)(d >> 63);
+            d = (uint64_t)r3 - X2[3] - br; uint32_t t3 = (uint32_t)d; br = (uint32_t)(d >> 63);
+            const bool ge = r4 != 0 || br == 0;
+            r0 = ge ? t0 : r0; r1 = ge ? t1 : r1; r2 = ge ? t2 : r2; r3 = ge ? t3 : r3; r4 = ge ? 0u : r4;
+            q3 = (q3 << 1) | (q2 >> 31); q2 = (q2 << 1) | (q1 >> 31); q1 = (q1 << 1) | (q0 >> 31); q0 = (q0 << 1) | (ge ? 1u : 0u);
+        }
+    }
+    a[0] = r0; a[1] = r1; a[2] = r2; a[3] = r3;
+    b[0] = q0; b[1] = q1; b[2] = q2; b[3] = q3;
+}
+// -phi(P) = (beta x, -y)
+KZG_HD void g1a_neg_phi(G1Affine &r, const G1Affine &p) {
+    const uint32_t bc[NFP] = FP_BETA_INIT;
+    Fp beta; for (int i = 0; i < NFP; i++) beta.l[i] = bc[i];
+    fp_mul(r.x, p.x, beta);
+    fp_neg(r.y, p.y);
+    if (g1a_is_inf(p)) r = p;
+}
+
 // ZCash compressed encoding of an affine point ((0,0) = infinity)
 KZG_HD void g1_compress_affine(uint8_t *out, const G1Affine &p) {
     if (g1a_is_inf(p)) {

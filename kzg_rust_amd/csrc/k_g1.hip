@@ -47,19 +47,37 @@ __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *recor
 }
 
 // ------------------------------------------------------------------------------------------------ lincomb
-// One 256-thread workgroup per batch.  Terms (3n + 1 scalar multiplications, each 256-bit double-and-add):
+// The 3n + 1 scalar multiplications of one batch
 //   class 0:  a_i * proof_i                                   -> proof_lincomb         (kzg.rs:601)
 //   class 1:  b_i * proof_i,  a_i * C_i,  c * (-G)            -> rhs                   (kzg.rs:603-622)
-// then an LDS tree reduction per class.  Output: (-proof_lincomb, rhs) as affine points for the pairing.
-constexpr int LINCOMB_THREADS = 256;
-__global__ void __launch_bounds__(LINCOMB_THREADS) k_lincomb(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b,
-                                                               const uint32_t *scal_c, int n, G1Affine *pair_pts) {
-    __shared__ G1Jac red[LINCOMB_THREADS];
-    const int g = blockIdx.x, tid = threadIdx.x;
+// are each split with the GLV endomorphism into two 128-bit halves  [k]P = [k mod x^2]P + [k div x^2](-phi P)
+// placed on two different lanes: 2(3n+1) items per batch, each a 128-step double-and-add chain.
+//
+// Latency matters here (a lone wave issues one instruction per ~5 cycles; two waves sharing a SIMD each drop to one per
+// ~9), so the items are dealt to ONE-WAVE workgroups that the dispatcher spreads over different CUs:
+//   k_lincomb_terms   one 64-lane workgroup per 64 items: scalar multiplication, then a butterfly sum per class over
+//                     the wave (shuffles, no LDS) -> 2 partial points per wave
+//   k_lincomb_finish  one workgroup per batch: lane c sums the partials of class c and converts to affine (the two
+//                     inversions run side by side) -> (-proof_lincomb, rhs) for the pairing.
+__device__ __forceinline__ G1Jac g1_shfl_xor(const G1Jac &v, int mask) {
+    G1Jac r;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask, 64); }
+    return r;
+}
+__host__ __device__ inline int lincomb_waves_per_group(int n) { return (2 * (3 * n + 1) + 63) / 64; }
+
+__global__ void __launch_bounds__(64) k_lincomb_terms(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b,
+                                                       const uint32_t *scal_c, int n, G1Jac *partials) {
+    const int wpg = lincomb_waves_per_group(n);
+    const int g = blockIdx.x / wpg, wv = blockIdx.x % wpg, lane = threadIdx.x;
+    const int item = wv * 64 + lane;
     const G1Affine *gp = pts + (size_t)g * 2 * n;        // [0,n) commitments, [n,2n) proofs
-    G1Jac acc0 = g1_inf(), acc1 = g1_inf();
-    for (int t = tid; t < 3 * n + 1; t += LINCOMB_THREADS) {
-        G1Affine p; uint32_t k[8]; int cls;
+    G1Jac m = g1_inf();
+    int cls = -1;
+    if (item < 2 * (3 * n + 1)) {
+        const int t = item >> 1, half = item & 1;
+        G1Affine p; uint32_t k[8];
         if (t < n) { p = gp[n + t]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + t) + q]; cls = 0; }
         else if (t < 2 * n) { p = gp[n + (t - n)]; for (int q = 0; q < 8; q++) k[q] = scal_b[8 * ((size_t)g * n + (t - n)) + q]; cls = 1; }
         else if (t < 3 * n) { p = gp[t - 2 * n]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + (t - 2 * n)) + q]; cls = 1; }
@@ -70,27 +88,32 @@ __global__ void __launch_bounds__(LINCOMB_THREADS) k_lincomb(const G1Affine *pts
             for (int q = 0; q < 8; q++) k[q] = scal_c[8 * (size_t)g + q];
             cls = 1;
         }
-        G1Jac m; g1_mul_words(m, p, k, 8);
-        if (cls == 0) g1_add(acc0, acc0, m); else g1_add(acc1, acc1, m);
+        uint32_t ka[4], kb[4];
+        glv_split(ka, kb, k);
+        if (half) { G1Affine q; g1a_neg_phi(q, p); p = q; }
+        g1_mul_words(m, p, half ? kb : ka, 4);
     }
-    G1Jac total[2];
-    for (int cls = 0; cls < 2; cls++) {
-        red[tid] = cls == 0 ? acc0 : acc1;
-        __syncthreads();
-        for (int s = LINCOMB_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
-            __syncthreads();
+    for (int c = 0; c < 2; c++) {
+        G1Jac v = g1_inf();
+        if (__ballot(cls == c) != 0ull) {                   // wave-uniform: skip a class nobody in this wave holds
+            if (cls == c) v = m;
+#pragma unroll 1
+            for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(v, off); g1_add(v, v, o); }
         }
-        if (tid == 0) total[cls] = red[0];
-        __syncthreads();
+        if (lane == 0) partials[((size_t)g * wpg + wv) * 2 + c] = v;
     }
-    if (tid == 0) {
-        G1Affine a0, a1;
-        g1_to_affine(a0, total[0]); g1_to_affine(a1, total[1]);
-        if (!g1a_is_inf(a0)) fp_neg(a0.y, a0.y);             // pairings_verify negates its first G1 argument (utils.rs:198-201)
-        pair_pts[2 * (size_t)g] = a0;
-        pair_pts[2 * (size_t)g + 1] = a1;
-    }
+}
+
+__global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, int n, G1Affine *pair_pts) {
+    const int wpg = lincomb_waves_per_group(n);
+    const int g = blockIdx.x, c = threadIdx.x;
+    if (c >= 2) return;
+    G1Jac acc = g1_inf();
+    for (int wv = 0; wv < wpg; wv++) { G1Jac v = partials[((size_t)g * wpg + wv) * 2 + c]; g1_add(acc, acc, v); }
+    G1Affine a;
+    g1_to_affine(a, acc);
+    if (c == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);          // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[2 * (size_t)g + c] = a;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -104,9 +127,12 @@ void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per
     hipLaunchKernelGGL(k_points_from_records, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_records, n_total, n_per_group, d_pts, d_err);
 }
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                    int groups, G1Affine *d_pair_pts, hipStream_t st) {
+                    int groups, G1Jac *d_partials, G1Affine *d_pair_pts, hipStream_t st) {
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_lincomb, dim3(groups), dim3(LINCOMB_THREADS), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_pair_pts);
+    const int wpg = lincomb_waves_per_group(n_per_group);
+    hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials);
+    hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
 }
+size_t lincomb_partials_bytes(int n_per_group, int groups) { return sizeof(G1Jac) * 2 * (size_t)lincomb_waves_per_group(n_per_group) * groups; }
 
 }  // namespace kzg

@@ -2,114 +2,118 @@
 //   y   = p(z)                                         (kzg.rs:467, evaluate_polynomial_in_evaluation_form)
 //   q_i = (p_i - y) / (w_i - z)            i != m      (kzg.rs:470-490)
 //   q_m = sum_{i != m} (p_i - y) w_i / (z (z - w_i))   when z == w_m is inside the domain (kzg.rs:494-523)
-// One 1024-thread workgroup per blob, 4 elements per thread; the per-element inverses 1/(z - w_i) computed for the
-// evaluation are reused for the quotient, so the reference's second and third batch inversions disappear:
-//   q_i = (y - p_i) * inv_i ,   q_m = z^-1 * sum_{i != m} (p_i - y) w_i inv_i .
+// One 1024-thread workgroup per blob, 4 elements per thread.  Instead of the reference's three 4096-long batch
+// inversions, T_i = prod_{j != i} (z - w_j) comes from the same "product of all the others" scan as k_eval, and
+//     1/(z - w_i) = T_i * W,   W = 1/(z^N - 1)                       (one Fr inversion per blob)
+// In-domain z = w_m: the factor (z - w_m) is replaced by 1 in the scan, so T_i = prod_{j != i,m}(w_m - w_j) and
+//     1/(w_m - w_i) = T_i * w_m / N   (prod_{j != m}(w_m - w_j) = N w_m^(N-1) = N / w_m),  z^-1 = z^(N-1):  no inversion.
+// y = (1/N) sum p_i w_i T_i  (or p_m), q_i = (y - p_i) / (z - w_i), q_m = -z^-1 sum_{i != m} q_i w_i.
 // The 4096-point MSM over q is k_msm.hip.
-#define KZG_FP_MUL_NOINLINE 1
 #include "kernels.h"
+#include "fr_block.h"
 
 namespace kzg {
 
-__device__ __forceinline__ void load_element_words(uint32_t w[8], const uint8_t *blob, int e) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(blob + 32 * (size_t)e);
-    uint4 a = p[0], b = p[1];
-    w[7] = __builtin_bswap32(a.x); w[6] = __builtin_bswap32(a.y); w[5] = __builtin_bswap32(a.z); w[4] = __builtin_bswap32(a.w);
-    w[3] = __builtin_bswap32(b.x); w[2] = __builtin_bswap32(b.y); w[1] = __builtin_bswap32(b.z); w[0] = __builtin_bswap32(b.w);
-}
-
-__device__ __forceinline__ Fr block_sum_1024(Fr *red, const Fr &v, int tid) {
-    red[tid] = v;
+__device__ __forceinline__ Fr block_sum_1024(Fr *wave_sum, Fr v, int lane, int wid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(v, off); fr_add(v, v, o); }
+    __syncthreads();                       // wave_sum may still be read from a previous call
+    if (lane == 0) wave_sum[wid] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) { Fr a = red[tid], b = red[tid + s]; fr_add(a, a, b); red[tid] = a; }
-        __syncthreads();
-    }
-    Fr r = red[0];
-    __syncthreads();
-    return r;
+    Fr sum = wave_sum[0];
+    for (int i = 1; i < 16; i++) fr_add(sum, sum, wave_sum[i]);
+    return sum;
 }
 
 __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const Fr *z_in, const Fr *roots, Fr *y_out, Fr *q_out, int *err) {
-    __shared__ Fr red[1024];
+    __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16], bcast;
     __shared__ int hit;
-    const int blob_i = blockIdx.x, tid = threadIdx.x;
+    const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
     Fr *q = q_out + (size_t)N_FE * blob_i;
     if (tid == 0) hit = -1;
     __syncthreads();
     const Fr z = z_in[blob_i];
     const Fr one = fr_one();
-    Fr inv[4];
-    {
-        Fr dd[4], pp[3];
-        bool bad = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = k * 1024 + tid;
-            uint32_t w[8]; load_element_words(w, blob, e);
-            bad = bad || !fr_words_canonical(w);
-            Fr d; fr_sub(d, z, roots[e]);
-            const bool zero = fr_is_zero(d);
-            if (zero) hit = e;
-            fr_select(dd[k], zero, d, one);
-        }
-        if (bad) atomicOr(&err[blob_i], ERR_NONCANONICAL_FR);
-        fr_mul(pp[0], dd[0], dd[1]);
-        fr_mul(pp[1], pp[0], dd[2]);
-        fr_mul(pp[2], pp[1], dd[3]);
-        Fr t; fr_inv(t, pp[2]);
-        fr_mul(inv[3], t, pp[1]); fr_mul(t, t, dd[3]);
-        fr_mul(inv[2], t, pp[0]); fr_mul(t, t, dd[2]);
-        fr_mul(inv[1], t, dd[0]); fr_mul(t, t, dd[1]);
-        inv[0] = t;
-    }
-    Fr sum = fr_zero();
+    Fr d[4], p[4];
+    bool bad = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int e = k * 1024 + tid;
-        uint32_t w[8]; load_element_words(w, blob, e);
-        Fr p; fr_from_words(p, w);
-        Fr t; fr_mul(t, inv[k], roots[e]); fr_mul(t, t, p);
-        fr_add(sum, sum, t);
+        uint32_t w[8]; load_blob_element_words(w, blob, e);
+        bad = bad || !fr_words_canonical(w);                      // blob_to_polynomial (kzg.rs:282-291)
+        fr_from_words(p[k], w);
+        Fr t; fr_sub(t, z, roots[e]);
+        const bool zero = fr_is_zero(t);
+        if (zero) hit = e;                                        // at most one element can match
+        fr_select(d[k], zero, t, one);
     }
-    sum = block_sum_1024(red, sum, tid);
-    const int m = hit;                                   // uniform after the barriers above
+    if (bad) atomicOr(&err[blob_i], ERR_NONCANONICAL_FR);
+    Fr a, b, L, T[4];
+    fr_mul(a, d[0], d[1]); fr_mul(b, d[2], d[3]); fr_mul(L, a, b);
+    fr_mul(T[0], d[1], b); fr_mul(T[1], d[0], b); fr_mul(T[2], a, d[3]); fr_mul(T[3], a, d[2]);
+    Fr ex, tot;
+    wave_product_except_self(ex, tot, L, lane);
+    if (lane == 0) wave_tot[wid] = tot;
+    __syncthreads();
+    if (wid == 0) {
+        Fr v = lane < 16 ? wave_tot[lane] : one, e2, t2;
+        wave_product_except_self(e2, t2, v, lane);
+        if (lane < 16) wave_ex[lane] = e2;
+    }
+    __syncthreads();
+    const int m = hit;                                            // block-uniform from here on
+    fr_mul(ex, ex, wave_ex[wid]);
+    Fr S = fr_zero();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        fr_mul(T[k], T[k], ex);                                   // prod over all other (non-hit) elements of (z - w_j)
+        Fr t; fr_mul(t, p[k], roots[k * 1024 + tid]); fr_mul(t, t, T[k]);
+        fr_add(S, S, t);
+    }
+    S = block_sum_1024(wave_sum, S, lane, wid);
+    const uint32_t inv4096[NFR] = FR_INV4096_INIT;
+    Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
     Fr y;
     if (m >= 0) {
-        uint32_t w[8]; load_element_words(w, blob, m);
-        fr_from_words(y, w);                             // kzg.rs:360-362
+        uint32_t w[8]; load_blob_element_words(w, blob, m);
+        fr_from_words(y, w);                                      // kzg.rs:360-362
     } else {
-        const uint32_t inv4096[NFR] = FR_INV4096_INIT;
-        Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-        Fr zn = z;
-        for (int i = 0; i < 12; i++) fr_sqr(zn, zn);
-        fr_sub(zn, zn, one);
-        fr_mul(y, sum, k4096);
-        fr_mul(y, y, zn);
+        fr_mul(y, S, k4096);
     }
-    if (tid == 0) y_out[blob_i] = y;
-    Fr sum2 = fr_zero();
+    // W with 1/(z - w_i) = T_i * W
+    if (tid == 0) {
+        Fr W;
+        if (m >= 0) fr_mul(W, z, k4096);                          // w_m / N
+        else {
+            Fr zn = z;
+            for (int i = 0; i < 12; i++) fr_sqr(zn, zn);
+            fr_sub(zn, zn, one);                                  // z^N - 1 != 0 outside the domain
+            fr_inv(W, zn);
+        }
+        bcast = W;
+        y_out[blob_i] = y;
+    }
+    __syncthreads();
+    const Fr W = bcast;
+    Fr S2 = fr_zero();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int e = k * 1024 + tid;
-        uint32_t w[8]; load_element_words(w, blob, e);
-        Fr p; fr_from_words(p, w);
-        Fr ymp; fr_sub(ymp, y, p);                       // y - p_i
-        if (e != m) {
-            Fr qe; fr_mul(qe, ymp, inv[k]);              // (p_i - y)/(w_i - z)
-            q[e] = qe;
-            if (m >= 0) {                                // (p_i - y) w_i / (z - w_i), accumulated for q_m
-                Fr t; fr_mul(t, qe, roots[e]);           // = (y - p_i) w_i inv_i
-                fr_sub(sum2, sum2, t);
-            }
-        }
+        if (e == m) continue;
+        Fr inv, ymp, qe;
+        fr_mul(inv, T[k], W);                                     // 1 / (z - w_i)
+        fr_sub(ymp, y, p[k]);
+        fr_mul(qe, ymp, inv);                                     // (p_i - y) / (w_i - z)
+        q[e] = qe;
+        if (m >= 0) { Fr t; fr_mul(t, qe, roots[e]); fr_sub(S2, S2, t); }   // + (p_i - y) w_i / (z - w_i)
     }
     if (m >= 0) {
-        sum2 = block_sum_1024(red, sum2, tid);
+        S2 = block_sum_1024(wave_sum, S2, lane, wid);
         if (tid == 0) {
-            Fr zi; fr_inv(zi, z);
-            Fr qm; fr_mul(qm, sum2, zi);
+            Fr zi = one, zz = z;                                  // z^-1 = z^(N-1) = z^4095 for z in the domain
+            for (int i = 0; i < 12; i++) { fr_mul(zi, zi, zz); fr_sqr(zz, zz); }
+            Fr qm; fr_mul(qm, S2, zi);
             q[m] = qm;
         }
     }

@@ -13,10 +13,10 @@
 // group element, so the same boolean.
 #define KZG_FP_MUL_NOINLINE 1
 #include "kernels.h"
+#include "fr_block.h"
 
 namespace kzg {
 
-__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 
 // ------------------------------------------------------------------------------------------------ challenge
 // One lane per blob: SHA-256 over  "FSBLOBVERIFY_V1_" | u64be(0) | u64be(4096) | blob | commitment  (131,152 bytes,
@@ -87,51 +87,6 @@ __global__ void __launch_bounds__(64) k_challenge(const uint8_t *blobs, const ui
 // blob and of the roots table); per thread  L_t = d0 d1 d2 d3  and the three-factor complements; across threads an
 // exclusive prefix * suffix product with wave shuffles (6+6 steps) and a 16-entry LDS stage; then a shuffle/LDS sum.
 // ~34 Fr products per thread instead of ~410 (one Fermat inversion per thread) in the first version of this kernel.
-KZG_HD void load_blob_element_words(uint32_t w[8], const uint8_t *blob, int e) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 *p = reinterpret_cast<const uint4 *>(blob + 32 * (size_t)e);
-    uint4 a = p[0], b = p[1];
-    w[7] = bswap32(a.x); w[6] = bswap32(a.y); w[5] = bswap32(a.z); w[4] = bswap32(a.w);
-    w[3] = bswap32(b.x); w[2] = bswap32(b.y); w[1] = bswap32(b.z); w[0] = bswap32(b.w);
-#else
-    be32_to_words(w, blob + 32 * (size_t)e);
-#endif
-}
-__device__ __forceinline__ Fr fr_shfl_up(const Fr &v, int delta) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < NFR; i++) r.l[i] = __shfl_up(v.l[i], delta, 64);
-    return r;
-}
-__device__ __forceinline__ Fr fr_shfl_down(const Fr &v, int delta) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < NFR; i++) r.l[i] = __shfl_down(v.l[i], delta, 64);
-    return r;
-}
-__device__ __forceinline__ Fr fr_shfl(const Fr &v, int src) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < NFR; i++) r.l[i] = __shfl(v.l[i], src, 64);
-    return r;
-}
-// product over the other lanes of the wave: exclusive prefix * exclusive suffix; also returns the wave total
-__device__ __forceinline__ void wave_product_except_self(Fr &excl, Fr &total, const Fr &v, int lane) {
-    const Fr one = fr_one();
-    Fr pre = v, suf = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        Fr a = fr_shfl_up(pre, off), b = fr_shfl_down(suf, off), t;
-        fr_mul(t, pre, a); fr_select(pre, lane >= off, pre, t);
-        fr_mul(t, suf, b); fr_select(suf, lane + off < 64, suf, t);
-    }
-    total = fr_shfl(pre, 63);
-    Fr pe = fr_shfl_up(pre, 1), se = fr_shfl_down(suf, 1);
-    fr_select(pe, lane == 0, pe, one);
-    fr_select(se, lane == 63, se, one);
-    fr_mul(excl, pe, se);
-}
-
 __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
                                                 uint8_t *records, int *err) {
     __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16];

@@ -55,7 +55,9 @@ void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st);
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                    int n_per_group, int groups, G1Affine *d_pair_pts /* [group][2] */, hipStream_t st);
+                    int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, G1Affine *d_pair_pts /* [group][2] */,
+                    hipStream_t st);
+size_t lincomb_partials_bytes(int n_per_group, int groups);
 void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 

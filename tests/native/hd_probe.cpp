@@ -64,6 +64,17 @@ int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
     g1_add(r, pj, qj);
     g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
 }
+// [k]P through the GLV split: [k mod x^2]P + [k div x^2](-phi P)
+int hd_glv_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be) {
+    G1Affine pa, qa, ra; G1Jac r1, r2; uint32_t w[8], a[4], b[4];
+    if (g1_decompress(pa, p)) return 1;
+    be32_to_words(w, k_be);
+    glv_split(a, b, w);
+    g1a_neg_phi(qa, pa);
+    g1_mul_words(r1, pa, a, 4); g1_mul_words(r2, qa, b, 4);
+    g1_add(r1, r1, r2);
+    g1_to_affine(ra, r1); g1_compress_affine(out, ra); return 0;
+}
 int hd_g2_decompress(const uint8_t *in) { G2Affine q; return g2_decompress(q, in); }
 // e(p1,q1) == e(p2,q2) via precomputed lines: ML(q1,-p1) * ML(q2,p2)
 int hd_pairings_verify(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {

@@ -133,6 +133,13 @@ def test_g1_mul_add(hd, oracle, setup_bytes):
                 out = C.create_string_buffer(48)
                 assert hd.hd_g1_mul_add(out, p, kb, q) == 0
                 assert out.raw == oracle.g1_mul_add(p, kb, q)
+    # GLV split (used by k_lincomb): scalars are < r there
+    for p in pts:
+        for k in [0, 1, 2, R - 1, (1 << 128) - 1, 1 << 128, 0xac45a4010001a4020000000100000000, 0xac45a4010001a4020000000100000000 - 1] + [rnd.randrange(R) for _ in range(4)]:
+            kb = k.to_bytes(32, "big")
+            out = C.create_string_buffer(48)
+            assert hd.hd_glv_mul(out, p, kb) == 0
+            assert out.raw == oracle.g1_mul_add(p, kb, None), hex(k)
     # add-or-double corner cases of the Jacobian+Jacobian routine
     two_g = oracle.g1_mul_add(G1_GEN, (2).to_bytes(32, "big"))
     neg_g = oracle.g1_mul_add(G1_GEN, (R - 1).to_bytes(32, "big"))
