@@ -11,7 +11,7 @@
 //                  weights it by (b+1) and the workgroup tree-reduces the 128 weighted buckets through LDS
 //   k_msm_finalize one workgroup per blob: sum the 32 window partials, to affine, ZCash-compress (48 bytes)
 // The result is the same group element blst's Pippenger returns, hence the same 48 bytes (utils.rs:221-227).
-#define KZG_FP_MUL_NOINLINE 1
+#define KZG_MID_INLINE 1
 #include "kernels.h"
 
 namespace kzg {

@@ -25,8 +25,23 @@ __device__ __forceinline__ Fr block_sum_1024(Fr *wave_sum, Fr v, int lane, int w
     return sum;
 }
 
+__device__ __forceinline__ void ts_store(uint32_t *ts, int k, int tid, const Fr &v) {
+#pragma unroll
+    for (int i = 0; i < NFR; i++) ts[(k * NFR + i) * 1024 + tid] = v.l[i];
+}
+__device__ __forceinline__ void ts_load(Fr &v, const uint32_t *ts, int k, int tid) {
+#pragma unroll
+    for (int i = 0; i < NFR; i++) v.l[i] = ts[(k * NFR + i) * 1024 + tid];
+}
+__device__ __forceinline__ Fr load_p(const uint8_t *blob, int e) {
+    uint32_t w[8]; load_blob_element_words(w, blob, e);
+    Fr p; fr_from_words(p, w);
+    return p;
+}
+
 __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const Fr *z_in, const Fr *roots, Fr *y_out, Fr *q_out, int *err) {
     __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16], bcast;
+    __shared__ uint32_t ts[4 * NFR * 1024];           // T_k per element, [k][limb][thread] (registers are capped at 128)
     __shared__ int hit;
     const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
@@ -35,26 +50,30 @@ __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const F
     __syncthreads();
     const Fr z = z_in[blob_i];
     const Fr one = fr_one();
-    Fr d[4], p[4];
-    bool bad = false;
+    Fr L;
+    {
+        Fr d[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int e = k * 1024 + tid;
-        uint32_t w[8]; load_blob_element_words(w, blob, e);
-        bad = bad || !fr_words_canonical(w);                      // blob_to_polynomial (kzg.rs:282-291)
-        fr_from_words(p[k], w);
-        Fr t; fr_sub(t, z, roots[e]);
-        const bool zero = fr_is_zero(t);
-        if (zero) hit = e;                                        // at most one element can match
-        fr_select(d[k], zero, t, one);
+        for (int k = 0; k < 4; k++) {
+            const int e = k * 1024 + tid;
+            Fr t; fr_sub(t, z, roots[e]);
+            const bool zero = fr_is_zero(t);
+            if (zero) hit = e;                                    // at most one element can match
+            fr_select(d[k], zero, t, one);
+        }
+        Fr a, b, c;
+        fr_mul(a, d[0], d[1]); fr_mul(b, d[2], d[3]); fr_mul(L, a, b);
+        fr_mul(c, d[1], b); ts_store(ts, 0, tid, c);
+        fr_mul(c, d[0], b); ts_store(ts, 1, tid, c);
+        fr_mul(c, a, d[3]); ts_store(ts, 2, tid, c);
+        fr_mul(c, a, d[2]); ts_store(ts, 3, tid, c);
     }
-    if (bad) atomicOr(&err[blob_i], ERR_NONCANONICAL_FR);
-    Fr a, b, L, T[4];
-    fr_mul(a, d[0], d[1]); fr_mul(b, d[2], d[3]); fr_mul(L, a, b);
-    fr_mul(T[0], d[1], b); fr_mul(T[1], d[0], b); fr_mul(T[2], a, d[3]); fr_mul(T[3], a, d[2]);
-    Fr ex, tot;
-    wave_product_except_self(ex, tot, L, lane);
-    if (lane == 0) wave_tot[wid] = tot;
+    Fr ex;
+    {
+        Fr tot;
+        wave_product_except_self(ex, tot, L, lane);
+        if (lane == 0) wave_tot[wid] = tot;
+    }
     __syncthreads();
     if (wid == 0) {
         Fr v = lane < 16 ? wave_tot[lane] : one, e2, t2;
@@ -65,22 +84,27 @@ __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const F
     const int m = hit;                                            // block-uniform from here on
     fr_mul(ex, ex, wave_ex[wid]);
     Fr S = fr_zero();
-#pragma unroll
+    bool bad = false;
+#pragma unroll 1
     for (int k = 0; k < 4; k++) {
-        fr_mul(T[k], T[k], ex);                                   // prod over all other (non-hit) elements of (z - w_j)
-        Fr t; fr_mul(t, p[k], roots[k * 1024 + tid]); fr_mul(t, t, T[k]);
+        const int e = k * 1024 + tid;
+        uint32_t w[8]; load_blob_element_words(w, blob, e);
+        bad = bad || !fr_words_canonical(w);                      // blob_to_polynomial (kzg.rs:282-291)
+        Fr p, T, t;
+        fr_from_words(p, w);
+        ts_load(T, ts, k, tid);
+        fr_mul(T, T, ex);                                         // prod over all other (non-hit) elements of (z - w_j)
+        ts_store(ts, k, tid, T);
+        fr_mul(t, p, roots[e]); fr_mul(t, t, T);
         fr_add(S, S, t);
     }
+    if (bad) atomicOr(&err[blob_i], ERR_NONCANONICAL_FR);
     S = block_sum_1024(wave_sum, S, lane, wid);
     const uint32_t inv4096[NFR] = FR_INV4096_INIT;
     Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
     Fr y;
-    if (m >= 0) {
-        uint32_t w[8]; load_blob_element_words(w, blob, m);
-        fr_from_words(y, w);                                      // kzg.rs:360-362
-    } else {
-        fr_mul(y, S, k4096);
-    }
+    if (m >= 0) y = load_p(blob, m);                              // kzg.rs:360-362
+    else fr_mul(y, S, k4096);
     // W with 1/(z - w_i) = T_i * W
     if (tid == 0) {
         Fr W;
@@ -97,13 +121,15 @@ __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const F
     __syncthreads();
     const Fr W = bcast;
     Fr S2 = fr_zero();
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; k++) {
         const int e = k * 1024 + tid;
         if (e == m) continue;
-        Fr inv, ymp, qe;
-        fr_mul(inv, T[k], W);                                     // 1 / (z - w_i)
-        fr_sub(ymp, y, p[k]);
+        Fr inv, ymp, qe, T;
+        ts_load(T, ts, k, tid);
+        fr_mul(inv, T, W);                                        // 1 / (z - w_i)
+        const Fr p = load_p(blob, e);
+        fr_sub(ymp, y, p);
         fr_mul(qe, ymp, inv);                                     // (p_i - y) / (w_i - z)
         q[e] = qe;
         if (m >= 0) { Fr t; fr_mul(t, qe, roots[e]); fr_sub(S2, S2, t); }   // + (p_i - y) w_i / (z - w_i)

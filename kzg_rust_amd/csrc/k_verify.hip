@@ -19,52 +19,111 @@ namespace kzg {
 
 
 // ------------------------------------------------------------------------------------------------ challenge
-// One lane per blob: SHA-256 over  "FSBLOBVERIFY_V1_" | u64be(0) | u64be(4096) | blob | commitment  (131,152 bytes,
-// consts.rs:19-22) = 2050 compressions, strictly sequential.  Also assembles the record's C / z / proof fields.
-__global__ void __launch_bounds__(64) k_challenge(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
-                                                   Fr *z_out, uint8_t *records) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
-    const uint8_t *cm = commitments + 48 * (size_t)i;
-    Sha256 s; sha256_init(s);
-    uint32_t w[16];
-    // block 0: domain | 0 | 4096 | blob[0..32)
-    w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
-    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = (uint32_t)N_FE;
-    {
-        uint4 a = blob[0], b = blob[1];
-        w[8] = bswap32(a.x); w[9] = bswap32(a.y); w[10] = bswap32(a.z); w[11] = bswap32(a.w);
-        w[12] = bswap32(b.x); w[13] = bswap32(b.y); w[14] = bswap32(b.z); w[15] = bswap32(b.w);
-    }
-    sha256_block(s, w);
-    // blocks 1..2047: blob[64b-32, 64b+32)
-    for (int b = 1; b < 2048; b++) {
+// z_i = SHA-256( "FSBLOBVERIFY_V1_" | u64be(0) | u64be(4096) | blob | commitment ) mod r   (kzg.rs:298-339; 131,152 bytes,
+// consts.rs:19-22) = 2050 compressions that are strictly sequential per blob (Merkle-Damgard), one blob per lane.
+// A lone wave issues one instruction per ~5 cycles, so the only lever on this chain is its instruction count.  The
+// message schedule does not depend on the chaining state, so it is moved to a second wave: in each 128-thread
+// workgroup wave 1 (producer) loads block b+1, expands W[0..63] and stores W[t]+K[t] to LDS while wave 0 (consumer)
+// runs the 64 rounds of block b from LDS (ds_read_b128, [t/4][lane][4] layout: conflict-free).  One barrier per block.
+// Rounds use v_alignbit (rotates), v_bitop3 (3-input xor / ch / maj) and v_add3.  Also assembles the record's
+// C / z / proof fields.
+__device__ __forceinline__ uint32_t ror(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }   // e ? f : g
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
+
+constexpr int CH_BLOCKS = 2050;
+__device__ __forceinline__ void challenge_block_words(uint32_t w[16], const uint4 *blob, const uint8_t *cm, int b) {
+    if (b >= 1 && b < 2048) {                       // blob[64b-32, 64b+32)
         const uint4 *p = blob + (4 * b - 2);
         uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
         w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
         w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
         w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
         w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
-        sha256_block(s, w);
-    }
-    // block 2048: blob[131040, 131072) | commitment[0..32)
-    {
+    } else if (b == 0) {                            // domain | 0 | 4096 | blob[0..32)
+        w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
+        w[4] = 0; w[5] = 0; w[6] = 0; w[7] = (uint32_t)N_FE;
+        uint4 v0 = blob[0], v1 = blob[1];
+        w[8] = bswap32(v0.x); w[9] = bswap32(v0.y); w[10] = bswap32(v0.z); w[11] = bswap32(v0.w);
+        w[12] = bswap32(v1.x); w[13] = bswap32(v1.y); w[14] = bswap32(v1.z); w[15] = bswap32(v1.w);
+    } else if (b == 2048) {                         // blob[131040, 131072) | commitment[0..32)
         const uint4 *p = blob + (4 * 2048 - 2);
         uint4 v0 = p[0], v1 = p[1];
         w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
         w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
         for (int k = 0; k < 8; k++) w[8 + k] = load_be32(cm + 4 * k);
+    } else {                                        // commitment[32..48) | 0x80 | zeros | bit length
+        for (int k = 0; k < 4; k++) w[k] = load_be32(cm + 32 + 4 * k);
+        w[4] = 0x80000000u;
+        for (int k = 5; k < 15; k++) w[k] = 0;
+        w[15] = (uint32_t)((32 + BLOB_BYTES + 48) * 8);
     }
-    sha256_block(s, w);
-    // block 2049: commitment[32..48) | 0x80 | zeros | bit length
-    for (int k = 0; k < 4; k++) w[k] = load_be32(cm + 32 + 4 * k);
-    w[4] = 0x80000000u;
-    for (int k = 5; k < 14; k++) w[k] = 0;
-    w[14] = 0; w[15] = (uint32_t)((32 + BLOB_BYTES + 48) * 8);
-    sha256_block(s, w);
+}
+
+__global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
+                                                    Fr *z_out, uint8_t *records) {
+    __shared__ uint4 wk[2][16][64];                 // [buffer][t/4][lane] -> W[t..t+3] + K[t..t+3]
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int i_raw = blockIdx.x * 64 + lane;
+    const int i = i_raw < n_total ? i_raw : n_total - 1;           // tail lanes redo the last blob (no out-of-bounds loads)
+    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
+    const uint8_t *cm = commitments + 48 * (size_t)i;
+    static const uint32_t K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+        0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+        0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+        0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+        0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+        0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+        0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+        0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    auto produce = [&](int b) {
+        uint32_t w[16];
+        challenge_block_words(w, blob, cm, b);
+        uint4 *dst = &wk[b & 1][0][lane];
+#pragma unroll
+        for (int t = 0; t < 64; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int tt = t + u;
+                if (tt >= 16) {
+                    const uint32_t w15 = w[(tt + 1) & 15], w2 = w[(tt + 14) & 15];
+                    const uint32_t s0 = xor3(ror(w15, 7), ror(w15, 18), w15 >> 3);
+                    const uint32_t s1 = xor3(ror(w2, 17), ror(w2, 19), w2 >> 10);
+                    w[tt & 15] = w[tt & 15] + s0 + w[(tt + 9) & 15] + s1;
+                }
+            }
+            dst[(t >> 2) * 64] = make_uint4(w[t & 15] + K[t], w[(t + 1) & 15] + K[t + 1], w[(t + 2) & 15] + K[t + 2], w[(t + 3) & 15] + K[t + 3]);
+        }
+    };
+    uint32_t h0 = 0x6a09e667u, h1 = 0xbb67ae85u, h2 = 0x3c6ef372u, h3 = 0xa54ff53au, h4 = 0x510e527fu, h5 = 0x9b05688cu, h6 = 0x1f83d9abu, h7 = 0x5be0cd19u;
+    if (role == 1) produce(0);
+    __syncthreads();
+    for (int b = 0; b < CH_BLOCKS; b++) {
+        if (role == 0) {
+            uint32_t a = h0, bb = h1, c = h2, d = h3, e = h4, f = h5, g = h6, h = h7;
+            const uint4 *src = &wk[b & 1][0][lane];
+#pragma unroll
+            for (int t = 0; t < 64; t += 4) {
+                const uint4 q = src[(t >> 2) * 64];
+                const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t1 = h + xor3(ror(e, 6), ror(e, 11), ror(e, 25)) + ch3(e, f, g) + wv[u];
+                    const uint32_t t2 = xor3(ror(a, 2), ror(a, 13), ror(a, 22)) + maj3(a, bb, c);
+                    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                }
+            }
+            h0 += a; h1 += bb; h2 += c; h3 += d; h4 += e; h5 += f; h6 += g; h7 += h;
+        } else if (b + 1 < CH_BLOCKS) {
+            produce(b + 1);
+        }
+        __syncthreads();
+    }
+    if (role != 0 || i_raw >= n_total) return;
     // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
-    uint32_t dw[8]; sha256_digest_to_words(dw, s);
+    const uint32_t dw[8] = {h7, h6, h5, h4, h3, h2, h1, h0};
     Fr z; fr_from_words(z, dw);
     z_out[i] = z;
     if (!records) return;
@@ -87,34 +146,42 @@ __global__ void __launch_bounds__(64) k_challenge(const uint8_t *blobs, const ui
 // blob and of the roots table); per thread  L_t = d0 d1 d2 d3  and the three-factor complements; across threads an
 // exclusive prefix * suffix product with wave shuffles (6+6 steps) and a 16-entry LDS stage; then a shuffle/LDS sum.
 // ~34 Fr products per thread instead of ~410 (one Fermat inversion per thread) in the first version of this kernel.
+__device__ __forceinline__ void cs_store(uint32_t *cs, int k, int tid, const Fr &v) {
+#pragma unroll
+    for (int i = 0; i < NFR; i++) cs[(k * NFR + i) * 1024 + tid] = v.l[i];
+}
+__device__ __forceinline__ void cs_load(Fr &v, const uint32_t *cs, int k, int tid) {
+#pragma unroll
+    for (int i = 0; i < NFR; i++) v.l[i] = cs[(k * NFR + i) * 1024 + tid];
+}
 __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
                                                 uint8_t *records, int *err) {
     __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16];
+    __shared__ uint32_t cs[4 * NFR * 1024];                       // the per-element complements c_k, [k][limb][thread]
     const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
-    const Fr z = z_in[blob_i];
-    Fr d[4], pw[4];
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int e = k * 1024 + tid;
-        uint32_t w[8]; load_blob_element_words(w, blob, e);
-        bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
-        const Fr om = roots[e];
-        Fr p; fr_from_words(p, w);
-        fr_mul(pw[k], p, om);                                     // p_i * w_i
-        fr_sub(d[k], z, om);                                      // z - w_i
+    // pass 1: denominators only.  c_k = product of the thread's other three (z - w), L = product of all four.
+    // Register budget: 1024 threads per workgroup cap a lane at 128 VGPRs (4 waves/SIMD), so the four c_k wait in LDS
+    // (144 KiB of the CU's 160: one workgroup per CU, which is what the VGPR budget allows anyway) and the blob / roots
+    // are re-read from L2 in pass 2: no scratch traffic.
+    Fr L;
+    {
+        const Fr z = z_in[blob_i];
+        Fr d0, d1, d2, d3, a, b, c;
+        fr_sub(d0, z, roots[tid]); fr_sub(d1, z, roots[1024 + tid]);
+        fr_sub(d2, z, roots[2048 + tid]); fr_sub(d3, z, roots[3072 + tid]);
+        fr_mul(a, d0, d1); fr_mul(b, d2, d3); fr_mul(L, a, b);
+        fr_mul(c, d1, b); cs_store(cs, 0, tid, c);
+        fr_mul(c, d0, b); cs_store(cs, 1, tid, c);
+        fr_mul(c, a, d3); cs_store(cs, 2, tid, c);
+        fr_mul(c, a, d2); cs_store(cs, 3, tid, c);
     }
-    if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
-    Fr a, b, L, S, t;
-    fr_mul(a, d[0], d[1]); fr_mul(b, d[2], d[3]); fr_mul(L, a, b);
-    fr_mul(t, d[1], b); fr_mul(S, pw[0], t);                      // complements of d0..d3 inside the thread
-    fr_mul(t, d[0], b); fr_mul(t, pw[1], t); fr_add(S, S, t);
-    fr_mul(t, a, d[3]); fr_mul(t, pw[2], t); fr_add(S, S, t);
-    fr_mul(t, a, d[2]); fr_mul(t, pw[3], t); fr_add(S, S, t);
-    Fr ex, tot;
-    wave_product_except_self(ex, tot, L, lane);
-    if (lane == 0) wave_tot[wid] = tot;
+    Fr ex;
+    {
+        Fr tot;
+        wave_product_except_self(ex, tot, L, lane);
+        if (lane == 0) wave_tot[wid] = tot;
+    }
     __syncthreads();
     if (wid == 0) {                                               // product of the other 15 waves' totals, for each wave
         Fr v = lane < 16 ? wave_tot[lane] : fr_one(), e2, t2;
@@ -123,6 +190,23 @@ __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z
     }
     __syncthreads();
     fr_mul(ex, ex, wave_ex[wid]);                                 // prod over all other threads of L
+    // pass 2: numerators.  S = sum_k p_k w_k c_k ; the blob element enters as a plain integer, so p*w (Montgomery w)
+    // is a plain-domain value and so is everything downstream: y comes out as the canonical integer, no conversions.
+    Fr S = fr_zero();
+    bool bad = false;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int e = k * 1024 + tid;
+        uint32_t w[8]; load_blob_element_words(w, blob, e);
+        bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
+        Fr p, t, c;
+        words_to_limbs<NFR, 8>(p.l, w);
+        fr_mul(t, p, roots[e]);                                   // p_i * w_i   (plain domain)
+        cs_load(c, cs, k, tid);
+        fr_mul(t, t, c);
+        fr_add(S, S, t);
+    }
+    if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
     fr_mul(S, S, ex);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(S, off); fr_add(S, S, o); }
@@ -133,12 +217,21 @@ __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z
         for (int i = 1; i < 16; i++) fr_add(sum, sum, wave_sum[i]);
         const uint32_t inv4096[NFR] = FR_INV4096_INIT;
         Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-        Fr y; fr_mul(y, sum, k4096);
-        if (y_out) y_out[blob_i] = y;
+        Fr y; fr_mul(y, sum, k4096);                              // canonical integer value of y
         if (records) {
-            uint8_t yb[32]; fr_to_be32(yb, y);
+            uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
             uint8_t *rec = records + (size_t)RECORD_BYTES * blob_i + 80;
-            for (int k = 0; k < 32; k++) rec[k] = yb[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                         // big-endian bytes, straight from registers
+                const uint32_t v = yw[7 - i];
+                rec[4 * i] = (uint8_t)(v >> 24); rec[4 * i + 1] = (uint8_t)(v >> 16); rec[4 * i + 2] = (uint8_t)(v >> 8); rec[4 * i + 3] = (uint8_t)v;
+            }
+        }
+        if (y_out) {                                              // Montgomery form for callers that want an Fr
+            const uint32_t r2[NFR] = FR_R2_INIT;
+            Fr R2; for (int i = 0; i < NFR; i++) R2.l[i] = r2[i];
+            Fr ym; fr_mul(ym, y, R2);
+            y_out[blob_i] = ym;
         }
     }
 }
@@ -214,7 +307,7 @@ __global__ void __launch_bounds__(64) k_pairing(const G1Affine *pair_pts, const 
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
                        hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_challenge, dim3((n_total + 63) / 64), dim3(64), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+    hipLaunchKernelGGL(k_challenge, dim3((n_total + 63) / 64), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
 }
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
