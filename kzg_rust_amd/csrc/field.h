@@ -196,7 +196,8 @@ KZG_HD void fp_pow(Fp &r, const Fp &a, const uint32_t *e) {
     }
     r = acc;
 }
-KZG_HD void fp_inv(Fp &r, const Fp &a) { const uint32_t e[12] = FP_EXP_INV_INIT; fp_pow(r, a, e); }
+// a^(p-2): kept as the independent cross-check of the divstep inversion (modinv.h) that fp_inv uses
+KZG_HD void fp_inv_fermat(Fp &r, const Fp &a) { const uint32_t e[12] = FP_EXP_INV_INIT; fp_pow(r, a, e); }
 // sqrt for p = 3 mod 4: a^((p+1)/4); false if a is not a square
 KZG_HD bool fp_sqrt(Fp &r, const Fp &a) {
     const uint32_t e[12] = FP_EXP_SQRT_INIT;
@@ -277,7 +278,7 @@ KZG_HD bool fr_words_canonical(const uint32_t w[8]) {
     words_to_limbs<NFR, 8>(v, w);
     return ul_sub<NFR>(t, v, FR_MOD) != 0;
 }
-KZG_HD void fr_inv(Fr &r, const Fr &a) {
+KZG_HD void fr_inv_fermat(Fr &r, const Fr &a) {
     const uint32_t e[8] = FR_EXP_INV_INIT;
     Fr acc = a;   // bit 254 of r-2 is set
     for (int i = 253; i >= 0; i--) {
@@ -311,3 +312,5 @@ KZG_HD bool fr_from_be32_checked(Fr &r, const uint8_t *in) {
 KZG_HD void fr_to_be32(uint8_t *out, const Fr &a) { uint32_t w[8]; fr_to_words(w, a); words_to_be32(out, w); }
 
 }  // namespace kzg
+
+#include "modinv.h"   // fp_inv / fr_inv: batched-divstep inversion (defined after the arithmetic it builds on)

@@ -15,9 +15,10 @@ int hd_fp_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
     if (!fp_from_be48(x, a, false) || !fp_from_be48(y, b, false)) return 1;
     switch (op) {
         case 0: fp_add(r, x, y); break; case 1: fp_sub(r, x, y); break; case 2: fp_mul(r, x, y); break;
-        case 3: fp_inv(r, x); break; case 4: if (!fp_sqrt(r, x)) return 2; break;
+        case 3: fp_inv_fermat(r, x); break; case 4: if (!fp_sqrt(r, x)) return 2; break;
         case 5: fp_neg(r, x); break; case 6: fp_dbl(r, x); break;
         case 7: { out[0] = fp_is_lex_largest(x); return 0; }
+        case 8: fp_inv(r, x); break;
         default: return 1;
     }
     fp_to_be48(out, r); return 0;
@@ -27,8 +28,9 @@ int hd_fr_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
     be32_to_words(w, a); fr_from_words(x, w); be32_to_words(w, b); fr_from_words(y, w);
     switch (op) {
         case 0: fr_add(r, x, y); break; case 1: fr_sub(r, x, y); break; case 2: fr_mul(r, x, y); break;
-        case 3: fr_inv(r, x); break;
+        case 3: fr_inv_fermat(r, x); break;
         case 4: { be32_to_words(w, a); out[0] = fr_words_canonical(w); return 0; }
+        case 5: fr_inv(r, x); break;
         default: return 1;
     }
     fr_to_be32(out, r); return 0;

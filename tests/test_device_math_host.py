@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "sha256.h", "consts_gen.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "modinv.h", "sha256.h", "consts_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
@@ -50,6 +50,8 @@ def test_fp_arithmetic(hd):
         assert _fp(hd, 5, a)[1] == (-a) % P
         assert _fp(hd, 6, a)[1] == (2 * a) % P
         assert C.create_string_buffer(1) is not None
+    for a in vals:                                   # divstep inversion (modinv.h) against Python
+        assert _fp(hd, 8, a)[1] == (pow(a, -1, P) if a else 0), hex(a)
     for a in vals[:20]:
         if a:
             assert _fp(hd, 3, a)[1] == pow(a, -1, P)
@@ -69,6 +71,8 @@ def test_fr_arithmetic(hd):
         out = C.create_string_buffer(32)
         hd.hd_fr_op(4, out, a.to_bytes(32, "big"), bytes(32))
         assert out.raw[0] == (1 if a < R else 0)
+    for a in vals:
+        assert _fr(hd, 5, a)[1] == (pow(a % R, -1, R) if a % R else 0), hex(a)
     for a in vals[:12]:
         if a % R:
             assert _fr(hd, 3, a)[1] == pow(a, -1, R)
