@@ -76,7 +76,7 @@ struct Workspace {
 struct kzg355_settings {
     int device = 0;
     DeviceTables t{};
-    DevBuf roots, msm_table, lines, lines_inf, g1_first2, lines_w, frob;
+    DevBuf roots, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
     std::mutex mu;
     std::vector<Workspace *> pool;
@@ -343,6 +343,19 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
         for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
         if (hipMemcpy(s->frob.p, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     }
+    {
+        static CoopInsn prog[COOP_PROGRAM_MAX];
+        const int n = build_pairing_program(prog);
+        if (n > COOP_PROGRAM_MAX || s->prog.ensure(sizeof(CoopInsn) * n)) return fail(KZG355_INTERNAL);
+        if (hipMemcpy(s->prog.p, prog, sizeof(CoopInsn) * n, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+        s->t.pairing_prog = s->prog.as<CoopInsn>();
+        s->t.pairing_prog_len = n;
+        static CoopSched sc[2];
+        build_coop_schedules(sc[0], sc[1]);
+        if (s->scheds.ensure(sizeof sc)) return fail(KZG355_NO_DEVICE);
+        if (hipMemcpy(s->scheds.p, sc, sizeof sc, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+        s->t.coop_scheds = s->scheds.as<CoopSched>();
+    }
     if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
@@ -404,7 +417,7 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
     s->roots.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
-    s->lines_w.release(); s->frob.release();
+    s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
 }
 

@@ -35,6 +35,9 @@ struct DeviceTables {
     G1Affine *g1_first2;     // file-order g1[0], g1[1] (only for the Lagrange-form check)
     LineW *lines_w;          // [3][68]: the same lines in the w basis (pairing_coop.h)
     FrobTables *frob;        // w-basis Frobenius tables
+    CoopInsn *pairing_prog;  // the pairing check as an instruction list (pairing_coop.h)
+    int pairing_prog_len;
+    CoopSched *coop_scheds;  // [2]: product and square work schedules
 };
 
 // ---- k_setup.hip

@@ -39,13 +39,63 @@ constexpr uint32_t LINE_MASK = (1u << 0) | (1u << 2) | (1u << 3) | (1u << 6) | (
 constexpr uint32_t EVEN_MASK = 0x555u;
 constexpr uint32_t FULL_MASK = 0xfffu;
 
+// Work schedule of one product type: which limb products lane l accumulates (all for the same convolution index s),
+// and which lanes' partial sums convolution index s collects.
+struct CoopSched {
+    uint8_t s[64];            // convolution index this lane works for (255: idle)
+    uint8_t np[64];           // number of (i, j) pairs, <= 3
+    uint8_t pi[64][3], pj[64][3];
+    uint8_t dbl[64];          // 1: the partial enters doubled (cross terms a_i a_j, i < j, of a square)
+    uint8_t first[23], cnt[23];   // lanes [first, first+cnt) hold the partials of index s
+};
 struct CoopMem {
     Fp12W f, t0, t1, t2, t3, t4;
     Fp12W line[2];
     Fp d[23];
     Fp px[2], py[2];
+    uint32_t part[64][2 * NFP];   // carried (normalised) partial column sums, one row per lane
+    CoopSched sched_mul, sched_sqr;
     int flag;
 };
+
+// Schedules: convolution index s of a full product has c_s = min(s, 22 - s) + 1 limb products; it gets ceil(c_s / 3)
+// lanes (56 lanes in all).  A square has floor(c_s / 2) cross products (2 per lane, doubled) plus a_{s/2}^2 on a lane of
+// its own for even s.
+inline void build_coop_schedules(CoopSched &mul, CoopSched &sqr) {
+    for (int l = 0; l < 64; l++) { mul.s[l] = sqr.s[l] = 255; mul.np[l] = sqr.np[l] = 0; mul.dbl[l] = sqr.dbl[l] = 0; }
+    int lane = 0;
+    for (int s = 0; s < 23; s++) {
+        mul.first[s] = (uint8_t)lane;
+        int k = 0;
+        for (int i = 0; i < 12; i++) {
+            const int j = s - i;
+            if (j < 0 || j > 11) continue;
+            if (k == 3) { lane++; k = 0; }
+            mul.s[lane] = (uint8_t)s; mul.pi[lane][k] = (uint8_t)i; mul.pj[lane][k] = (uint8_t)j; mul.np[lane] = (uint8_t)(++k);
+        }
+        lane++;
+        mul.cnt[s] = (uint8_t)(lane - mul.first[s]);
+    }
+    // (56 lanes used)
+    lane = 0;
+    for (int s = 0; s < 23; s++) {
+        sqr.first[s] = (uint8_t)lane;
+        int k = 0; bool any = false;
+        for (int i = 0; i < 12; i++) {
+            const int j = s - i;
+            if (j <= i || j > 11) continue;
+            if (k == 2) { lane++; k = 0; }
+            sqr.s[lane] = (uint8_t)s; sqr.pi[lane][k] = (uint8_t)i; sqr.pj[lane][k] = (uint8_t)j; sqr.np[lane] = (uint8_t)(++k); sqr.dbl[lane] = 1;
+            any = true;
+        }
+        if (any) lane++;
+        if (!(s & 1)) {
+            sqr.s[lane] = (uint8_t)s; sqr.pi[lane][0] = sqr.pj[lane][0] = (uint8_t)(s >> 1); sqr.np[lane] = 1; sqr.dbl[lane] = 0;
+            lane++;
+        }
+        sqr.cnt[s] = (uint8_t)(lane - sqr.first[s]);
+    }
+}
 
 // Tower line triple (pairing.h LineCoeff) -> w basis
 KZG_HD void line_to_w(LineW &o, const LineCoeff &l) {
@@ -95,64 +145,68 @@ KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
 }
 
 // ---------------------------------------------------------------------------------- cooperative Fp12 operations
-// phase 2 of every product: fold the 23 convolution terms with w^12 = 2 w^6 - 2
+// phase 3 of every product: fold the 23 convolution terms with w^12 = 2 w^6 - 2:
+//     k <= 5:  c_k = d_k - 2 (d_{k+12} + 2 d_{k+18})        (d_23 = 0)
+//     k >= 6:  c_k = d_k + 2 (d_{k+12} + d_{k+6})           (d_23 = 0)
+// written without lane-dependent branches (a wave would execute every branch body one after the other).
 KZG_HD void coop_fold(Fp12W &dst, const Fp *d, int k) {
-    Fp r, t;
-    if (k <= 4) {
-        fp_dbl(t, d[k + 18]); fp_add(t, t, d[k + 12]); fp_dbl(t, t);      // 4 d_{k+18} + 2 d_{k+12}
-        fp_sub(r, d[k], t);
-    } else if (k == 5) {
-        fp_dbl(t, d[17]); fp_sub(r, d[5], t);
-    } else if (k <= 10) {
-        fp_add(t, d[k + 6], d[k + 12]); fp_dbl(t, t); fp_add(r, d[k], t);
-    } else {
-        fp_dbl(t, d[17]); fp_add(r, d[11], t);
+    const bool low = k <= 5;
+    const Fp zero = fp_zero();
+    Fp v, x, y;
+    fp_select(v, k <= 10, zero, d[k + 12 <= 22 ? k + 12 : 22]);            // d_{k+12} or 0
+    fp_select(x, low, d[low ? 0 : k + 6], d[k <= 4 ? k + 18 : 0]);          // low: d_{k+18} (k <= 4), else d_{k+6}
+    if (k == 5) x = zero;
+    fp_dbl(y, x); fp_select(x, low, x, y);                                  // low: 2 d_{k+18}
+    fp_add(v, v, x); fp_dbl(v, v);                                          // 2 ( ... )
+    fp_neg(y, v); fp_select(v, low, v, y);
+    fp_add(dst.c[k], d[k], v);
+}
+
+// Phases 1 and 2 of every product.  Phase 1: every lane accumulates its <= 3 limb products (unreduced 64-bit columns),
+// carries them and parks the 28 columns in m.part.  Phase 2: lane s < 23 adds up the partials of convolution index s
+// (doubling cross terms of a square), and Montgomery-reduces once -> m.d[s].
+KZG_HD void coop_convolve(CoopMem &m, const CoopSched &sc, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
+    COOP_LANES(lane) {
+        if (sc.s[lane] != 255) {
+            uint64_t acc[2 * NFP];
+            wide_zero(acc);
+            const int np = sc.np[lane];
+            for (int k = 0; k < np; k++) {
+                const int i = sc.pi[lane][k], j = sc.pj[lane][k];
+                if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, b.c[j].l);
+            }
+            wide_carry(acc);
+#pragma unroll
+            for (int c = 0; c < 2 * NFP; c++) m.part[lane][c] = (uint32_t)acc[c];
+        }
     }
-    dst.c[k] = r;
+    COOP_SYNC();
+    COOP_LANES(lane) {
+        if (lane < 23) {
+            uint64_t acc[2 * NFP];
+            wide_zero(acc);
+            const int f = sc.first[lane], n = sc.cnt[lane];
+            for (int q = f; q < f + n; q++) {
+                const uint32_t sh = sc.dbl[q];
+#pragma unroll
+                for (int c = 0; c < 2 * NFP; c++) acc[c] += (uint64_t)m.part[q][c] << sh;
+            }
+            wide_carry(acc);
+            wide_reduce(m.d[lane], acc);
+        }
+    }
+    COOP_SYNC();
 }
 
 // dst = a * b, b having non-zero coefficients only where bmask has a bit set.  dst may alias a or b.
 KZG_HD void coop_mul(CoopMem &m, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
-    COOP_LANES(lane) {
-        if (lane < 23) {
-            uint64_t acc[2 * NFP];
-            wide_zero(acc);
-            int pending = 0;
-            for (int j = 0; j < 12; j++) {
-                const int i = lane - j;
-                if (!((bmask >> j) & 1u) || i < 0 || i > 11) continue;
-                wide_mac(acc, a.c[i].l, b.c[j].l);
-                if (++pending == 4) { wide_carry(acc); pending = 0; }
-            }
-            wide_carry(acc);
-            wide_reduce(m.d[lane], acc);
-        }
-    }
-    COOP_SYNC();
+    coop_convolve(m, m.sched_mul, a, b, bmask);
     COOP_LANES(lane) { if (lane < 12) coop_fold(dst, m.d, lane); }
     COOP_SYNC();
 }
-
 // dst = a^2.  dst may alias a.
 KZG_HD void coop_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
-    COOP_LANES(lane) {
-        if (lane < 23) {
-            uint64_t acc[2 * NFP];
-            wide_zero(acc);
-            int pending = 0;
-            const int lo = lane > 11 ? lane - 11 : 0;
-            for (int i = lo; 2 * i < lane; i++) {            // pairs i < j = lane - i
-                wide_mac(acc, a.c[i].l, a.c[lane - i].l);
-                if (++pending == 4) { wide_carry(acc); pending = 0; }
-            }
-            wide_carry(acc);
-            wide_double(acc);
-            if (!(lane & 1)) wide_mac(acc, a.c[lane >> 1].l, a.c[lane >> 1].l);
-            wide_carry(acc);
-            wide_reduce(m.d[lane], acc);
-        }
-    }
-    COOP_SYNC();
+    coop_convolve(m, m.sched_sqr, a, a, FULL_MASK);
     COOP_LANES(lane) { if (lane < 12) coop_fold(dst, m.d, lane); }
     COOP_SYNC();
 }
@@ -201,30 +255,27 @@ KZG_HD bool coop_is_one(CoopMem &m, const Fp12W &a) {
     COOP_SYNC();
     return m.flag != 0;
 }
-// dst = a^-1 = conj(a) * N^-1 with N = a * conj(a) in Fp6 (even powers of w only).  The Fp6 inversion is a short
-// single-lane tower computation.  Uses t3, t4 of the block.  dst may alias a.
-KZG_HD void coop_inv(CoopMem &m, Fp12W &dst, const Fp12W &a) {
-    coop_conj(m.t3, a);
-    coop_mul(m, m.t4, a, m.t3, FULL_MASK);            // N: odd coefficients are zero
+// In-place inverse of an Fp6 element stored in the w basis (even powers of w only; the odd coefficients are zero):
+// a short single-lane tower computation.  With N = a * conj(a) in Fp6 this gives a^-1 = conj(a) * N^-1.
+KZG_HD void coop_fp6_inv(Fp12W &x) {
     COOP_LANES(lane) {
         if (lane == 0) {
             Fp6 n, ni;
             Fp2 *nc[3] = {&n.c0, &n.c1, &n.c2};
             for (int j = 0; j < 3; j++) {              // (x0 + x1 u) v^j  <-  w^(2j): x0 - x1, w^(2j+6): x1
-                nc[j]->c1 = m.t4.c[2 * j + 6];
-                fp_add(nc[j]->c0, m.t4.c[2 * j], m.t4.c[2 * j + 6]);
+                nc[j]->c1 = x.c[2 * j + 6];
+                fp_add(nc[j]->c0, x.c[2 * j], x.c[2 * j + 6]);
             }
             fp6_inv(ni, n);
             const Fp2 *ic[3] = {&ni.c0, &ni.c1, &ni.c2};
-            for (int k = 0; k < 12; k++) m.t4.c[k] = fp_zero();
+            for (int k = 0; k < 12; k++) x.c[k] = fp_zero();
             for (int j = 0; j < 3; j++) {
-                fp_sub(m.t4.c[2 * j], ic[j]->c0, ic[j]->c1);
-                m.t4.c[2 * j + 6] = ic[j]->c1;
+                fp_sub(x.c[2 * j], ic[j]->c0, ic[j]->c1);
+                x.c[2 * j + 6] = ic[j]->c1;
             }
         }
     }
     COOP_SYNC();
-    coop_mul(m, dst, m.t3, m.t4, EVEN_MASK);
 }
 
 struct FrobTables { Fp a1[12], b1[12], a2[12]; };     // power-1 tables and the power-2 table (its g1 part is zero)
@@ -237,65 +288,112 @@ KZG_HD void coop_frob2(Fp12W &dst, const Fp12W &a, const Fp *tab) {
     COOP_SYNC();
 }
 
-// a^x for a in the cyclotomic subgroup (x < 0 -> conjugate).  Uses t3 as scratch.  dst must not alias a.
-KZG_HD void coop_cyc_exp_x(CoopMem &m, Fp12W &dst, const Fp12W &a) {
-    coop_copy(dst, a);
+// ---------------------------------------------------------------------------------- the pairing as a program
+// Every call site of coop_mul / coop_sqr is a ~4k-instruction inlined body, and the pairing check has dozens of
+// them; spelled out as straight-line code the kernel was >0.5 MB of instructions (far beyond the 64 KB instruction
+// cache).  Instead the check is a flat list of instructions over 8 Fp12 slots, built once by build_pairing_program()
+// on the host, and the kernel is a small interpreter with ONE body per opcode.
+enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_EVEN, OP_LINE_EVAL, OP_CONJ, OP_FROB1, OP_FROB2, OP_FP6INV, OP_COPY };
+struct CoopInsn { uint8_t op, dst, a, b; };
+enum : uint8_t { S_F = 0, S_T0 = 1, S_T1 = 2, S_T2 = 3, S_T3 = 4, S_T4 = 5, S_L0 = 6, S_L1 = 7 };
+constexpr int COOP_PROGRAM_MAX = 1024;
+
+inline int build_pairing_program(CoopInsn *p) {
+    int n = 0;
+    auto emit = [&](uint8_t op, uint8_t d, uint8_t a, uint8_t b) { p[n].op = op; p[n].dst = d; p[n].a = a; p[n].b = b; n++; };
+    auto cyc_exp_x = [&](uint8_t d, uint8_t a) {           // d = a^x (x < 0): square-and-multiply over |x|, then conjugate
+        emit(OP_COPY, d, a, 0);
+        for (int i = 62; i >= 0; i--) { emit(OP_SQR, d, d, 0); if ((BLS_X_ABS >> i) & 1) emit(OP_MUL, d, d, a); }
+        emit(OP_CONJ, d, d, 0);
+    };
+    // Miller loops of both pairs, sharing the squarings (utils.rs:206-209)
+    emit(OP_SET_ONE, S_F, 0, 0);
+    int line = 0;
     for (int i = 62; i >= 0; i--) {
-        coop_sqr(m, dst, dst);
-        if ((BLS_X_ABS >> i) & 1) coop_mul(m, dst, dst, a, FULL_MASK);
+        emit(OP_SQR, S_F, S_F, 0);
+        const int steps = 1 + (int)((BLS_X_ABS >> i) & 1);
+        for (int s = 0; s < steps; s++, line++) {
+            emit(OP_LINE_EVAL, 0, (uint8_t)line, 0);
+            emit(OP_MUL_LINE0, S_F, S_F, S_L0);
+            emit(OP_MUL_LINE1, S_F, S_F, S_L1);
+        }
     }
-    coop_conj(dst, dst);
+    emit(OP_CONJ, S_F, S_F, 0);                                                       // x < 0
+    // final exponentiation (utils.rs:210): easy part, then 3 * hard part = (x-1)^2 (x+p)(x^2+p^2-1) + 3
+    emit(OP_CONJ, S_T0, S_F, 0);                                                      // f^-1 = conj(f) * N^-1, N = f conj(f) in Fp6
+    emit(OP_MUL, S_T4, S_F, S_T0); emit(OP_FP6INV, S_T4, S_T4, 0); emit(OP_MUL_EVEN, S_T1, S_T0, S_T4);
+    emit(OP_MUL, S_F, S_T0, S_T1);                                                    // ^(p^6-1)
+    emit(OP_FROB2, S_T0, S_F, 0); emit(OP_MUL, S_F, S_T0, S_F);                               // ^(p^2+1)
+    cyc_exp_x(S_T1, S_F); emit(OP_CONJ, S_T0, S_F, 0); emit(OP_MUL, S_T1, S_T1, S_T0);        // a = f^(x-1)
+    cyc_exp_x(S_T2, S_T1); emit(OP_CONJ, S_T0, S_T1, 0); emit(OP_MUL, S_T1, S_T2, S_T0);      // a = a^(x-1)
+    cyc_exp_x(S_T2, S_T1); emit(OP_FROB1, S_T0, S_T1, 0); emit(OP_MUL, S_T2, S_T2, S_T0);     // b = a^(x+p)
+    cyc_exp_x(S_T1, S_T2); cyc_exp_x(S_T0, S_T1);                                             // b^(x^2)
+    emit(OP_FROB2, S_T1, S_T2, 0); emit(OP_MUL, S_T0, S_T0, S_T1);                            // * b^(p^2)
+    emit(OP_CONJ, S_T1, S_T2, 0); emit(OP_MUL, S_T0, S_T0, S_T1);                             // * b^-1
+    emit(OP_SQR, S_T1, S_F, 0); emit(OP_MUL, S_T1, S_T1, S_F);                                // f^3
+    emit(OP_MUL, S_T0, S_T0, S_T1);                                                           // verdict: slot T0 == 1 ?
+    return n;
 }
 
-// The whole check  ML(Q1, P1) * ML(Q2, P2) -> final exponentiation -> == 1, for precomputed line tables of Q1, Q2.
-// p1 / p2 = (0,0) (infinity) makes that side contribute 1.
-KZG_HD bool coop_pairing_check(CoopMem &m, const LineW *lines1, const G1Affine &p1, const LineW *lines2, const G1Affine &p2,
-                               const FrobTables &ft) {
+KZG_HD Fp12W &coop_slot(CoopMem &m, int s) {
+    Fp12W *base = &m.f;                          // f, t0..t4, line[0], line[1] are laid out contiguously
+    return base[s];
+}
+
+// Interpreter.  p1 / p2 = (0,0) (infinity) makes that pair contribute 1 (its line products are skipped).
+KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopSched *scheds, const LineW *lines1, const G1Affine &p1,
+                               const LineW *lines2, const G1Affine &p2, const FrobTables &ft) {
     const bool use1 = !g1a_is_inf(p1), use2 = !g1a_is_inf(p2);
     COOP_LANES(lane) {
+        {   // bring the two schedules next to the data (byte-wise copy, 64 lanes)
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(scheds);
+            uint8_t *dm = reinterpret_cast<uint8_t *>(&m.sched_mul), *ds = reinterpret_cast<uint8_t *>(&m.sched_sqr);
+            for (int o = lane; o < (int)sizeof(CoopSched); o += 64) { dm[o] = src[o]; ds[o] = src[sizeof(CoopSched) + o]; }
+        }
         if (lane == 0) { m.px[0] = p1.x; m.py[0] = p1.y; m.px[1] = p2.x; m.py[1] = p2.y; }
         if (lane < 24) { m.line[lane / 12].c[lane % 12] = fp_zero(); }
     }
     COOP_SYNC();
-    coop_set_one(m.f);
-    int n = 0;
-    for (int i = 62; i >= 0; i--) {
-        coop_sqr(m, m.f, m.f);
-        const int steps = 1 + (int)((BLS_X_ABS >> i) & 1);
-        for (int s = 0; s < steps; s++, n++) {
-            COOP_LANES(lane) {                          // evaluate both lines at their points: 8 products on 8 lanes
-                if (lane < 12) {
-                    const int q = lane / 6, e = lane % 6;
-                    const LineW &L = q == 0 ? lines1[n] : lines2[n];
-                    Fp v;
-                    switch (e) {
-                        case 0: m.line[q].c[0] = L.l0; break;
-                        case 1: m.line[q].c[6] = L.l6; break;
-                        case 2: fp_mul(v, L.l2, m.px[q]); m.line[q].c[2] = v; break;
-                        case 3: fp_mul(v, L.l8, m.px[q]); m.line[q].c[8] = v; break;
-                        case 4: fp_mul(v, L.l3, m.py[q]); m.line[q].c[3] = v; break;
-                        default: fp_mul(v, L.l9, m.py[q]); m.line[q].c[9] = v; break;
+    for (int pc = 0; pc < n_insn; pc++) {
+        const CoopInsn in = prog[pc];
+        Fp12W &dst = coop_slot(m, in.dst);
+        const Fp12W &a = coop_slot(m, in.a);
+        if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
+            const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2);
+            const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
+            if (!skip) coop_mul(m, dst, a, coop_slot(m, in.b), mask);
+            continue;
+        }
+        switch (in.op) {
+            case OP_SET_ONE: coop_set_one(dst); break;
+            case OP_SQR: coop_sqr(m, dst, a); break;
+            case OP_LINE_EVAL: {
+                const int n = in.a;
+                COOP_LANES(lane) {                          // evaluate both lines at their points: 8 products on 8 lanes
+                    if (lane < 12) {
+                        const int q = lane / 6, e = lane % 6;
+                        const LineW &L = q == 0 ? lines1[n] : lines2[n];
+                        Fp v;
+                        switch (e) {
+                            case 0: m.line[q].c[0] = L.l0; break;
+                            case 1: m.line[q].c[6] = L.l6; break;
+                            case 2: fp_mul(v, L.l2, m.px[q]); m.line[q].c[2] = v; break;
+                            case 3: fp_mul(v, L.l8, m.px[q]); m.line[q].c[8] = v; break;
+                            case 4: fp_mul(v, L.l3, m.py[q]); m.line[q].c[3] = v; break;
+                            default: fp_mul(v, L.l9, m.py[q]); m.line[q].c[9] = v; break;
+                        }
                     }
                 }
+                COOP_SYNC();
+                break;
             }
-            COOP_SYNC();
-            if (use1) coop_mul(m, m.f, m.f, m.line[0], LINE_MASK);
-            if (use2) coop_mul(m, m.f, m.f, m.line[1], LINE_MASK);
+            case OP_CONJ: coop_conj(dst, a); break;
+            case OP_FROB1: coop_frob(dst, a, ft.a1, ft.b1); break;
+            case OP_FROB2: coop_frob2(dst, a, ft.a2); break;
+            case OP_FP6INV: coop_fp6_inv(dst); break;
+            default: coop_copy(dst, a); break;
         }
     }
-    coop_conj(m.f, m.f);                                // x < 0
-    // final exponentiation, same chain as pairing.h final_exp_is_one
-    coop_conj(m.t0, m.f); coop_inv(m, m.t1, m.f); coop_mul(m, m.f, m.t0, m.t1, FULL_MASK);          // ^(p^6-1)
-    coop_frob2(m.t0, m.f, ft.a2); coop_mul(m, m.f, m.t0, m.f, FULL_MASK);                          // ^(p^2+1)
-    // hard part: f^((x-1)^2 (x+p)(x^2+p^2-1)) * f^3
-    coop_cyc_exp_x(m, m.t1, m.f); coop_conj(m.t0, m.f); coop_mul(m, m.t1, m.t1, m.t0, FULL_MASK);   // a = f^(x-1)
-    coop_cyc_exp_x(m, m.t2, m.t1); coop_conj(m.t0, m.t1); coop_mul(m, m.t1, m.t2, m.t0, FULL_MASK); // a = a^(x-1)
-    coop_cyc_exp_x(m, m.t2, m.t1); coop_frob(m.t0, m.t1, ft.a1, ft.b1); coop_mul(m, m.t2, m.t2, m.t0, FULL_MASK);   // b = a^(x+p)
-    coop_cyc_exp_x(m, m.t1, m.t2); coop_cyc_exp_x(m, m.t0, m.t1);                                    // b^(x^2) -> t0
-    coop_frob2(m.t1, m.t2, ft.a2); coop_mul(m, m.t0, m.t0, m.t1, FULL_MASK);                        // * b^(p^2)
-    coop_conj(m.t1, m.t2); coop_mul(m, m.t0, m.t0, m.t1, FULL_MASK);                                 // * b^-1
-    coop_sqr(m, m.t1, m.f); coop_mul(m, m.t1, m.t1, m.f, FULL_MASK);                                 // f^3
-    coop_mul(m, m.t0, m.t0, m.t1, FULL_MASK);
     return coop_is_one(m, m.t0);
 }
 
