@@ -175,8 +175,10 @@ def main():
         avg_s = tot_ms / cnt / 1e3
         blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "pairing", "points_from_records") else blobs_total / cnt
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(dom, blobs_per_launch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch,
                     "avg_launch_ms": round(tot_ms / cnt, 4), "launches": cnt,
                     "kernel_ms_share": {f: round(v[0], 3) for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0])},
                     "path_bytes_per_blob": PATH_BYTES_PER_BLOB,
@@ -203,6 +205,23 @@ def main():
     s.free()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_family, blobs_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, WRITE_SIZE as is; separate passes, collected with this same bench command).  The counters are per
+    blob there; scaled to this run's launch size.  None if no summary is committed for that kernel."""
+    import glob
+    names = {"eval": "k_eval", "challenge": "k_challenge", "lincomb": "k_lincomb_terms", "pairing": "k_pairing_coop",
+             "validate_points": "k_validate_points", "rpowers": "k_rpowers", "points_from_records": "k_points_from_records"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")))
+    if not files or kernel_family not in names:
+        return None, None
+    d = json.load(open(files[-1]))["per_kernel"].get(names[kernel_family])
+    if not d:
+        return None, None
+    per_blob = d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"]
+    return per_blob * blobs_per_launch, os.path.relpath(files[-1], ROOT)
 
 
 def time_cpu_baseline(commitments, proofs, host_blobs, n):

@@ -148,3 +148,101 @@ def test_stage_records_match_oracle(kz, settings, random_set, oracle, oracle_set
     okm = (C.c_bool * 2)(); stm = (C.c_int * 2)()
     rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(okm, stm, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n // 2, 2, settings.handle)
     assert rc == 0 and list(okm) == [True, True] and list(stm) == [0, 0]
+
+
+def _product_commit_prove(kz, settings, blobs):
+    B = [kz.Blob(b) for b in blobs]
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, settings)
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, settings)
+    return B, cs, ps
+
+
+def test_batch64_round_trip_and_oracle_agreement(kz, settings, oracle, oracle_settings):
+    """The only n = 64 correctness signal the reference has is its bench (benches/kzg_benches.rs:34-41, 113-120: commit,
+    prove, then unwrap() the batch verify).  Made explicit here: honest batch -> true, one swapped proof -> false, and the
+    CPU oracle agrees on both; commitments / proofs of a few blobs are also compared with the oracle bit for bit."""
+    blobs = [random_blob(2000 + i) for i in range(64)]
+    B, cs, ps = _product_commit_prove(kz, settings, blobs)
+    for i in (0, 17, 63):
+        assert cs[i].to_bytes() == oracle.blob_to_kzg_commitment(blobs[i], oracle_settings)
+        assert ps[i].to_bytes() == oracle.compute_blob_kzg_proof(blobs[i], cs[i].to_bytes(), oracle_settings)
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, ps, settings) is True
+    assert oracle.verify_blob_kzg_proof_batch(blobs, [c.to_bytes() for c in cs], [p.to_bytes() for p in ps], oracle_settings) is True
+    bad = list(ps); bad[40], bad[41] = bad[41], bad[40]
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, bad, settings) is False
+    assert oracle.verify_blob_kzg_proof_batch(blobs, [c.to_bytes() for c in cs], [p.to_bytes() for p in bad], oracle_settings) is False
+    # idempotence: the same call again gives the same verdicts
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, ps, settings) is True
+
+
+def test_odd_batch_sizes(kz, settings):
+    """Batch sizes that do not line up with wave / workgroup sizes (65 = one lane into a second SHA workgroup; 3n+1 GLV
+    items spilling into a partial wave)."""
+    blobs = [random_blob(3000 + i) for i in range(67)]
+    B, cs, ps = _product_commit_prove(kz, settings, blobs)
+    for n in (7, 33, 65, 67):
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], ps[:n], settings) is True
+        bad = list(ps[:n]); bad[n - 1] = ps[(n - 2)]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], bad, settings) is False
+
+
+def test_skewed_blobs_msm(kz, settings, oracle, oracle_settings):
+    """Digit distributions that overload single MSM buckets: a constant blob (every window puts all 4096 points in one
+    bucket), all-zero, all r-1, and 31-byte-packed data (top byte 0: window 31 only sees digits 0/1)."""
+    r_minus_1 = bytes.fromhex("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000000")
+    const_el = bytes.fromhex("0012ab" + "cd" * 29)
+    blobs = [const_el * 4096, bytes(131072), r_minus_1 * 4096, (b"\x00" + b"\xff" * 31) * 4096,
+             b"".join((i % 7).to_bytes(32, "big") for i in range(4096))]
+    cs = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], settings)
+    for b, c in zip(blobs, cs):
+        assert c.to_bytes() == oracle.blob_to_kzg_commitment(b, oracle_settings)
+    ps = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], cs, settings)
+    for b, c, p in zip(blobs, cs, ps):
+        assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
+    assert kz.Kzg.verify_blob_kzg_proof_batch([kz.Blob(b) for b in blobs], cs, ps, settings) is True
+
+
+def test_many_api_reports_per_unit_status(kz, settings, random_set):
+    blobs, cs, ps = random_set
+    bad_blob = bytearray(blobs[1]); bad_blob[64:96] = b"\xff" * 32          # element 2 >= r
+    res = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(blobs[0]), kz.Blob(bytes(bad_blob)), kz.Blob(blobs[2])], settings)
+    assert res[0].to_bytes() == cs[0] and isinstance(res[1], kz.BadArgs) and res[2].to_bytes() == cs[2]
+    resp = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(blobs[0]), kz.Blob(blobs[1])],
+                                              [kz.KzgCommitment(cs[0]), kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)], settings)
+    assert resp[0].to_bytes() == ps[0] and isinstance(resp[1], kz.BadArgs)
+
+
+def test_concurrent_calls_on_one_handle(kz, settings, random_set):
+    """The reference's KzgSettings is Send + Sync; the handle must serve concurrent callers (workspace pool)."""
+    import threading
+    blobs, cs, ps = random_set
+    B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+    out = [None] * 6
+
+    def work(i):
+        if i % 2 == 0:
+            out[i] = kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, settings)
+        else:
+            out[i] = kz.Kzg.blob_to_kzg_commitment(B[i], settings).to_bytes() == cs[i]
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out == [True] * 6
+
+
+def test_sharded_driver_world1_on_gpu(kz, settings, random_set):
+    """kzg_rust_amd/sharded.py over the HIP engine with no process group (world = 1): same verdicts as the batch call."""
+    import torch
+    from kzg_rust_amd.sharded import HipEngine, verify_blob_kzg_proof_batch_sharded
+    blobs, cs, ps = random_set
+    n = len(blobs) // 2
+    dev = torch.device("cuda", settings.device)
+    bad = list(ps[n:]); bad[0], bad[1] = bad[1], bad[0]
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n] + blobs[n:2 * n])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n] + cs[n:2 * n])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(ps[:n] + bad)), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n, 2, HipEngine(settings))
+    assert ok == [True, False] and st == [0, 0]
