@@ -40,7 +40,17 @@ KERNEL_BYTES_PER_BLOB = {
     "lincomb": 2 * 112 + 64 + 2 * 112 / N_PER_BATCH,
     "pairing": (2 * 68 * 3 * 2 * 56 + 2 * 112) / N_PER_BATCH,   # two 68-line tables + two points per batch
 }
+KERNEL_BYTES_PER_BLOB.update({
+    "msm_bucket": 4096 * (96 + 32) + 48,              # SURVEY 8(d) B_commit: affine G1 sweep + scalars + output
+    "msm_finalize": 32 * 168 + 48,
+    "digits": 131072 + 131072,
+    "quotient": 131072 + 131072 + 147456,
+})
 FAMILIES = list(KERNEL_BYTES_PER_BLOB)
+OP_BYTES_PER_BLOB = {"verify": PATH_BYTES_PER_BLOB, "commit": 4096 * (96 + 32) + 48, "proof": 131072 + 131072 + 393216 + 48 + 48}
+OP_METRIC = {"verify": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, batch=64)",
+             "commit": "blobs/sec on blob_to_kzg_commitment (mainnet 4096-point G1 MSM)",
+             "proof": "blobs/sec on compute_blob_kzg_proof (mainnet 4096)"}
 
 
 def main():
@@ -50,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=1024,
                     help="independent 64-blob batches verified by one step (one launch set)")
+    ap.add_argument("--op", choices=["verify", "commit", "proof"], default="verify",
+                    help="verify = the headline metric; commit / proof = secondary single-GPU metrics (BASELINE.json configs[1], [2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -78,6 +90,8 @@ def main():
     assert s.device == local_rank
 
     K, W = max(1, args.steps), max(0, args.warmup)
+    if args.op != "verify" and args.concurrent == 1024:
+        args.concurrent = 64                      # MSM-bound ops: 4096 blobs per step keep the default run short
     Cc = max(1, args.concurrent)
     n_local = N_PER_BATCH
     # ---- untimed setup: Cc distinct batches per step; this rank owns blobs [rank*64, rank*64+64) of each batch.
@@ -104,30 +118,32 @@ def main():
     assert rc == 0, rc
     proofs = out.raw
     t_p = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
-    t_rec = torch.empty(Cc * n_local * 160, dtype=torch.uint8, device=dev)
-    t_all = torch.empty(world * Cc * n_local * 160, dtype=torch.uint8, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
     ok = (C.c_bool * Cc)()
     stg = (C.c_int * Cc)()
 
+    from kzg_rust_amd.sharded import HipEngine, verify_blob_kzg_proof_batch_sharded
+    engine = HipEngine(s)
+    out48 = C.create_string_buffer(48 * n_blobs)
+
     def run_steps(g):
-        """g <= Cc independent steps in one launch set; returns when the verdicts are on the host."""
-        if world == 1:
+        """one launch set over g independent 64-blob batches; returns when the results are on the host."""
+        nb = g * n_local
+        if args.op == "commit":
+            rc = L.kzg355_blob_to_kzg_commitment_many_device(out48, st, t_blobs.data_ptr(), nb, s.handle)
+            assert rc == 0 and out48.raw[:48 * nb] == commitments[:48 * nb]
+        elif args.op == "proof":
+            rc = L.kzg355_compute_blob_kzg_proof_many_device(out48, st, t_blobs.data_ptr(), t_c.data_ptr(), nb, s.handle)
+            assert rc == 0 and out48.raw[:48 * nb] == proofs[:48 * nb]
+        elif world == 1:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
             assert rc == 0, rc
+            assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
         else:
-            rc = L.kzg355_verify_shard_records_device(t_rec.data_ptr(), stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
-            assert rc == 0, rc
-            nloc = g * n_local * 160
-            gathered = t_all[:world * nloc]
-            dist.all_gather_into_tensor(gathered, t_rec[:nloc])          # ONE collective per launch set (RCCL over xGMI)
-            # [rank][batch][64*160] -> [batch][rank][64*160]: records of a batch in transcript order
-            recs = gathered.view(world, g, n_local * 160).permute(1, 0, 2).contiguous()
-            torch.cuda.synchronize()
-            rc = L.kzg355_verify_records_device(ok, stg, recs.data_ptr(), n_local * world, g, s.handle)
-            assert rc == 0, rc
-        assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
+            # stage 1 on the local shard -> ONE all-gather of the 160-byte records (RCCL over xGMI) -> stage 2 replicated
+            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine)
+            assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
     def barrier():
         torch.cuda.synchronize()
@@ -174,6 +190,8 @@ def main():
         tot_ms, cnt = stats[dom]
         avg_s = tot_ms / cnt / 1e3
         blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "pairing", "points_from_records") else blobs_total / cnt
+        if args.op != "verify":
+            blobs_per_launch = Cc * n_local
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
         traffic, traffic_src = pmc_traffic(dom, blobs_per_launch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -181,21 +199,22 @@ def main():
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch,
                     "avg_launch_ms": round(tot_ms / cnt, 4), "launches": cnt,
                     "kernel_ms_share": {f: round(v[0], 3) for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0])},
-                    "path_bytes_per_blob": PATH_BYTES_PER_BLOB,
-                    "path_frac_of_hbm_peak": value * PATH_BYTES_PER_BLOB / (world * HBM_PEAK_GBPS * 1e9),
+                    "path_bytes_per_blob": OP_BYTES_PER_BLOB[args.op],
+                    "path_frac_of_hbm_peak": value * OP_BYTES_PER_BLOB[args.op] / (world * HBM_PEAK_GBPS * 1e9),
                     "note": "integer-ALU/latency-bound path: ~1e3 integer ops per byte, HBM fraction is small by construction"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = time_cpu_baseline(commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
+        cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
 
     if rank == 0:
         line = {
-            "metric": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, batch=64)",
+            "metric": OP_METRIC[args.op],
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
-            "config": {"workload": "kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch"
+            "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
+                                    f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-gather of 160-B records"),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "inputs": "resident in HBM", "latency_ms_single_batch": round(latency_ms, 3)},
@@ -224,7 +243,7 @@ def pmc_traffic(kernel_family, blobs_per_launch):
     return per_blob * blobs_per_launch, os.path.relpath(files[-1], ROOT)
 
 
-def time_cpu_baseline(commitments, proofs, host_blobs, n):
+def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
     """The CPU oracle (kind "port": the build's restatement of the reference algorithm, NOT blst) on the host cores of
     this box: verify_blob_kzg_proof_batch over the same first 64-blob batch, single thread like the reference."""
     from oracle.oracle import Oracle, build
@@ -239,16 +258,26 @@ def time_cpu_baseline(commitments, proofs, host_blobs, n):
     blobs = [bytes(host_blobs[i * BLOB:(i + 1) * BLOB]) for i in range(n)]
     cs = [commitments[48 * i:48 * i + 48] for i in range(n)]
     ps = [proofs[48 * i:48 * i + 48] for i in range(n)]
-    reps, t_total = 0, 0.0
+    reps, t_total, units = 0, 0.0, 0
     while t_total < 10.0 and reps < 200:
         t0 = time.perf_counter()
-        assert o.verify_blob_kzg_proof_batch(blobs, cs, ps, so) is True
+        if op == "verify":
+            assert o.verify_blob_kzg_proof_batch(blobs, cs, ps, so) is True
+            units += n
+        elif op == "commit":
+            assert o.blob_to_kzg_commitment(blobs[reps % n], so) == cs[reps % n]
+            units += 1
+        else:
+            assert o.compute_blob_kzg_proof(blobs[reps % n], cs[reps % n], so) == ps[reps % n]
+            units += 1
         t_total += time.perf_counter() - t0
         reps += 1
     o.free_trusted_setup(so)
-    return {"value": reps * n / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x verify_blob_kzg_proof_batch(n=64) on the bench's first batch, oracle -O3 -march=native, "
-                      f"{t_total:.1f} s; restatement in portable C, not blst (blst's asm is likely 1.5-3x faster per core)",
+    what = {"verify": "verify_blob_kzg_proof_batch(n=64) on the bench's first batch", "commit": "blob_to_kzg_commitment on blobs of the first batch",
+            "proof": "compute_blob_kzg_proof on blobs of the first batch"}[op]
+    return {"value": units / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; restatement in portable C, not blst "
+                      f"(blst's asm is likely 1.5-3x faster per core)",
             "host_cpus": os.cpu_count()}
 
 

@@ -160,7 +160,34 @@ KZG_HD void fp_dbl(Fp &r, const Fp &a) { KZG_FP_CONSTS mod_add<NFP>(r.l, a.l, a.
 KZG_HD void fp_neg(Fp &r, const Fp &a) { Fp z = fp_zero(); fp_sub(r, z, a); }
 KZG_HD bool fp_is_zero(const Fp &a) { return ul_is_zero<NFP>(a.l); }
 KZG_HD bool fp_eq(const Fp &a, const Fp &b) { return ul_eq<NFP>(a.l, b.l); }
-#if defined(KZG_FP_MUL_NOINLINE)
+#if defined(KZG_FP_MUL_CALL) && defined(__HIP_DEVICE_COMPILE__)
+// Throughput kernels: ONE out-of-line Fp product per kernel image, operands and result in VGPRs (two 16-lane vector
+// arguments = v0..v31, result v0..v15).  A fully inlined G1 formula is ~7k instructions (11 products): several of them
+// plus their callers overflow the 64 KB instruction cache that neighbouring CUs share, and with 8 waves per CU at
+// different program counters instruction fetch becomes the bottleneck.  With the call the hot loop is ~1.5k instructions.
+typedef uint32_t fp_vec __attribute__((ext_vector_type(16)));
+__device__ __attribute__((noinline)) inline fp_vec fp_mul_vec(fp_vec a, fp_vec b) {
+    KZG_FP_CONSTS
+    uint32_t x[NFP], y[NFP], r[NFP];
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { x[i] = a[i]; y[i] = b[i]; }
+    mont_mul<NFP>(r, x, y, FP_MOD, FP_INVW);
+    fp_vec o;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) o[i] = r[i];
+    o[14] = 0; o[15] = 0;
+    return o;
+}
+KZG_HD void fp_mul(Fp &r, const Fp &a, const Fp &b) {
+    fp_vec x, y;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { x[i] = a.l[i]; y[i] = b.l[i]; }
+    x[14] = 0; x[15] = 0; y[14] = 0; y[15] = 0;
+    const fp_vec o = fp_mul_vec(x, y);
+#pragma unroll
+    for (int i = 0; i < NFP; i++) r.l[i] = o[i];
+}
+#elif defined(KZG_FP_MUL_NOINLINE)
 KZG_HD_NOINLINE void fp_mul(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }
 #else
 KZG_HD void fp_mul(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }

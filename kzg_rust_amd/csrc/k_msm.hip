@@ -64,79 +64,116 @@ __global__ void __launch_bounds__(256) k_digits_from_fr(const Fr *scalars, int n
 }
 
 constexpr int MSM_THREADS = MSM_BUCKETS;   // 128: one lane per bucket
-constexpr int MSM_LANE_CAP = 64;           // entries one lane accumulates alone (uniform digits: 32 +- 6 per bucket)
 
-__global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digits, const G1Affine *table, G1Jac *partials) {
-    __shared__ uint16_t sorted[N_FE];
+// One workgroup handles `wpb` consecutive windows of one blob, MSM_MERGE (4) at a time.  Because the table is pre-shifted
+// per window, a point with digit d contributes d * table[w][i] whatever its window, so
+//   * the 16,384 digits of 4 windows go through ONE LDS counting sort (entry = index | window << 12 | sign << 15) and
+//     lane b walks one list of ~128 points: the lane-to-lane spread that a wave pays for (max over its 64 lanes) drops
+//     from +40 % (32 +- 6 points) to +20 % (128 +- 11);
+//   * the 128 bucket accumulators are SHARED by all wpb windows and the per-bucket weighting + tree reduction (about as
+//     expensive as 27 point additions per lane) is paid once per workgroup instead of once per window.
+// wpb = 4 keeps the dependent chain short (one blob alone: 8 workgroups); wpb = 8 when there are blobs enough to fill
+// the chip anyway.  The reduction scratch reuses the sort buffer, so LDS stays at 33 KB (4 workgroups per CU).
+// MSM_MERGE = 1 / wpb = 1 (one window per workgroup, 32 workgroups per blob) is the latency form used for small calls.
+template <int MSM_MERGE>
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digits, const G1Affine *table, G1Jac *partials, int wpb) {
+    constexpr int SORT_BYTES = MSM_MERGE * N_FE * 2, RED_BYTES = MSM_THREADS * (int)sizeof(G1Jac);
+    __shared__ __attribute__((aligned(16))) uint16_t sorted[(SORT_BYTES > RED_BYTES ? SORT_BYTES : RED_BYTES) / 2];   // sort buffer, reused for reductions
     __shared__ int cnt[MSM_BUCKETS + 1], start[MSM_BUCKETS + 1], cursor[MSM_BUCKETS + 1];
-    __shared__ G1Jac red[MSM_THREADS];
-    const int bw = blockIdx.x;                       // blob * 32 + window
-    const int w = bw % MSM_WINDOWS, tid = threadIdx.x;
-    for (int b = tid; b <= MSM_BUCKETS; b += MSM_THREADS) cnt[b] = 0;
-    __syncthreads();
-    // 32 consecutive digits per thread, two 16-byte loads (the whole window is one 4 KiB coalesced read)
-    const uint4 *dp = reinterpret_cast<const uint4 *>(digits + (size_t)bw * N_FE + 32 * tid);
-    const uint4 d0 = dp[0], d1 = dp[1];
-    const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-    const int bias = w == MSM_WINDOWS - 1 ? 0 : 127;
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int d = (int)((dw[k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
-        const int bucket = d < 0 ? -d : d;
-        if (bucket) atomicAdd(&cnt[bucket], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int b = 1; b <= MSM_BUCKETS; b++) { start[b] = acc; cursor[b] = acc; acc += cnt[b]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int d = (int)((dw[k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
-        const int bucket = d < 0 ? -d : d;
-        if (bucket) {
-            const int pos = atomicAdd(&cursor[bucket], 1);
-            sorted[pos] = (uint16_t)((32 * tid + k) | (d < 0 ? 0x8000 : 0));
-        }
-    }
-    __syncthreads();
-    // bucket accumulation: lane b sums the points whose |digit| == b + 1 -- but at most MSM_LANE_CAP of them.
-    // Real blobs are far from uniform (31-byte packing leaves the top byte 0, so window 31 only sees digits 0/1, and a
-    // constant blob puts all 4096 points of every window in ONE bucket): entries beyond the cap are summed by the whole
-    // workgroup (strided partial sums + LDS tree) and handed back to the bucket's lane, so no lane walks a long list.
-    const G1Affine *tw = table + (size_t)w * N_FE;
+    G1Jac *red = reinterpret_cast<G1Jac *>(sorted);
+    constexpr int LANE_CAP = MSM_MERGE == 1 ? 64 : 192;   // entries one lane accumulates alone per pass (uniform digits: 32 +- 6 / 128 +- 11)
+    const int groups_per_blob = MSM_WINDOWS / wpb;
+    const int blob = blockIdx.x / groups_per_blob, wg = blockIdx.x % groups_per_blob, tid = threadIdx.x;
     G1Jac acc = g1_inf();
-    {
-        const int b = tid + 1, s0 = start[b];
-        const int c = cnt[b] < MSM_LANE_CAP ? cnt[b] : MSM_LANE_CAP;
-        for (int j = s0; j < s0 + c; j++) {
-            const uint32_t v = sorted[j];
-            G1Affine p = tw[v & 0x0fff];
-            if (v & 0x8000) fp_neg(p.y, p.y);
-            g1_add_mixed(acc, acc, p);
+    for (int w0 = wg * wpb; w0 < (wg + 1) * wpb; w0 += MSM_MERGE) {
+        __syncthreads();                                  // previous lists / reduction scratch no longer in use
+        for (int b = tid; b <= MSM_BUCKETS; b += MSM_THREADS) cnt[b] = 0;
+        __syncthreads();
+        // per window: 32 consecutive digits per thread, two 16-byte loads (each window is one 4 KiB coalesced read)
+        uint32_t dw[MSM_MERGE][8];
+#pragma unroll
+        for (int wi = 0; wi < MSM_MERGE; wi++) {
+            const uint4 *dp = reinterpret_cast<const uint4 *>(digits + ((size_t)blob * MSM_WINDOWS + w0 + wi) * N_FE + 32 * tid);
+            const uint4 d0 = dp[0], d1 = dp[1];
+            dw[wi][0] = d0.x; dw[wi][1] = d0.y; dw[wi][2] = d0.z; dw[wi][3] = d0.w;
+            dw[wi][4] = d1.x; dw[wi][5] = d1.y; dw[wi][6] = d1.z; dw[wi][7] = d1.w;
         }
-    }
-    for (int b = 1; b <= MSM_BUCKETS; b++) {            // workgroup-uniform loop; normally no bucket qualifies
-        const int extra = cnt[b] - MSM_LANE_CAP;
-        if (extra <= 0) continue;
-        const int base = start[b] + MSM_LANE_CAP;
-        G1Jac part = g1_inf();
-        for (int j = tid; j < extra; j += MSM_THREADS) {
-            const uint32_t v = sorted[base + j];
-            G1Affine p = tw[v & 0x0fff];
-            if (v & 0x8000) fp_neg(p.y, p.y);
-            g1_add_mixed(part, part, p);
+#pragma unroll
+        for (int wi = 0; wi < MSM_MERGE; wi++) {
+            const int bias = (w0 + wi) == MSM_WINDOWS - 1 ? 0 : 127;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int d = (int)((dw[wi][k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
+                const int bucket = d < 0 ? -d : d;
+                if (bucket) atomicAdd(&cnt[bucket], 1);
+            }
         }
         __syncthreads();
-        red[tid] = part;
+        if (tid == 0) {
+            int run = 0;
+            for (int b = 1; b <= MSM_BUCKETS; b++) { start[b] = run; cursor[b] = run; run += cnt[b]; }
+        }
         __syncthreads();
-        for (int s = MSM_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s && tid + s < extra) { G1Jac x = red[tid], y = red[tid + s]; g1_add(x, x, y); red[tid] = x; }
+#pragma unroll
+        for (int wi = 0; wi < MSM_MERGE; wi++) {
+            const int bias = (w0 + wi) == MSM_WINDOWS - 1 ? 0 : 127;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int d = (int)((dw[wi][k >> 2] >> (8 * (k & 3))) & 0xff) - bias;
+                const int bucket = d < 0 ? -d : d;
+                if (bucket) {
+                    const int pos = atomicAdd(&cursor[bucket], 1);
+                    sorted[pos] = (uint16_t)((32 * tid + k) | (wi << 12) | (d < 0 ? 0x8000 : 0));
+                }
+            }
+        }
+        __syncthreads();
+        // bucket accumulation: lane b sums the points whose |digit| == b + 1 -- but at most MSM_LANE_CAP of them per pass.
+        // Real blobs are far from uniform (31-byte packing leaves the top byte 0, so window 31 only sees digits 0/1, and a
+        // constant blob puts all 4096 points of every window in ONE bucket): entries beyond the cap are summed by the whole
+        // workgroup (strided partial sums + tree) and handed back to the bucket's lane, so no lane walks a long list.
+        const G1Affine *tw = table + (size_t)w0 * N_FE;
+        {
+            const int b = tid + 1, s0 = start[b];
+            const int c = cnt[b] < LANE_CAP ? cnt[b] : LANE_CAP;
+            // software-pipelined gather: the table row of entry j+1 is requested before the addition of entry j, so the
+            // L2 / Infinity-Cache latency of the 112-byte row hides under ~6.6k instructions of field arithmetic
+            uint32_t v = c > 0 ? sorted[s0] : 0u;
+            G1Affine p = tw[v & 0x3fff];                   // window-in-group * 4096 + index
+            for (int j = 0; j < c; j++) {
+                const uint32_t vn = j + 1 < c ? sorted[s0 + j + 1] : v;
+                const G1Affine pn = tw[vn & 0x3fff];
+                if (v & 0x8000) fp_neg(p.y, p.y);
+                g1_add_mixed(acc, acc, p);
+                v = vn; p = pn;
+            }
+        }
+        for (int b = 1; b <= MSM_BUCKETS; b++) {            // workgroup-uniform loop; normally no bucket qualifies
+            const int extra = cnt[b] - LANE_CAP;
+            if (extra <= 0) continue;
+            const int base = start[b] + LANE_CAP;
+            G1Jac part = g1_inf();
+            for (int j = tid; j < extra; j += MSM_THREADS) {
+                const uint32_t v = sorted[base + j];
+                G1Affine p = tw[v & 0x3fff];
+                if (v & 0x8000) fp_neg(p.y, p.y);
+                g1_add_mixed(part, part, p);
+            }
+            // tree over the lanes by shuffles + one LDS-free cross-wave step is not worth it here (rare path): go through
+            // global-memory-free registers: wave butterfly, then wave 1 hands its sum to wave 0 through `cnt`-sized scratch
+            for (int off = 1; off < 64; off <<= 1) {
+                G1Jac o;
+#pragma unroll
+                for (int q = 0; q < NFP; q++) { o.x.l[q] = __shfl_xor(part.x.l[q], off, 64); o.y.l[q] = __shfl_xor(part.y.l[q], off, 64); o.z.l[q] = __shfl_xor(part.z.l[q], off, 64); }
+                g1_add(part, part, o);
+            }
+            // every lane of a wave now holds that wave's total; combine the two waves via the partial-sum slot of lane b-1
+            __shared__ G1Jac wave_part[2];
+            if ((tid & 63) == 0) wave_part[tid >> 6] = part;
+            __syncthreads();
+            if (tid == b - 1) { G1Jac x = wave_part[0], y = wave_part[1]; g1_add(x, x, y); g1_add(acc, acc, x); }
             __syncthreads();
         }
-        if (tid == b - 1) { G1Jac x = red[0]; g1_add(acc, acc, x); }
-        __syncthreads();
     }
     // weight by the bucket index (b+1 <= 128: 8-bit double-and-add), then tree-reduce across the workgroup
     {
@@ -146,6 +183,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digit
             g1_dbl(r, r);
             if ((m >> bit) & 1) g1_add(r, r, acc);
         }
+        __syncthreads();                                  // the sort buffer becomes the reduction scratch
         red[tid] = r;
     }
     __syncthreads();
@@ -153,13 +191,13 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digit
         if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
         __syncthreads();
     }
-    if (tid == 0) partials[bw] = red[0];
+    if (tid == 0) partials[(size_t)blob * groups_per_blob + wg] = red[0];
 }
 
-__global__ void __launch_bounds__(64) k_msm_finalize(const G1Jac *partials, uint8_t *out48) {
+__global__ void __launch_bounds__(64) k_msm_finalize(const G1Jac *partials, uint8_t *out48, int ppb) {
     __shared__ G1Jac red[MSM_WINDOWS];
     const int blob = blockIdx.x, tid = threadIdx.x;
-    if (tid < MSM_WINDOWS) red[tid] = partials[(size_t)blob * MSM_WINDOWS + tid];
+    if (tid < MSM_WINDOWS) red[tid] = tid < ppb ? partials[(size_t)blob * ppb + tid] : g1_inf();
     __syncthreads();
     for (int s = MSM_WINDOWS / 2; s > 0; s >>= 1) {
         if (tid < s) { G1Jac a = red[tid], b = red[tid + s]; g1_add(a, a, b); red[tid] = a; }
@@ -182,13 +220,17 @@ void launch_digits_from_fr(const Fr *d_scalars, int n, uint8_t *d_digits, hipStr
     const size_t total = (size_t)n * N_FE;
     hipLaunchKernelGGL(k_digits_from_fr, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_scalars, n, d_digits);
 }
+// windows per workgroup: 1 (latency form) for small calls, 8 (two merged passes of 4) once there are blobs enough to fill the chip
+int msm_windows_per_block(int n) { return n >= 128 ? 8 : 1; }
 void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_partials, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_msm_bucket, dim3(n * MSM_WINDOWS), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials);
+    const int wpb = msm_windows_per_block(n);
+    if (wpb == 1) hipLaunchKernelGGL(k_msm_bucket<1>, dim3(n * MSM_WINDOWS), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials, 1);
+    else hipLaunchKernelGGL(k_msm_bucket<4>, dim3(n * (MSM_WINDOWS / wpb)), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials, wpb);
 }
 void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_msm_finalize, dim3(n), dim3(64), 0, st, d_partials, d_out48);
+    hipLaunchKernelGGL(k_msm_finalize, dim3(n), dim3(64), 0, st, d_partials, d_out48, MSM_WINDOWS / msm_windows_per_block(n));
 }
 
 }  // namespace kzg
