@@ -192,6 +192,42 @@ KZG_HD void g1a_neg_phi(G1Affine &r, const G1Affine &p) {
     if (g1a_is_inf(p)) r = p;
 }
 
+// [k]P for a 128-bit k with signed 4-bit windows: digits in [-8, 8], table {1..8}P built once per lane (7 additions),
+// then 32 x (4 doublings + 1 addition).  Plain double-and-add pays dbl + add on EVERY bit (in a 64-lane wave some lane
+// always has its bit set): 128 x (dbl + madd) = 1.4M instructions per lane; this is ~0.9M.  The table lives in global
+// memory ([entry][word][lane]: coalesced per wave) because 64 lanes x 8 Jacobian points do not fit anything smaller.
+constexpr int W4_ENTRIES = 8;
+KZG_HD void w4_store(uint32_t *tab, int e, int lane, const G1Jac &v) {
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { tab[((e * 3 + 0) * NFP + i) * 64 + lane] = v.x.l[i]; tab[((e * 3 + 1) * NFP + i) * 64 + lane] = v.y.l[i]; tab[((e * 3 + 2) * NFP + i) * 64 + lane] = v.z.l[i]; }
+}
+KZG_HD void w4_load(G1Jac &v, const uint32_t *tab, int e, int lane) {
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { v.x.l[i] = tab[((e * 3 + 0) * NFP + i) * 64 + lane]; v.y.l[i] = tab[((e * 3 + 1) * NFP + i) * 64 + lane]; v.z.l[i] = tab[((e * 3 + 2) * NFP + i) * 64 + lane]; }
+}
+KZG_HD void g1_mul128_w4(G1Jac &r, const G1Affine &p, const uint32_t k[4], uint32_t *tab, int lane) {
+    G1Jac t; g1_from_affine(t, p);
+    w4_store(tab, 0, lane, t);
+    for (int e = 1; e < W4_ENTRIES; e++) { g1_add_mixed(t, t, p); w4_store(tab, e, lane, t); }     // (e+1) P
+    // signed recoding: k + 0x888...8 (33 nibbles) then nibble - 8 -> digits d_0..d_32 in [-8, 7], d_32 in {0, 1} - handled as nibble 32 unbiased
+    uint32_t e4[5];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c += (uint64_t)k[i] + 0x88888888u; e4[i] = (uint32_t)c; c >>= 32; }
+    e4[4] = (uint32_t)c;                                   // 0 or 1: the 33rd digit (unbiased)
+    G1Jac acc = g1_inf();
+    if (e4[4]) w4_load(acc, tab, 0, lane);                 // top digit 1 -> P
+    for (int nib = 31; nib >= 0; nib--) {
+        g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc);
+        const int d = (int)((e4[nib >> 3] >> (4 * (nib & 7))) & 15u) - 8;
+        const int mag = d < 0 ? -d : d;
+        G1Jac q = g1_inf();
+        if (mag) { w4_load(q, tab, mag - 1, lane); if (d < 0) fp_neg(q.y, q.y); }
+        g1_add(acc, acc, q);
+    }
+    r = acc;
+}
+
 // ZCash compressed encoding of an affine point ((0,0) = infinity)
 KZG_HD void g1_compress_affine(uint8_t *out, const G1Affine &p) {
     if (g1a_is_inf(p)) {

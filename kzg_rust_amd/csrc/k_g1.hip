@@ -68,9 +68,10 @@ __device__ __forceinline__ G1Jac g1_shfl_xor(const G1Jac &v, int mask) {
 __host__ __device__ inline int lincomb_waves_per_group(int n) { return (2 * (3 * n + 1) + 63) / 64; }
 
 __global__ void __launch_bounds__(64) k_lincomb_terms(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b,
-                                                       const uint32_t *scal_c, int n, G1Jac *partials) {
+                                                       const uint32_t *scal_c, int n, G1Jac *partials, uint32_t *wtabs) {
     const int wpg = lincomb_waves_per_group(n);
     const int g = blockIdx.x / wpg, wv = blockIdx.x % wpg, lane = threadIdx.x;
+    uint32_t *wtab = wtabs + (size_t)blockIdx.x * (W4_ENTRIES * 3 * NFP * 64);
     const int item = wv * 64 + lane;
     const G1Affine *gp = pts + (size_t)g * 2 * n;        // [0,n) commitments, [n,2n) proofs
     G1Jac m = g1_inf();
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(64) k_lincomb_terms(const G1Affine *pts, const
         uint32_t ka[4], kb[4];
         glv_split(ka, kb, k);
         if (half) { G1Affine q; g1a_neg_phi(q, p); p = q; }
-        g1_mul_words(m, p, half ? kb : ka, 4);
+        g1_mul128_w4(m, p, half ? kb : ka, wtab, lane);
     }
     for (int c = 0; c < 2; c++) {
         G1Jac v = g1_inf();
@@ -130,9 +131,14 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
                     int groups, G1Jac *d_partials, G1Affine *d_pair_pts, hipStream_t st) {
     if (groups <= 0) return;
     const int wpg = lincomb_waves_per_group(n_per_group);
-    hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials);
+    // the per-wave window tables follow the partial sums in the same scratch allocation (lincomb_partials_bytes)
+    uint32_t *d_wtabs = reinterpret_cast<uint32_t *>(d_partials + 2 * (size_t)wpg * groups);
+    hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials, d_wtabs);
     hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
 }
-size_t lincomb_partials_bytes(int n_per_group, int groups) { return sizeof(G1Jac) * 2 * (size_t)lincomb_waves_per_group(n_per_group) * groups; }
+size_t lincomb_partials_bytes(int n_per_group, int groups) {
+    const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
+    return sizeof(G1Jac) * 2 * waves + sizeof(uint32_t) * W4_ENTRIES * 3 * NFP * 64 * waves;
+}
 
 }  // namespace kzg

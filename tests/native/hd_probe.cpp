@@ -77,6 +77,15 @@ int hd_glv_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be) {
     g1_add(r1, r1, r2);
     g1_to_affine(ra, r1); g1_compress_affine(out, ra); return 0;
 }
+// [k]P for a 128-bit k through the signed 4-bit window routine used by k_lincomb_terms (lane 5 of a 64-lane table)
+int hd_w4_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be16) {
+    G1Affine pa, ra; G1Jac r; uint32_t k[4];
+    if (g1_decompress(pa, p)) return 1;
+    for (int i = 0; i < 4; i++) k[i] = ((uint32_t)k_be16[4 * (3 - i)] << 24) | ((uint32_t)k_be16[4 * (3 - i) + 1] << 16) | ((uint32_t)k_be16[4 * (3 - i) + 2] << 8) | k_be16[4 * (3 - i) + 3];
+    std::vector<uint32_t> tab(W4_ENTRIES * 3 * NFP * 64);
+    g1_mul128_w4(r, pa, k, tab.data(), 5);
+    g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
+}
 int hd_g2_decompress(const uint8_t *in) { G2Affine q; return g2_decompress(q, in); }
 // e(p1,q1) == e(p2,q2) via precomputed lines: ML(q1,-p1) * ML(q2,p2)
 int hd_pairings_verify(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {

@@ -144,6 +144,13 @@ def test_g1_mul_add(hd, oracle, setup_bytes):
             out = C.create_string_buffer(48)
             assert hd.hd_glv_mul(out, p, kb) == 0
             assert out.raw == oracle.g1_mul_add(p, kb, None), hex(k)
+    # signed 4-bit window multiplication by a 128-bit scalar (k_lincomb_terms)
+    for p in pts:
+        for k in [0, 1, 7, 8, 9, 15, 16, (1 << 128) - 1, 0x88888888888888888888888888888888, 0x77777777777777777777777777777777,
+                  0x8000000000000000_0000000000000000] + [rnd.randrange(1 << 128) for _ in range(4)]:
+            out = C.create_string_buffer(48)
+            assert hd.hd_w4_mul(out, p, k.to_bytes(16, "big")) == 0
+            assert out.raw == oracle.g1_mul_add(p, k.to_bytes(32, "big"), None), hex(k)
     # add-or-double corner cases of the Jacobian+Jacobian routine
     two_g = oracle.g1_mul_add(G1_GEN, (2).to_bytes(32, "big"))
     neg_g = oracle.g1_mul_add(G1_GEN, (R - 1).to_bytes(32, "big"))
