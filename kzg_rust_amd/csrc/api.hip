@@ -185,6 +185,37 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     return KZG355_OK;
 }
 
+// Enqueue one launch set on w->stream (no host synchronisation) ...
+int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G) {
+    const int n_total = npg * G;
+    int rc;
+    if ((rc = w->records.ensure((size_t)RECORD_BYTES * n_total))) return rc;
+    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * (size_t)n_total))) return rc;
+    if ((rc = w->err.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->ok.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->h_ok.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * (size_t)G))) return rc;
+    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
+    if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    return KZG355_OK;
+}
+// ... and wait for it: verdicts / statuses of its G batches.  Returns the first non-OK status.
+int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G) {
+    HIPCHK(hipStreamSynchronize(w->stream));
+    tm.collect();
+    int first = KZG355_OK;
+    for (int i = 0; i < G; i++) {
+        int st = status_from_err(w->h_err.as<int>()[i]);
+        if (status) status[i] = st;
+        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
+        else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
 int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, size_t npg, size_t groups,
                             const kzg355_settings *cs) {
     if (!cs || !ok) return KZG355_BADARGS;
@@ -196,31 +227,10 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
     if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
-    kzg355_settings *s = g.s; Workspace *w = g.w;
-    const int n_total = (int)(npg * groups), G = (int)groups;
-    int rc;
-    if ((rc = w->records.ensure((size_t)RECORD_BYTES * n_total))) return rc;
-    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * (size_t)n_total))) return rc;
-    if ((rc = w->err.ensure(sizeof(int) * (size_t)G))) return rc;
-    if ((rc = w->ok.ensure(sizeof(int) * (size_t)G))) return rc;
-    if ((rc = w->h_ok.ensure(sizeof(int) * (size_t)G))) return rc;
-    if ((rc = w->h_err.ensure(sizeof(int) * (size_t)G))) return rc;
-    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
-    Timed tm(s, w);
-    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, (int)npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
-    if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), (int)npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
-    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
-    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
-    HIPCHK(hipStreamSynchronize(w->stream));
-    tm.collect();
-    int first = KZG355_OK;
-    for (int i = 0; i < G; i++) {
-        int st = status_from_err(w->h_err.as<int>()[i]);
-        if (status) status[i] = st;
-        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
-        else if (first == KZG355_OK) first = st;
-    }
-    return first;
+    Timed tm(g.s, g.w);
+    int rc = verify_enqueue(g.s, g.w, tm, d_blobs, d_c, d_p, (int)npg, (int)groups);
+    if (rc) return rc;
+    return verify_collect(g.w, tm, ok, status, (int)groups);
 }
 
 int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes) {
@@ -541,16 +551,41 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t
     const size_t n = n_per_group * groups;
     if (n == 0) return verify_many_device_impl(ok, status, nullptr, nullptr, nullptr, n_per_group, groups, cs);
     if (!blobs || !commitments || !proofs) return KZG355_BADARGS;
-    // stage the inputs in a workspace of their own; the compute call below takes a second one from the pool
-    WsGuard g(cs);
-    if (!g.w) return KZG355_NO_DEVICE;
-    Workspace *w = g.w;
-    int rc;
-    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
-    if ((rc = stage_to_device(w, w->commitments, commitments, 48 * n))) return rc;
-    if ((rc = stage_to_device(w, w->proofs, proofs, 48 * n))) return rc;
-    HIPCHK(hipStreamSynchronize(w->stream));
-    return verify_many_device_impl(ok, status, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), n_per_group, groups, cs);
+    if (n > (size_t)1 << 24) return KZG355_BADARGS;
+    // Host buffers: the batches are cut into chunks of <= 256 MiB of blobs and double-buffered over two workspaces, so
+    // the H2D copy of chunk k+1 (on its own stream) runs while the kernels of chunk k execute.
+    size_t gpc = ((size_t)256 << 20) / ((size_t)BLOB_BYTES * n_per_group);      // batches per chunk
+    if (gpc < 1) gpc = 1;
+    if (gpc > groups) gpc = groups;
+    WsGuard g0(cs), g1(cs);
+    if (!g0.w || !g1.w) return KZG355_NO_DEVICE;
+    kzg355_settings *s = g0.s;
+    Workspace *ws[2] = {g0.w, g1.w};
+    Timed tm0(s, ws[0]), tm1(s, ws[1]);
+    Timed *tms[2] = {&tm0, &tm1};
+    int first = KZG355_OK;
+    size_t prev_g0 = 0, prev_cnt = 0;
+    int k = 0;
+    for (size_t gstart = 0; gstart < groups; gstart += gpc, k++) {
+        const size_t cnt = groups - gstart < gpc ? groups - gstart : gpc;
+        Workspace *w = ws[k & 1];
+        const size_t nb = cnt * n_per_group, off = gstart * n_per_group;
+        int rc;
+        if ((rc = stage_to_device(w, w->blobs, blobs + (size_t)BLOB_BYTES * off, (size_t)BLOB_BYTES * nb))) return rc;
+        if ((rc = stage_to_device(w, w->commitments, commitments + 48 * off, 48 * nb))) return rc;
+        if ((rc = stage_to_device(w, w->proofs, proofs + 48 * off, 48 * nb))) return rc;
+        if ((rc = verify_enqueue(s, w, *tms[k & 1], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)n_per_group, (int)cnt))) return rc;
+        if (k > 0) {   // collect the previous chunk while this one runs
+            rc = verify_collect(ws[(k - 1) & 1], *tms[(k - 1) & 1], ok + prev_g0, status ? status + prev_g0 : nullptr, (int)prev_cnt);
+            if (rc == KZG355_NO_DEVICE) return rc;
+            if (rc != KZG355_OK && first == KZG355_OK) first = rc;
+        }
+        prev_g0 = gstart; prev_cnt = cnt;
+    }
+    int rc = verify_collect(ws[(k - 1) & 1], *tms[(k - 1) & 1], ok + prev_g0, status ? status + prev_g0 : nullptr, (int)prev_cnt);
+    if (rc == KZG355_NO_DEVICE) return rc;
+    if (rc != KZG355_OK && first == KZG355_OK) first = rc;
+    return first;
 }
 
 int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,

@@ -66,3 +66,22 @@ def test_host_mirror_type_rules():
         kz.KzgProof.from_hex("0xzz")                 # kzg.rs:82-86
     assert kz.Bytes32.from_hex("0x" + "11" * 32) == kz.Bytes32.from_hex("11" * 32)
     assert kz.KzgCommitment.from_hex("c0" + "00" * 47).to_bytes()[0] == 0xC0
+
+
+def test_trusted_setup_json_helper(setup_bytes):
+    """TrustedSetup (src/trusted_setup.rs): hex with/without 0x, truncation of G1 to 4096, round trip, length errors."""
+    import json
+    import kzg_rust_amd as kz
+    g1, g2 = setup_bytes
+    g1l = [g1[48 * i:48 * i + 48] for i in range(4096)]
+    g2l = [g2[96 * i:96 * i + 96] for i in range(65)]
+    text = json.dumps({"setup_G1": ["ignored"], "setup_G1_lagrange": ["0x" + p.hex() for p in g1l] + [g1l[0].hex()] * 3,
+                       "setup_G2": [p.hex() for p in g2l], "roots_of_unity": []})
+    ts = kz.TrustedSetup.from_json(text)
+    assert ts.g1_len() == 4096 and ts.g2_len() == 65          # truncated (trusted_setup.rs:151)
+    assert ts.g1_points() == g1l and ts.g2_points() == g2l
+    assert kz.TrustedSetup.from_json(ts.to_json()).g1_points() == g1l
+    with pytest.raises(kz.InvalidBytesLength):
+        kz.TrustedSetup.from_json(json.dumps({"setup_G1_lagrange": ["0x00"], "setup_G2": []}))
+    with pytest.raises(kz.InvalidHexFormat):
+        kz.TrustedSetup.from_json(json.dumps({"setup_G1_lagrange": ["0xzz"], "setup_G2": []}))

@@ -75,6 +75,20 @@ def test_load_trusted_setup_errors(kz, setup_bytes, tmp_path):
         kz.Kzg.load_trusted_setup_file(str(tmp_path / "missing.txt"))
 
 
+def test_load_from_json_trusted_setup(kz, setup_bytes, golden_vectors, golden_blobs):
+    """Kzg::load_trusted_setup fed from the JSON helper (src/trusted_setup.rs) gives a working handle."""
+    import json
+    g1, g2 = setup_bytes
+    text = json.dumps({"setup_G1_lagrange": ["0x" + g1[48 * i:48 * i + 48].hex() for i in range(4096)],
+                       "setup_G2": ["0x" + g2[96 * i:96 * i + 96].hex() for i in range(65)]})
+    ts = kz.TrustedSetup.from_json(text)
+    s = kz.Kzg.load_trusted_setup(ts.g1_points(), ts.g2_points())
+    case = [c for c in golden_vectors["blob_to_kzg_commitment"] if c["output"]][0]
+    got = kz.Kzg.blob_to_kzg_commitment(kz.Blob(golden_blobs[case["input"]["blob"]["blob"]]), s)
+    assert got.to_bytes().hex() == case["output"][2:]
+    s.free()
+
+
 N_RANDOM = 8
 
 
