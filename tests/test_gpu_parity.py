@@ -260,3 +260,58 @@ def test_sharded_driver_world1_on_gpu(kz, settings, random_set):
     torch.cuda.synchronize()
     ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n, 2, HipEngine(settings))
     assert ok == [True, False] and st == [0, 0]
+
+
+def test_differential_verify_kzg_proof_mutations(kz, settings, oracle, oracle_settings, random_set):
+    """Differential test against the oracle on mutated inputs: valid statements, wrong y / z / proof, points off the
+    curve, points on the curve but outside G1, non-canonical field elements, flag-bit corruptions.  Ok/Err and the
+    boolean must agree case by case."""
+    import random
+    from oracle.oracle import OracleError
+    rnd = random.Random(99)
+    blobs, cs, ps = random_set
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    base = []
+    for i in range(4):
+        z = random_field_element(40 + i)
+        p, y = oracle.compute_kzg_proof(blobs[i], z, oracle_settings)
+        base.append((cs[i], z, y, p))
+
+    def mutate(t):
+        c, z, y, p = t
+        k = rnd.randrange(10)
+        if k == 0:
+            return t
+        if k == 1:
+            return (c, z, ((int.from_bytes(y, "big") + 1) % R).to_bytes(32, "big"), p)
+        if k == 2:
+            return (c, ((int.from_bytes(z, "big") + 1) % R).to_bytes(32, "big"), y, p)
+        if k == 3:
+            return (c, z, y, rnd.choice(ps))
+        if k == 4:   # random x: usually not on the curve, sometimes on the curve but outside the subgroup
+            b = bytearray(rnd.randrange(1 << 381).to_bytes(48, "big")); b[0] = (b[0] & 0x1F) | 0x80 | (0x20 if rnd.random() < .5 else 0)
+            return (bytes(b), z, y, p) if rnd.random() < .5 else (c, z, y, bytes(b))
+        if k == 5:
+            return (c, (R + rnd.randrange(1000)).to_bytes(32, "big"), y, p)      # non-canonical z
+        if k == 6:
+            return (c, z, b"\xff" * 32, p)                                        # non-canonical y
+        if k == 7:
+            b = bytearray(c); b[0] ^= rnd.choice([0x80, 0x40, 0x20]); return (bytes(b), z, y, p)
+        if k == 8:
+            return (bytes([0xC0]) + bytes(47), z, y, bytes([0xC0]) + bytes(47))   # infinity / infinity
+        b = bytearray(p); b[rnd.randrange(1, 48)] ^= 1 << rnd.randrange(8); return (c, z, y, bytes(b))
+
+    n_ok = n_err = n_true = 0
+    for _ in range(120):
+        c, z, y, p = mutate(rnd.choice(base))
+        try:
+            want = oracle.verify_kzg_proof(c, z, y, p, oracle_settings)
+        except OracleError:
+            want = None
+        try:
+            got = kz.Kzg.verify_kzg_proof(kz.KzgCommitment(c), kz.Bytes32(z), kz.Bytes32(y), kz.KzgProof(p), settings)
+        except kz.Error:
+            got = None
+        assert got == want, (c.hex(), z.hex(), y.hex(), p.hex(), got, want)
+        n_ok += want is not None; n_err += want is None; n_true += want is True
+    assert n_true >= 5 and n_err >= 10 and n_ok - n_true >= 10      # every outcome class was exercised
