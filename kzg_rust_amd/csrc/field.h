@@ -127,6 +127,36 @@ template <int N> KZG_HD void mont_mul(uint32_t *r, const uint32_t *a, const uint
 #pragma unroll
     for (int j = 0; j < N; j++) r[j] = br ? t[j] : s[j];
 }
+// Same product WITHOUT the final conditional subtraction: result < m (1 + a*b / (m 2^(29N))), limbs normalised.
+// For operands below ~2.6 m the result stays below 1.1 m, which is all a following product (or a bounded number of
+// additions) needs; the last operation of a chain uses mont_mul, which canonicalises.  Saves ~45 of ~316 (Fr)
+// instructions per product on throughput kernels.
+template <int N> KZG_HD void mont_mul_lazy(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *m, const uint32_t inv) {
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t bi = b[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] += (uint64_t)a[j] * bi;
+        const uint32_t q = ((uint32_t)acc[0] * inv) & LMASK;
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] += (uint64_t)q * m[j];
+        const uint64_t carry = acc[0] >> LB;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        c += acc[j];
+        r[j] = j < N - 1 ? ((uint32_t)c & LMASK) : (uint32_t)c;     // the top limb keeps any excess
+        c >>= LB;
+    }
+}
 // 32-bit word array (little-endian words, NW of them) -> N 29-bit limbs
 template <int N, int NW> KZG_HD void words_to_limbs(uint32_t *l, const uint32_t *w) {
 #pragma unroll
@@ -273,6 +303,14 @@ KZG_HD void fr_add(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_add<NFR>
 KZG_HD void fr_sub(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_sub<NFR>(r.l, a.l, b.l, FR_MOD); }
 KZG_HD void fr_mul(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
 KZG_HD void fr_sqr(Fr &r, const Fr &a) { fr_mul(r, a, a); }
+// lazy product: operands < ~2.6 r, result < 1.1 r, not canonical (see mont_mul_lazy)
+KZG_HD void fr_mul_lazy(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul_lazy<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
+// lazy sum: plain limb addition with carry normalisation, no reduction (value grows; keep chains short)
+KZG_HD void fr_add_lazy(Fr &r, const Fr &a, const Fr &b) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) { uint32_t t = a.l[i] + b.l[i] + c; c = i < NFR - 1 ? t >> LB : 0u; r.l[i] = i < NFR - 1 ? (t & LMASK) : t; }
+}
 KZG_HD bool fr_is_zero(const Fr &a) { return ul_is_zero<NFR>(a.l); }
 KZG_HD bool fr_eq(const Fr &a, const Fr &b) { return ul_eq<NFR>(a.l, b.l); }
 KZG_HD void fr_select(Fr &r, bool take_b, const Fr &a, const Fr &b) {

@@ -35,21 +35,25 @@ __device__ __forceinline__ Fr fr_shfl(const Fr &v, int src) {
     for (int i = 0; i < NFR; i++) r.l[i] = __shfl(v.l[i], src, 64);
     return r;
 }
-// product over the other lanes of the wave: exclusive prefix * exclusive suffix; also returns the wave total
+// product over the other lanes of the wave: exclusive prefix * exclusive suffix; also returns the wave total.
+// LAZY = true uses non-canonical products (values < 1.1 r; see mont_mul_lazy) -- for chains that end in a canonical product.
+template <bool LAZY = false>
 __device__ __forceinline__ void wave_product_except_self(Fr &excl, Fr &total, const Fr &v, int lane) {
     const Fr one = fr_one();
     Fr pre = v, suf = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         Fr a = fr_shfl_up(pre, off), b = fr_shfl_down(suf, off), t;
-        fr_mul(t, pre, a); fr_select(pre, lane >= off, pre, t);
-        fr_mul(t, suf, b); fr_select(suf, lane + off < 64, suf, t);
+        if (LAZY) fr_mul_lazy(t, pre, a); else fr_mul(t, pre, a);
+        fr_select(pre, lane >= off, pre, t);
+        if (LAZY) fr_mul_lazy(t, suf, b); else fr_mul(t, suf, b);
+        fr_select(suf, lane + off < 64, suf, t);
     }
     total = fr_shfl(pre, 63);
     Fr pe = fr_shfl_up(pre, 1), se = fr_shfl_down(suf, 1);
     fr_select(pe, lane == 0, pe, one);
     fr_select(se, lane == 63, se, one);
-    fr_mul(excl, pe, se);
+    if (LAZY) fr_mul_lazy(excl, pe, se); else fr_mul(excl, pe, se);
 }
 
 

@@ -170,26 +170,26 @@ __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z
         Fr d0, d1, d2, d3, a, b, c;
         fr_sub(d0, z, roots[tid]); fr_sub(d1, z, roots[1024 + tid]);
         fr_sub(d2, z, roots[2048 + tid]); fr_sub(d3, z, roots[3072 + tid]);
-        fr_mul(a, d0, d1); fr_mul(b, d2, d3); fr_mul(L, a, b);
-        fr_mul(c, d1, b); cs_store(cs, 0, tid, c);
-        fr_mul(c, d0, b); cs_store(cs, 1, tid, c);
-        fr_mul(c, a, d3); cs_store(cs, 2, tid, c);
-        fr_mul(c, a, d2); cs_store(cs, 3, tid, c);
+        fr_mul_lazy(a, d0, d1); fr_mul_lazy(b, d2, d3); fr_mul_lazy(L, a, b);      // lazy products: values < 1.1 r
+        fr_mul_lazy(c, d1, b); cs_store(cs, 0, tid, c);
+        fr_mul_lazy(c, d0, b); cs_store(cs, 1, tid, c);
+        fr_mul_lazy(c, a, d3); cs_store(cs, 2, tid, c);
+        fr_mul_lazy(c, a, d2); cs_store(cs, 3, tid, c);
     }
     Fr ex;
     {
         Fr tot;
-        wave_product_except_self(ex, tot, L, lane);
+        wave_product_except_self<true>(ex, tot, L, lane);
         if (lane == 0) wave_tot[wid] = tot;
     }
     __syncthreads();
     if (wid == 0) {                                               // product of the other 15 waves' totals, for each wave
         Fr v = lane < 16 ? wave_tot[lane] : fr_one(), e2, t2;
-        wave_product_except_self(e2, t2, v, lane);
+        wave_product_except_self<true>(e2, t2, v, lane);
         if (lane < 16) wave_ex[lane] = e2;
     }
     __syncthreads();
-    fr_mul(ex, ex, wave_ex[wid]);                                 // prod over all other threads of L
+    fr_mul_lazy(ex, ex, wave_ex[wid]);                            // prod over all other threads of L
     // pass 2: numerators.  S = sum_k p_k w_k c_k ; the blob element enters as a plain integer, so p*w (Montgomery w)
     // is a plain-domain value and so is everything downstream: y comes out as the canonical integer, no conversions.
     Fr S = fr_zero();
@@ -201,13 +201,13 @@ __global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z
         bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
         Fr p, t, c;
         words_to_limbs<NFR, 8>(p.l, w);
-        fr_mul(t, p, roots[e]);                                   // p_i * w_i   (plain domain)
+        fr_mul_lazy(t, p, roots[e]);                              // p_i * w_i   (plain domain)
         cs_load(c, cs, k, tid);
-        fr_mul(t, t, c);
-        fr_add(S, S, t);
+        fr_mul_lazy(t, t, c);
+        fr_add_lazy(S, S, t);                                     // S < 4.4 r
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
-    fr_mul(S, S, ex);
+    fr_mul(S, S, ex);                                             // canonical again: the chain of lazy products ends here
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(S, off); fr_add(S, S, o); }
     if (lane == 0) wave_sum[wid] = S;
