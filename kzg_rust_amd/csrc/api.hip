@@ -82,6 +82,7 @@ struct kzg355_settings {
     DeviceTables t{};
     DevBuf roots, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
+    int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
     std::mutex mu;
     std::vector<Workspace *> pool;
     bool timing = false;
@@ -177,7 +178,13 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
     if ((rc = w->lc_partials.ensure(lincomb_partials_bytes(npg, groups)))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
-    tm.begin("lincomb"); launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream); tm.end();
+    // windowed per-term form (shortest chain) for few batches, bucket method (least issue work) when many are in flight
+    const bool buckets = npg >= 8 && npg <= 128 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
+    if (buckets && (rc = w->lc_partials.ensure(lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
+    tm.begin("lincomb");
+    if (buckets) launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream);
+    else launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
+    tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
     else launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
@@ -383,6 +390,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
         s->t.coop_scheds = s->scheds.as<CoopSched>();
     }
     if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
+    if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);

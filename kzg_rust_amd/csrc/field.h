@@ -157,6 +157,36 @@ template <int N> KZG_HD void mont_mul_lazy(uint32_t *r, const uint32_t *a, const
         c >>= LB;
     }
 }
+// r = (a*b + c*d) / R, lazily: two products share one Montgomery reduction (2N^2 + N^2 limb products instead of 4N^2).
+// Operands as for mont_mul_lazy with (a*b + c*d) < ~5 m^2; the column sums stay below 2^64 for N <= 9 limbs of 29 bits.
+template <int N> KZG_HD void mont_mul2_lazy(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d,
+                                            const uint32_t *m, const uint32_t inv) {
+    static_assert(N <= 9, "column accumulators sized for at most 9 limbs");
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t bi = b[i], di = d[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) { acc[j] += (uint64_t)a[j] * bi; acc[j] += (uint64_t)c[j] * di; }
+        const uint32_t q = ((uint32_t)acc[0] * inv) & LMASK;
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[j] += (uint64_t)q * m[j];
+        const uint64_t carry = acc[0] >> LB;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    uint64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        cy += acc[j];
+        r[j] = j < N - 1 ? ((uint32_t)cy & LMASK) : (uint32_t)cy;
+        cy >>= LB;
+    }
+}
 // 32-bit word array (little-endian words, NW of them) -> N 29-bit limbs
 template <int N, int NW> KZG_HD void words_to_limbs(uint32_t *l, const uint32_t *w) {
 #pragma unroll
@@ -305,6 +335,8 @@ KZG_HD void fr_mul(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul<NFR
 KZG_HD void fr_sqr(Fr &r, const Fr &a) { fr_mul(r, a, a); }
 // lazy product: operands < ~2.6 r, result < 1.1 r, not canonical (see mont_mul_lazy)
 KZG_HD void fr_mul_lazy(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul_lazy<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
+// r = a*b + c*d with one reduction (lazy; result < 1.1 r for a*b + c*d < ~5 r^2)
+KZG_HD void fr_mul2_lazy(Fr &r, const Fr &a, const Fr &b, const Fr &c, const Fr &d) { KZG_FR_CONSTS mont_mul2_lazy<NFR>(r.l, a.l, b.l, c.l, d.l, FR_MOD, FR_INVW); }
 // lazy sum: plain limb addition with carry normalisation, no reduction (value grows; keep chains short)
 KZG_HD void fr_add_lazy(Fr &r, const Fr &a, const Fr &b) {
     uint32_t c = 0;

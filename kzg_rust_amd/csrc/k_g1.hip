@@ -117,6 +117,126 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
     pair_pts[2 * (size_t)g + c] = a;
 }
 
+// ------------------------------------------------------------------------------------------------ lincomb, bucket form
+// Throughput form of the same two sums: a variable-base Pippenger MSM per batch ("the batched G1 MSM" of
+// verify_kzg_proof_batch).  Independent scalar multiplications cost ~1830 field-product equivalents per lane whatever the
+// batch; the bucket method shares the doublings:
+//   k_lc_prep     one lane per term: GLV split, signed 4-bit recoding of both halves (33 digits in [-8, 8]),
+//                 the two points P and -phi(P)                                    -> items[2(3n+1)], digits[item][33]
+//   k_lc_buckets  one wave = 8 (window, class) tasks x 8 buckets: LDS counting sort of the class's items by |digit|,
+//                 lane (task, b) adds up its list (mixed additions), weights by b, 8-lane butterfly -> S[class][window]
+//   k_lc_horner   one lane per (batch, class): Horner over the 33 windows (4 doublings + 1 addition each), to affine
+// ~2.3x less issue work per batch than the windowed form above; its dependent chain is no shorter (the Horner tail),
+// so it is used when many batches are in flight and the windowed form otherwise.
+constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
+constexpr int LC_DIG_STRIDE = 36;
+__host__ __device__ inline int lc_items(int n) { return 2 * (3 * n + 1); }
+constexpr int LC_WAVES_PER_CLASS = 5;   // 33 windows / 8 tasks per wave
+
+__global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b, const uint32_t *scal_c, int n,
+                                                 G1Affine *items, int8_t *digits) {
+    const int nt = 3 * n + 1, bpg = (nt + 63) / 64;
+    const int g = blockIdx.x / bpg, t = (blockIdx.x % bpg) * 64 + threadIdx.x;
+    if (t >= nt) return;
+    const G1Affine *gp = pts + (size_t)g * 2 * n;
+    G1Affine p; uint32_t k[8];
+    if (t < n) { p = gp[n + t]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + t) + q]; }
+    else if (t < 2 * n) { p = gp[n + (t - n)]; for (int q = 0; q < 8; q++) k[q] = scal_b[8 * ((size_t)g * n + (t - n)) + q]; }
+    else if (t < 3 * n) { p = gp[t - 2 * n]; for (int q = 0; q < 8; q++) k[q] = scal_a[8 * ((size_t)g * n + (t - 2 * n)) + q]; }
+    else {
+        const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT;
+        for (int q = 0; q < NFP; q++) { p.x.l[q] = gx[q]; p.y.l[q] = gy[q]; }
+        fp_neg(p.y, p.y);
+        for (int q = 0; q < 8; q++) k[q] = scal_c[8 * (size_t)g + q];
+    }
+    uint32_t half[2][4];
+    glv_split(half[0], half[1], k);
+    G1Affine q2; g1a_neg_phi(q2, p);
+    const size_t base = (size_t)g * lc_items(n) + 2 * (size_t)t;
+    items[base] = p; items[base + 1] = q2;
+    for (int h = 0; h < 2; h++) {
+        uint32_t e4[5]; uint64_t c = 0;
+        for (int i = 0; i < 4; i++) { c += (uint64_t)half[h][i] + 0x88888888u; e4[i] = (uint32_t)c; c >>= 32; }
+        e4[4] = (uint32_t)c;
+        int8_t *d = digits + (base + h) * LC_DIG_STRIDE;
+        for (int w = 0; w < 32; w++) d[w] = (int8_t)((int)((e4[w >> 3] >> (4 * (w & 7))) & 15u) - 8);
+        d[32] = (int8_t)e4[4];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S) {
+    __shared__ uint16_t lists[8][520];           // per task: item | sign << 15, grouped by bucket
+    __shared__ int cnt[8][9], start[8][9], cursor[8][9];
+    const int g = blockIdx.x / (2 * LC_WAVES_PER_CLASS), wv = blockIdx.x % (2 * LC_WAVES_PER_CLASS), lane = threadIdx.x;
+    const int cls = wv < LC_WAVES_PER_CLASS ? 1 : 0;
+    const int w0 = (wv % LC_WAVES_PER_CLASS) * 8;
+    const int ni = lc_items(n);
+    const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;       // item range of the class (terms t < n are class 0)
+    const G1Affine *it = items + (size_t)g * ni;
+    const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
+    if (w0 == LC_WINDOWS - 1) {
+        // the carry digit (0 or 1): a single bucket holding about half of the items -> spread it over the whole wave
+        G1Jac acc = g1_inf();
+        for (int j = lo + lane; j < hi; j += 64)
+            if (dg[(size_t)j * LC_DIG_STRIDE + w0]) { G1Affine p = it[j]; g1_add_mixed(acc, acc, p); }
+#pragma unroll 1
+        for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
+        if (lane == 0) S[((size_t)g * 2 + cls) * LC_WINDOWS + w0] = acc;
+        return;
+    }
+    for (int q = lane; q < 72; q += 64) cnt[q / 9][q % 9] = 0;
+    __syncthreads();
+    for (int tk = 0; tk < 8; tk++) {
+        const int w = w0 + tk;
+        if (w >= LC_WINDOWS) break;
+        for (int j = lo + lane; j < hi; j += 64) { const int d = dg[(size_t)j * LC_DIG_STRIDE + w]; if (d) atomicAdd(&cnt[tk][d < 0 ? -d : d], 1); }
+    }
+    __syncthreads();
+    if (lane < 8) { int run = 0; for (int b = 1; b <= 8; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
+    __syncthreads();
+    for (int tk = 0; tk < 8; tk++) {
+        const int w = w0 + tk;
+        if (w >= LC_WINDOWS) break;
+        for (int j = lo + lane; j < hi; j += 64) {
+            const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
+            if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk][pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
+        }
+    }
+    __syncthreads();
+    const int tk = lane >> 3, b = (lane & 7) + 1, w = w0 + tk;
+    G1Jac acc = g1_inf();
+    if (w < LC_WINDOWS) {
+        const int s0 = start[tk][b], c = cnt[tk][b];
+        for (int q = 0; q < c; q++) {
+            const uint32_t v = lists[tk][s0 + q];
+            G1Affine p = it[v & 0x7fff];
+            if (v & 0x8000) fp_neg(p.y, p.y);
+            g1_add_mixed(acc, acc, p);
+        }
+    }
+    // b * acc (b <= 8: 4-bit double-and-add), then sum over the 8 buckets of the task
+    G1Jac r = g1_inf();
+    for (int bit = 3; bit >= 0; bit--) { g1_dbl(r, r); if ((b >> bit) & 1) g1_add(r, r, acc); }
+#pragma unroll 1
+    for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
+    if (b == 1 && w < LC_WINDOWS) S[((size_t)g * 2 + cls) * LC_WINDOWS + w] = r;
+}
+
+__global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * groups) return;
+    const int g = id >> 1, cls = id & 1;
+    const G1Jac *s = S + ((size_t)g * 2 + cls) * LC_WINDOWS;
+    G1Jac acc = s[LC_WINDOWS - 1];
+    for (int w = LC_WINDOWS - 2; w >= 0; w--) {
+        g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc);
+        G1Jac v = s[w]; g1_add(acc, acc, v);
+    }
+    G1Affine a; g1_to_affine(a, acc);
+    if (cls == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[2 * (size_t)g + cls] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
                             hipStream_t st) {
@@ -135,6 +255,22 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
     uint32_t *d_wtabs = reinterpret_cast<uint32_t *>(d_partials + 2 * (size_t)wpg * groups);
     hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials, d_wtabs);
     hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
+}
+void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
+                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st) {
+    if (groups <= 0) return;
+    const size_t ni = (size_t)lc_items(n_per_group) * groups;
+    G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
+    G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
+    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * groups);
+    const int nt = 3 * n_per_group + 1;
+    hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S);
+    hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
+}
+size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
+    const size_t ni = (size_t)lc_items(n_per_group) * groups;
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 256;
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;

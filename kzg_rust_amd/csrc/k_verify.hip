@@ -4,7 +4,7 @@
 // Stage 1 (independent per blob -- "HOT LOOP A", kzg.rs:671-683):
 //   k_validate_points   validate_kzg_g1 on C_i and proof_i          (utils.rs:282-310)   1 lane / point
 //   k_challenge         z_i = SHA-256 Fiat-Shamir challenge          (kzg.rs:298-339)     1 lane / blob
-//   k_eval              blob -> Fr (canonical check) and y_i=p_i(z_i) (kzg.rs:282-291, 346-389) 1 workgroup / blob
+//   k_eval              blob -> Fr (canonical check) and y_i=p_i(z_i) (kzg.rs:282-291, 346-389) 1 wave / blob
 // Stage 2 (per batch of n records -- verify_kzg_proof_batch, kzg.rs:579-627):
 //   k_rpowers           r = hash of the transcript, r^i, r^i z_i, sum r^i y_i   (utils.rs:426-474)
 //   k_lincomb           sum r^i proof_i  and  sum r^i C_i + sum r^i z_i proof_i - [sum r^i y_i]G
@@ -146,78 +146,49 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
 // blob and of the roots table); per thread  L_t = d0 d1 d2 d3  and the three-factor complements; across threads an
 // exclusive prefix * suffix product with wave shuffles (6+6 steps) and a 16-entry LDS stage; then a shuffle/LDS sum.
 // ~34 Fr products per thread instead of ~410 (one Fermat inversion per thread) in the first version of this kernel.
-__device__ __forceinline__ void cs_store(uint32_t *cs, int k, int tid, const Fr &v) {
-#pragma unroll
-    for (int i = 0; i < NFR; i++) cs[(k * NFR + i) * 1024 + tid] = v.l[i];
-}
-__device__ __forceinline__ void cs_load(Fr &v, const uint32_t *cs, int k, int tid) {
-#pragma unroll
-    for (int i = 0; i < NFR; i++) v.l[i] = cs[(k * NFR + i) * 1024 + tid];
-}
-__global__ void __launch_bounds__(1024) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
-                                                uint8_t *records, int *err) {
-    __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16];
-    __shared__ uint32_t cs[4 * NFR * 1024];                       // the per-element complements c_k, [k][limb][thread]
-    const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// One wave per blob, 64 elements per lane, no LDS and no barrier.  A lane folds its elements into the pair
+//     P = prod_k d_k ,  S = sum_k p_k w_k prod_{j != k} d_j          (d = z - w)
+// by  S <- S d + (p w) P ,  P <- P d   -- 3.5 product-equivalents per element (the two products of S share one reduction),
+// and the wave combines the 64 pairs as  sum_l S_l prod_{m != l} P_m  with one "product of all the others" scan.
+// z inside the domain needs no special case: with d_m = 0 every term but the m-th vanishes and
+// (1/N) p_m w_m prod_{j != m}(w_m - w_j) = p_m, which is what kzg.rs:360-362 returns.
+// Domains: z, w, d, P in Montgomery form; the blob element enters as a plain integer, so p w, S and y are plain: y comes
+// out as the canonical integer with no conversion.  Intermediate products are lazy (< 1.1 r), the last ones canonical.
+__global__ void __launch_bounds__(64, 4) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
+                                                 uint8_t *records, int *err) {
+    const int blob_i = blockIdx.x, lane = threadIdx.x;
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
-    // pass 1: denominators only.  c_k = product of the thread's other three (z - w), L = product of all four.
-    // Register budget: 1024 threads per workgroup cap a lane at 128 VGPRs (4 waves/SIMD), so the four c_k wait in LDS
-    // (144 KiB of the CU's 160: one workgroup per CU, which is what the VGPR budget allows anyway) and the blob / roots
-    // are re-read from L2 in pass 2: no scratch traffic.
-    Fr L;
-    {
-        const Fr z = z_in[blob_i];
-        Fr d0, d1, d2, d3, a, b, c;
-        fr_sub(d0, z, roots[tid]); fr_sub(d1, z, roots[1024 + tid]);
-        fr_sub(d2, z, roots[2048 + tid]); fr_sub(d3, z, roots[3072 + tid]);
-        fr_mul_lazy(a, d0, d1); fr_mul_lazy(b, d2, d3); fr_mul_lazy(L, a, b);      // lazy products: values < 1.1 r
-        fr_mul_lazy(c, d1, b); cs_store(cs, 0, tid, c);
-        fr_mul_lazy(c, d0, b); cs_store(cs, 1, tid, c);
-        fr_mul_lazy(c, a, d3); cs_store(cs, 2, tid, c);
-        fr_mul_lazy(c, a, d2); cs_store(cs, 3, tid, c);
-    }
-    Fr ex;
-    {
-        Fr tot;
-        wave_product_except_self<true>(ex, tot, L, lane);
-        if (lane == 0) wave_tot[wid] = tot;
-    }
-    __syncthreads();
-    if (wid == 0) {                                               // product of the other 15 waves' totals, for each wave
-        Fr v = lane < 16 ? wave_tot[lane] : fr_one(), e2, t2;
-        wave_product_except_self<true>(e2, t2, v, lane);
-        if (lane < 16) wave_ex[lane] = e2;
-    }
-    __syncthreads();
-    fr_mul_lazy(ex, ex, wave_ex[wid]);                            // prod over all other threads of L
-    // pass 2: numerators.  S = sum_k p_k w_k c_k ; the blob element enters as a plain integer, so p*w (Montgomery w)
-    // is a plain-domain value and so is everything downstream: y comes out as the canonical integer, no conversions.
-    Fr S = fr_zero();
+    const Fr z = z_in[blob_i];
+    Fr P, S;
     bool bad = false;
+    uint32_t w[8]; Fr root;
+    load_blob_element_words(w, blob, lane); root = roots[lane];
 #pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-        const int e = k * 1024 + tid;
-        uint32_t w[8]; load_blob_element_words(w, blob, e);
+    for (int k = 0; k < 64; k++) {
+        uint32_t wn[8]; Fr rootn;
+        const int en = (k < 63 ? k + 1 : k) * 64 + lane;          // next element's loads fly during this one's products
+        load_blob_element_words(wn, blob, en); rootn = roots[en];
         bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
-        Fr p, t, c;
+        Fr p, d, q;
         words_to_limbs<NFR, 8>(p.l, w);
-        fr_mul_lazy(t, p, roots[e]);                              // p_i * w_i   (plain domain)
-        cs_load(c, cs, k, tid);
-        fr_mul_lazy(t, t, c);
-        fr_add_lazy(S, S, t);                                     // S < 4.4 r
+        fr_sub(d, z, root);
+        fr_mul_lazy(q, p, root);                                  // p_i * w_i   (plain domain)
+        if (k == 0) { P = d; S = q; }
+        else { fr_mul2_lazy(S, S, d, q, P); fr_mul_lazy(P, P, d); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = wn[i];
+        root = rootn;
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
+    Fr ex, tot;
+    wave_product_except_self<true>(ex, tot, P, lane);
     fr_mul(S, S, ex);                                             // canonical again: the chain of lazy products ends here
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(S, off); fr_add(S, S, o); }
-    if (lane == 0) wave_sum[wid] = S;
-    __syncthreads();
-    if (tid == 0) {
-        Fr sum = wave_sum[0];
-        for (int i = 1; i < 16; i++) fr_add(sum, sum, wave_sum[i]);
+    if (lane == 0) {
         const uint32_t inv4096[NFR] = FR_INV4096_INIT;
         Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-        Fr y; fr_mul(y, sum, k4096);                              // canonical integer value of y
+        Fr y; fr_mul(y, S, k4096);                                // canonical integer value of y
         if (records) {
             uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
             uint8_t *rec = records + (size_t)RECORD_BYTES * blob_i + 80;
@@ -312,7 +283,7 @@ void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, con
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(1024), 0, st, d_blobs, d_z, t.roots, n_per_group, d_y, d_records, d_err);
+    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, n_per_group, d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st) {

@@ -315,3 +315,32 @@ def test_differential_verify_kzg_proof_mutations(kz, settings, oracle, oracle_se
         assert got == want, (c.hex(), z.hex(), y.hex(), p.hex(), got, want)
         n_ok += want is not None; n_err += want is None; n_true += want is True
     assert n_true >= 5 and n_err >= 10 and n_ok - n_true >= 10      # every outcome class was exercised
+
+
+def test_bucket_lincomb_matches_windowed(kz, setup_bytes, settings, oracle, oracle_settings):
+    """The two forms of the batch linear combination (per-term windowed, bucket method) must agree: honest batches verify,
+    corrupted ones do not, for batch sizes around the bucket kernel's packing (8 tasks x 8 buckets per wave, 33 windows)
+    and past its limit (129 falls back to the windowed form).  KZG355_LINCOMB pins the form for one settings handle."""
+    g1, g2 = setup_bytes
+    os.environ["KZG355_LINCOMB"] = "bucket"
+    try:
+        sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_LINCOMB"]
+    try:
+        blobs = [random_blob(7000 + i) for i in range(129)]
+        B, cs, ps = _product_commit_prove(kz, settings, blobs)
+        for n in (8, 9, 33, 64, 128, 129):
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], ps[:n], sb) is True
+            bad = list(ps[:n]); bad[n - 1] = ps[n - 2]
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], bad, sb) is False
+            badc = list(cs[:n]); badc[0] = cs[1]
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], badc, ps[:n], sb) is False
+        # many batches in one launch (the throughput entry point), one of them wrong
+        groups = [(B[16 * g:16 * g + 16], cs[16 * g:16 * g + 16], ps[16 * g:16 * g + 16]) for g in range(8)]
+        groups[5] = (groups[5][0], groups[5][1], list(reversed(groups[5][2])))
+        res = kz.Kzg.verify_blob_kzg_proof_batch_many(groups, sb)
+        assert [r is True for r in res] == [g != 5 for g in range(8)]
+        assert oracle.verify_blob_kzg_proof_batch(blobs[:16], [c.to_bytes() for c in cs[:16]], [p.to_bytes() for p in ps[:16]], oracle_settings) is True
+    finally:
+        sb.free()
