@@ -61,6 +61,20 @@ __device__ __forceinline__ void challenge_block_words(uint32_t w[16], const uint
     }
 }
 
+__device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, uint8_t *records) {
+    // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
+    const uint32_t dw[8] = {hh[7], hh[6], hh[5], hh[4], hh[3], hh[2], hh[1], hh[0]};
+    Fr z; fr_from_words(z, dw);
+    z_out[i] = z;
+    if (!records) return;
+    uint8_t *rec = records + (size_t)RECORD_BYTES * i;
+    for (int k = 0; k < 48; k++) rec[k] = cm[k];
+    uint8_t zb[32]; fr_to_be32(zb, z);
+    for (int k = 0; k < 32; k++) rec[48 + k] = zb[k];
+    const uint8_t *pr = proofs + 48 * (size_t)i;
+    for (int k = 0; k < 48; k++) rec[112 + k] = pr[k];
+}
+
 __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
                                                     Fr *z_out, uint8_t *records) {
     __shared__ uint4 wk[2][16][64];                 // [buffer][t/4][lane] -> W[t..t+3] + K[t..t+3]
@@ -122,17 +136,55 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
         __syncthreads();
     }
     if (role != 0 || i_raw >= n_total) return;
-    // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
-    const uint32_t dw[8] = {h7, h6, h5, h4, h3, h2, h1, h0};
-    Fr z; fr_from_words(z, dw);
-    z_out[i] = z;
-    if (!records) return;
-    uint8_t *rec = records + (size_t)RECORD_BYTES * i;
-    for (int k = 0; k < 48; k++) rec[k] = cm[k];
-    uint8_t zb[32]; fr_to_be32(zb, z);
-    for (int k = 0; k < 32; k++) rec[48 + k] = zb[k];
-    const uint8_t *pr = proofs + 48 * (size_t)i;
-    for (int k = 0; k < 48; k++) rec[112 + k] = pr[k];
+    const uint32_t hh[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+    challenge_finish(hh, i, cm, proofs, z_out, records);
+}
+
+// The same hash with schedule and rounds in ONE wave.  The two-wave form above halves the dependent chain per block, which is
+// what counts while every wave has a SIMD to itself (<= 512 workgroups on 1024 SIMDs); past that its producer and consumer
+// share SIMDs, each wave issues at half rate, and the lighter single wave (~1430 instead of 930 + 500 instructions per
+// block, no LDS hand-off, no barrier) finishes sooner.
+__global__ void __launch_bounds__(64) k_challenge_1w(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
+                                                      Fr *z_out, uint8_t *records) {
+    const int lane = threadIdx.x;
+    const int i_raw = blockIdx.x * 64 + lane;
+    const int i = i_raw < n_total ? i_raw : n_total - 1;
+    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
+    const uint8_t *cm = commitments + 48 * (size_t)i;
+    static const uint32_t K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+        0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+        0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+        0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+        0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+        0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+        0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+        0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    uint32_t hh[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint32_t w[16], wn[16];
+    challenge_block_words(w, blob, cm, 0);
+#pragma unroll 1
+    for (int b = 0; b < CH_BLOCKS; b++) {
+        challenge_block_words(wn, blob, cm, b + 1 < CH_BLOCKS ? b + 1 : b);     // next block's loads fly during the rounds
+        uint32_t a = hh[0], bb = hh[1], c = hh[2], d = hh[3], e = hh[4], f = hh[5], g = hh[6], h = hh[7];
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                const uint32_t s0 = xor3(ror(w15, 7), ror(w15, 18), w15 >> 3);
+                const uint32_t s1 = xor3(ror(w2, 17), ror(w2, 19), w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+            }
+            const uint32_t t1 = h + xor3(ror(e, 6), ror(e, 11), ror(e, 25)) + ch3(e, f, g) + (w[t & 15] + K[t]);
+            const uint32_t t2 = xor3(ror(a, 2), ror(a, 13), ror(a, 22)) + maj3(a, bb, c);
+            h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        hh[0] += a; hh[1] += bb; hh[2] += c; hh[3] += d; hh[4] += e; hh[5] += f; hh[6] += g; hh[7] += h;
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = wn[k];
+    }
+    if (i_raw >= n_total) return;
+    challenge_finish(hh, i, cm, proofs, z_out, records);
 }
 
 // ------------------------------------------------------------------------------------------------ evaluation
@@ -141,11 +193,6 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
 // cases z == w_i.  Because  prod_j (z - w_j) = z^N - 1,  the same value is
 //         y = (1/N) * sum_i  p_i w_i * prod_{j != i} (z - w_j)
 // which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m).
-// "Product of all the others" is a scan: one 1024-thread workgroup per blob, 4 elements per thread
-// (element e = k*1024 + tid: consecutive lanes read consecutive 32-byte elements -> coalesced 1 KiB wave loads of the
-// blob and of the roots table); per thread  L_t = d0 d1 d2 d3  and the three-factor complements; across threads an
-// exclusive prefix * suffix product with wave shuffles (6+6 steps) and a 16-entry LDS stage; then a shuffle/LDS sum.
-// ~34 Fr products per thread instead of ~410 (one Fermat inversion per thread) in the first version of this kernel.
 // One wave per blob, 64 elements per lane, no LDS and no barrier.  A lane folds its elements into the pair
 //     P = prod_k d_k ,  S = sum_k p_k w_k prod_{j != k} d_j          (d = z - w)
 // by  S <- S d + (p w) P ,  P <- P d   -- 3.5 product-equivalents per element (the two products of S share one reduction),
@@ -276,9 +323,11 @@ __global__ void __launch_bounds__(64) k_pairing(const G1Affine *pair_pts, const 
 
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
-                       hipStream_t st) {
+                       hipStream_t st, int form) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_challenge, dim3((n_total + 63) / 64), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+    const int wgs = (n_total + 63) / 64;
+    if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+    else hipLaunchKernelGGL(k_challenge_1w, dim3(wgs), dim3(64), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
 }
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {

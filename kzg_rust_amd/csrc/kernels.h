@@ -50,7 +50,7 @@ void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proof
                             G1Affine *d_pts /* [group][2*npg]: commitments then proofs; may be null */, int *d_err /* per group */,
                             hipStream_t st);
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
-                       Fr *d_z, uint8_t *d_records, hipStream_t st);
+                       Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
                  uint8_t *d_records /* y written at +80; may be null */, int *d_err, hipStream_t st);
 // stage 2 (per group of n records): points from records, r-powers, lincomb, pairing

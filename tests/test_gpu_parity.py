@@ -344,3 +344,43 @@ def test_bucket_lincomb_matches_windowed(kz, setup_bytes, settings, oracle, orac
         assert oracle.verify_blob_kzg_proof_batch(blobs[:16], [c.to_bytes() for c in cs[:16]], [p.to_bytes() for p in ps[:16]], oracle_settings) is True
     finally:
         sb.free()
+
+
+def _records_of(kz, s, blobs, cs, ps):
+    import torch
+    n = len(blobs)
+    dev = torch.device("cuda", s.device)
+    t_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    t_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
+    t_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
+    t_rec = torch.zeros(160 * n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = (C.c_int * 1)(-1)
+    rc = kz.kzg.lib().kzg355_verify_shard_records_device(t_rec.data_ptr(), st, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n, 1, s.handle)
+    assert rc == 0 and st[0] == 0
+    return bytes(t_rec.cpu().numpy())
+
+
+@pytest.mark.parametrize("form", ["1w", "2w"])
+def test_challenge_kernel_forms_match_oracle(form, kz, setup_bytes, random_set, oracle, oracle_settings):
+    """Both forms of the Fiat-Shamir kernel (producer/consumer pair of waves for few blobs, single wave when the card is
+    full) give the oracle's z_i -- and so the same y_i -- whatever size picks between them in production.  65 + 2 blobs:
+    a second, partial workgroup."""
+    g1, g2 = setup_bytes
+    os.environ["KZG355_CHALLENGE"] = form
+    try:
+        s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_CHALLENGE"]
+    try:
+        blobs, cs, ps = random_set
+        reps = (65 + len(blobs) - 1) // len(blobs) + 1
+        B, Cs, Ps = (blobs * reps)[:67], (cs * reps)[:67], (ps * reps)[:67]
+        rec = _records_of(kz, s, B, Cs, Ps)
+        inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+        for i in range(67):
+            j = i % len(blobs)
+            assert rec[160 * i + 48:160 * i + 80] == inter["z"][j], f"z[{i}]"
+            assert rec[160 * i + 80:160 * i + 112] == inter["y"][j], f"y[{i}]"
+    finally:
+        s.free()
