@@ -159,7 +159,8 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     // Point validation depends on nothing but the inputs.  While the card is far from full (few batches) it runs on the side
     // stream next to the challenge -> evaluation (-> r powers) chain and the main stream waits for it only where the points
     // are first needed (join_side()).  With many batches in flight both kernels fill the card on their own and sharing the
-    // SIMDs only slows the challenge kernel's producer/consumer hand-off (measured: 8.9 + 4.2 ms apart, 14.1 ms together).
+    // SIMDs only slows the challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together:
+    // one-wave workgroups of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
     if (n_total <= 16384) {
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));

@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 //   k_lc_horner   one lane per (batch, class): Horner over the 33 windows (4 doublings + 1 addition each), to affine
 // ~2.3x less issue work per batch than the windowed form above; its dependent chain is no shorter (the Horner tail),
 // so it is used when many batches are in flight and the windowed form otherwise.
-constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
 constexpr int LC_DIG_STRIDE = 36;
+constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
 __host__ __device__ inline int lc_items(int n) { return 2 * (3 * n + 1); }
 constexpr int LC_WAVES_PER_CLASS = 5;   // 33 windows / 8 tasks per wave
 

@@ -1,21 +1,30 @@
 // k_pairing.hip -- the pairing check of verify_kzg_proof_batch (reference src/utils.rs:189-214, called at kzg.rs:625)
-// as a wave-cooperative kernel: one 64-lane workgroup per batch, Fp12 coefficients spread over the lanes
+// as a wave-cooperative kernel: one 64-lane wave per batch, Fp12 coefficients spread over the lanes
 // (pairing_coop.h).  ~20x shorter dependent chain than the one-lane-per-batch kernel in k_verify.hip.
-#define KZG_FP_MUL_NOINLINE 1
+#define KZG_MID_INLINE 1     // everything inline: no stack objects, no scratch (the out-of-line tower routines cost 1.5 KB of scratch per lane)
 #include "kernels.h"
 
 namespace kzg {
 
-__global__ void __launch_bounds__(64) k_pairing_coop(const G1Affine *pair_pts, const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
-                                                      const CoopInsn *prog, int n_insn, const CoopSched *scheds, int *ok) {
-    __shared__ CoopMem mem;
-    const int g = blockIdx.x;
+// PAIRING_WAVES batches per workgroup, one wave each.  The waves of ONE workgroup are spread over the CU's four SIMDs, and
+// the padded LDS request (launch_pairing) lets exactly ceil(groups / 1024) workgroups onto a CU: every wave of this
+// latency-bound kernel gets a SIMD to itself as long as groups <= 1024.  (With one-wave workgroups the placement was left
+// to the dispatcher: 4.1 ms on a good day, 6.1 ms when two waves shared a SIMD -- same wave-cycles, same clocks.)
+constexpr int PAIRING_WAVES = 4;
+__global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Affine *pair_pts, int groups,
+                                                                      const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
+                                                                      const CoopInsn *prog, int n_insn, const CoopSched *scheds, int *ok) {
+    __shared__ CoopMem mems[PAIRING_WAVES];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g_raw = blockIdx.x * PAIRING_WAVES + wid;
+    const int g = g_raw < groups ? g_raw : groups - 1;            // a tail wave redoes the last batch and writes nothing
+    CoopMem &mem = mems[wid];
     G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
     if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
     if (lines_inf[0]) p2 = g1a_inf();
     // ML([tau]G2, -proof_lincomb) * ML(G2, rhs): lines_w[2] = setup g2[1] = [tau]G2, lines_w[0] = G2 generator
     const bool r = coop_pairing_check(mem, prog, n_insn, scheds, lines_w + 2 * N_LINES, p1, lines_w, p2, *frob);
-    if (threadIdx.x == 0) ok[g] = r ? 1 : 0;
+    if (lane == 0 && g_raw < groups) ok[g] = r ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, LineW *lines_w, int n) {
@@ -27,7 +36,16 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
 
 void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_pairing_coop, dim3(groups), dim3(64), 0, st, d_pair_pts, t.lines_w, t.lines_inf, t.frob, t.pairing_prog, t.pairing_prog_len, t.coop_scheds, d_ok);
+    const int wgs = (groups + PAIRING_WAVES - 1) / PAIRING_WAVES;
+    // pad the LDS request so that no more than ceil(wgs / 256) workgroups fit on a CU: an even spread by construction
+    const int per_cu = (wgs + 255) / 256;
+    const size_t fixed = sizeof(CoopMem) * PAIRING_WAVES + 1024;
+    size_t pad = 0;
+    const size_t want = ((size_t)160 * 1024 / per_cu) & ~(size_t)1023;
+    if (want > fixed && want - fixed < 64 * 1024) pad = want - fixed;
+    else if (want > fixed) pad = 64 * 1024 - 1024;
+    hipLaunchKernelGGL(k_pairing_coop, dim3(wgs), dim3(64 * PAIRING_WAVES), pad, st, d_pair_pts, groups, t.lines_w, t.lines_inf,
+                       t.frob, t.pairing_prog, t.pairing_prog_len, t.coop_scheds, d_ok);
 }
 void launch_lines_to_w(DeviceTables t, hipStream_t st) {
     hipLaunchKernelGGL(k_lines_to_w, dim3(1), dim3(256), 0, st, t.lines, t.lines_w, 3 * N_LINES);

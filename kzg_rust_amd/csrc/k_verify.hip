@@ -144,10 +144,10 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
 // what counts while every wave has a SIMD to itself (<= 512 workgroups on 1024 SIMDs); past that its producer and consumer
 // share SIMDs, each wave issues at half rate, and the lighter single wave (~1430 instead of 930 + 500 instructions per
 // block, no LDS hand-off, no barrier) finishes sooner.
-__global__ void __launch_bounds__(64) k_challenge_1w(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
+constexpr int CH1W_THREADS = 256;       // four waves per workgroup: one per SIMD of the CU it lands on
+__global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
                                                       Fr *z_out, uint8_t *records) {
-    const int lane = threadIdx.x;
-    const int i_raw = blockIdx.x * 64 + lane;
+    const int i_raw = blockIdx.x * CH1W_THREADS + threadIdx.x;
     const int i = i_raw < n_total ? i_raw : n_total - 1;
     const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
     const uint8_t *cm = commitments + 48 * (size_t)i;
@@ -327,7 +327,7 @@ void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, con
     if (n_total <= 0) return;
     const int wgs = (n_total + 63) / 64;
     if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
-    else hipLaunchKernelGGL(k_challenge_1w, dim3(wgs), dim3(64), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+    else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
 }
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {

@@ -23,8 +23,11 @@
 #include "pairing.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define COOP_LANES(lane) for (int lane = (int)threadIdx.x, coop_once_ = 1; coop_once_; coop_once_ = 0)
-#define COOP_SYNC() __syncthreads()
+// One WAVE per Fp12 computation (a workgroup may hold several, each with its own CoopMem): the phases are separated by a
+// wave-local fence -- LDS operations of one wave complete in order, so waiting for them is all a "barrier" has to do.
+#define COOP_LANES(lane) for (int lane = (int)(threadIdx.x & 63), coop_once_ = 1; coop_once_; coop_once_ = 0)
+#define COOP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #else
 #define COOP_LANES(lane) for (int lane = 0; lane < 64; lane++)
 #define COOP_SYNC() ((void)0)

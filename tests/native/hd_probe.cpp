@@ -19,6 +19,7 @@ int hd_fp_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
         case 5: fp_neg(r, x); break; case 6: fp_dbl(r, x); break;
         case 7: { out[0] = fp_is_lex_largest(x); return 0; }
         case 8: fp_inv(r, x); break;
+        case 9: fp_sqr(r, x); break;
         default: return 1;
     }
     fp_to_be48(out, r); return 0;
@@ -33,6 +34,15 @@ int hd_fr_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
         case 5: fr_inv(r, x); break;
         default: return 1;
     }
+    fr_to_be32(out, r); return 0;
+}
+// out = a*b + c*d mod r through the lazy two-product reduction, then canonicalised by one ordinary product with 1
+int hd_fr_mul2(uint8_t *out, const uint8_t *a, const uint8_t *b, const uint8_t *c, const uint8_t *d) {
+    Fr x[4], r; uint32_t w[8]; const uint8_t *in[4] = {a, b, c, d};
+    for (int i = 0; i < 4; i++) { be32_to_words(w, in[i]); fr_from_words(x[i], w); }
+    fr_mul2_lazy(r, x[0], x[1], x[2], x[3]);
+    Fr l; fr_mul_lazy(l, r, fr_one());          // a lazy value fed to a lazy product ...
+    fr_mul(r, l, fr_one());                     // ... and the canonical product that ends the chain
     fr_to_be32(out, r); return 0;
 }
 // 0 ok / 1 bad encoding / 2 not on curve / 3 not in subgroup ; out = recompressed point

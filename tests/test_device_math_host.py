@@ -48,6 +48,7 @@ def test_fp_arithmetic(hd):
             assert _fp(hd, 1, a, b)[1] == (a - b) % P
             assert _fp(hd, 2, a, b)[1] == (a * b) % P
         assert _fp(hd, 5, a)[1] == (-a) % P
+        assert _fp(hd, 9, a)[1] == (a * a) % P            # dedicated squaring (mont_sqr)
         assert _fp(hd, 6, a)[1] == (2 * a) % P
         assert C.create_string_buffer(1) is not None
     for a in vals:                                   # divstep inversion (modinv.h) against Python
@@ -71,6 +72,11 @@ def test_fr_arithmetic(hd):
         out = C.create_string_buffer(32)
         hd.hd_fr_op(4, out, a.to_bytes(32, "big"), bytes(32))
         assert out.raw[0] == (1 if a < R else 0)
+    for _ in range(200):                             # fused a*b + c*d with one reduction (k_eval's S <- S d + q P)
+        a, b, c, d = (rnd.choice(vals) for _ in range(4))
+        out = C.create_string_buffer(32)
+        assert hd.hd_fr_mul2(out, *(v.to_bytes(32, "big") for v in (a, b, c, d))) == 0
+        assert int.from_bytes(out.raw, "big") == (a * b + c * d) % R
     for a in vals:
         assert _fr(hd, 5, a)[1] == (pow(a % R, -1, R) if a % R else 0), hex(a)
     for a in vals[:12]:
