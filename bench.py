@@ -238,15 +238,19 @@ def pmc_traffic(kernel_family, blobs_per_launch):
     MI355X_MICROARCH.md, WRITE_SIZE as is; separate passes, collected with this same bench command).  The counters are per
     blob there; scaled to this run's launch size.  None if no summary is committed for that kernel."""
     import glob
-    names = {"eval": "k_eval", "challenge": "k_challenge", "lincomb": "k_lincomb_terms", "pairing": "k_pairing_coop",
-             "validate_points": "k_validate_points", "rpowers": "k_rpowers", "points_from_records": "k_points_from_records"}
+    names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_prep", "k_lc_buckets", "k_lc_horner"],
+             "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
+             "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "quotient": ["k_quotient"]}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")))
     if not files or kernel_family not in names:
         return None, None
-    d = json.load(open(files[-1]))["per_kernel"].get(names[kernel_family])
-    if not d:
+    per = json.load(open(files[-1]))["per_kernel"]
+    ds = [per[k] for k in names[kernel_family] if k in per]
+    if kernel_family in ("challenge", "msm_bucket"):
+        ds = ds[:1]                                              # alternative forms of one kernel, not a sequence
+    if not ds:
         return None, None
-    per_blob = d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"]
+    per_blob = sum(d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"] for d in ds)
     return per_blob * blobs_per_launch, os.path.relpath(files[-1], ROOT)
 
 

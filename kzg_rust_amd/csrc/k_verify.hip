@@ -33,33 +33,41 @@ __device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { re
 __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
 
 constexpr int CH_BLOCKS = 2050;
-__device__ __forceinline__ void challenge_block_words(uint32_t w[16], const uint4 *blob, const uint8_t *cm, int b) {
-    if (b >= 1 && b < 2048) {                       // blob[64b-32, 64b+32)
-        const uint4 *p = blob + (4 * b - 2);
-        uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
-        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
-        w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
-        w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
-    } else if (b == 0) {                            // domain | 0 | 4096 | blob[0..32)
-        w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
-        w[4] = 0; w[5] = 0; w[6] = 0; w[7] = (uint32_t)N_FE;
-        uint4 v0 = blob[0], v1 = blob[1];
-        w[8] = bswap32(v0.x); w[9] = bswap32(v0.y); w[10] = bswap32(v0.z); w[11] = bswap32(v0.w);
-        w[12] = bswap32(v1.x); w[13] = bswap32(v1.y); w[14] = bswap32(v1.z); w[15] = bswap32(v1.w);
-    } else if (b == 2048) {                         // blob[131040, 131072) | commitment[0..32)
-        const uint4 *p = blob + (4 * 2048 - 2);
-        uint4 v0 = p[0], v1 = p[1];
-        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
-        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
-        for (int k = 0; k < 8; k++) w[8 + k] = load_be32(cm + 4 * k);
-    } else {                                        // commitment[32..48) | 0x80 | zeros | bit length
-        for (int k = 0; k < 4; k++) w[k] = load_be32(cm + 32 + 4 * k);
-        w[4] = 0x80000000u;
-        for (int k = 5; k < 15; k++) w[k] = 0;
-        w[15] = (uint32_t)((32 + BLOB_BYTES + 48) * 8);
+// The hashed message puts the blob at offset 32, so compression b covers blob[64b-32, 64b+32): every block straddles two
+// aligned 64-byte sectors of the blob.  Reading "the block's 64 bytes" touches each sector twice (two blocks apart in time:
+// at full-card sizes the second touch misses and HBM fetches double -- 281 KB per 131 KB blob by FETCH_SIZE).  The reader below
+// loads each ALIGNED sector once, one block ahead, uses its lower half now and carries its upper half to the next block.
+struct ChallengeReader {
+    const uint4 *blob; const uint8_t *cm;
+    uint4 nxt[4];            // sector b (blob[64b, 64b+64)), loaded by prefetch(b)
+    uint32_t carry[8];       // upper half of sector b-1, big-endian words
+    __device__ __forceinline__ void prefetch(int b) {
+        if (b < 2048) { const uint4 *p = blob + 4 * b; nxt[0] = p[0]; nxt[1] = p[1]; nxt[2] = p[2]; nxt[3] = p[3]; }
     }
-}
+    // words of compression b; prefetch(b) must have run.  Leaves carry ready for b + 1.
+    __device__ __forceinline__ void words(uint32_t w[16], int b) {
+        if (b == 0) {                                   // domain | u64be(0) | u64be(4096)
+            w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
+            w[4] = 0; w[5] = 0; w[6] = 0; w[7] = (uint32_t)N_FE;
+        } else if (b <= 2048) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = carry[k];
+        }
+        if (b < 2048) {
+            w[8] = bswap32(nxt[0].x); w[9] = bswap32(nxt[0].y); w[10] = bswap32(nxt[0].z); w[11] = bswap32(nxt[0].w);
+            w[12] = bswap32(nxt[1].x); w[13] = bswap32(nxt[1].y); w[14] = bswap32(nxt[1].z); w[15] = bswap32(nxt[1].w);
+            carry[0] = bswap32(nxt[2].x); carry[1] = bswap32(nxt[2].y); carry[2] = bswap32(nxt[2].z); carry[3] = bswap32(nxt[2].w);
+            carry[4] = bswap32(nxt[3].x); carry[5] = bswap32(nxt[3].y); carry[6] = bswap32(nxt[3].z); carry[7] = bswap32(nxt[3].w);
+        } else if (b == 2048) {                         // ... | commitment[0..32)
+            for (int k = 0; k < 8; k++) w[8 + k] = load_be32(cm + 4 * k);
+        } else {                                        // commitment[32..48) | 0x80 | zeros | bit length
+            for (int k = 0; k < 4; k++) w[k] = load_be32(cm + 32 + 4 * k);
+            w[4] = 0x80000000u;
+            for (int k = 5; k < 15; k++) w[k] = 0;
+            w[15] = (uint32_t)((32 + BLOB_BYTES + 48) * 8);
+        }
+    }
+};
 
 __device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, uint8_t *records) {
     // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
@@ -92,9 +100,11 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
         0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
         0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
         0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    ChallengeReader rd; rd.blob = blob; rd.cm = cm;
     auto produce = [&](int b) {
         uint32_t w[16];
-        challenge_block_words(w, blob, cm, b);
+        rd.words(w, b);
+        rd.prefetch(b + 1);                          // flies during the schedule expansion below
         uint4 *dst = &wk[b & 1][0][lane];
 #pragma unroll
         for (int t = 0; t < 64; t += 4) {
@@ -112,7 +122,7 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
         }
     };
     uint32_t h0 = 0x6a09e667u, h1 = 0xbb67ae85u, h2 = 0x3c6ef372u, h3 = 0xa54ff53au, h4 = 0x510e527fu, h5 = 0x9b05688cu, h6 = 0x1f83d9abu, h7 = 0x5be0cd19u;
-    if (role == 1) produce(0);
+    if (role == 1) { rd.prefetch(0); produce(0); }
     __syncthreads();
     for (int b = 0; b < CH_BLOCKS; b++) {
         if (role == 0) {
@@ -161,11 +171,13 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
         0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
         0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
     uint32_t hh[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
-    uint32_t w[16], wn[16];
-    challenge_block_words(w, blob, cm, 0);
+    ChallengeReader rd; rd.blob = blob; rd.cm = cm;
+    rd.prefetch(0);
 #pragma unroll 1
     for (int b = 0; b < CH_BLOCKS; b++) {
-        challenge_block_words(wn, blob, cm, b + 1 < CH_BLOCKS ? b + 1 : b);     // next block's loads fly during the rounds
+        uint32_t w[16];
+        rd.words(w, b);
+        rd.prefetch(b + 1);                          // next sector's loads fly during the rounds
         uint32_t a = hh[0], bb = hh[1], c = hh[2], d = hh[3], e = hh[4], f = hh[5], g = hh[6], h = hh[7];
 #pragma unroll
         for (int t = 0; t < 64; t++) {
@@ -180,8 +192,6 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
             h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
         }
         hh[0] += a; hh[1] += bb; hh[2] += c; hh[3] += d; hh[4] += e; hh[5] += f; hh[6] += g; hh[7] += h;
-#pragma unroll
-        for (int k = 0; k < 16; k++) w[k] = wn[k];
     }
     if (i_raw >= n_total) return;
     challenge_finish(hh, i, cm, proofs, z_out, records);
