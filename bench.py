@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=1024,
+    ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=2048,
                     help="independent 64-blob batches verified by one step (one launch set)")
     ap.add_argument("--op", choices=["verify", "commit", "proof"], default="verify",
                     help="verify = the headline metric; commit / proof = secondary single-GPU metrics (BASELINE.json configs[1], [2])")

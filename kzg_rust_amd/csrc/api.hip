@@ -81,7 +81,7 @@ struct Workspace {
 struct kzg355_settings {
     int device = 0;
     DeviceTables t{};
-    DevBuf roots, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
+    DevBuf roots, eval_tab, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
@@ -365,6 +365,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     int rc = KZG355_OK;
     auto fail = [&](int code) { g1b.release(); g2b.release(); err.release(); kzg355_free_trusted_setup(s); return code; };
     if ((rc = s->roots.ensure(sizeof(Fr) * N_FE))) return fail(rc);
+    if ((rc = s->eval_tab.ensure(sizeof(EvalGroupTab) * (N_FE / 4)))) return fail(rc);
     if ((rc = s->msm_table.ensure(sizeof(G1Affine) * (size_t)N_FE * MSM_WINDOWS))) return fail(rc);
     if ((rc = s->lines.ensure(sizeof(LineCoeff) * 3 * N_LINES))) return fail(rc);
     if ((rc = s->lines_inf.ensure(sizeof(int) * 3))) return fail(rc);
@@ -375,6 +376,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     if ((rc = g2b.ensure(96 * n2))) return fail(rc);
     if ((rc = err.ensure(sizeof(int)))) return fail(rc);
     s->t.roots = s->roots.as<Fr>();
+    s->t.eval_tab = s->eval_tab.as<EvalGroupTab>();
     s->t.msm_table = s->msm_table.as<G1Affine>();
     s->t.lines = s->lines.as<LineCoeff>();
     s->t.lines_inf = s->lines_inf.as<int>();
@@ -462,7 +464,7 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     hipSetDevice(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
-    s->roots.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
+    s->roots.release(); s->eval_tab.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
 }

@@ -72,6 +72,17 @@ __global__ void __launch_bounds__(256) k_setup_roots(Fr *roots) {
     roots[brp12((uint32_t)i)] = acc;
 }
 
+// Per group of four domain points (positions 4k..4k+3 = w, -w, iw, -iw): w^-1 and w^4 for k_eval (eval_core.h).
+__global__ void __launch_bounds__(256) k_setup_eval_tab(const Fr *roots, EvalGroupTab *tab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N_FE / 4) return;
+    const Fr w = roots[4 * k];
+    EvalGroupTab g;
+    fr_inv(g.inv_root, w);
+    fr_sqr(g.rho, w); fr_sqr(g.rho, g.rho);
+    tab[k] = g;
+}
+
 // Fixed-base precomputation: table[w][i] = 2^(8w) * g1_values[i] in affine form, w = 1..31 (window 0 is g1_values).
 // One thread per point; 8 doublings + one inversion per window.
 __global__ void __launch_bounds__(64) k_setup_msm_table(G1Affine *table) {
@@ -94,6 +105,7 @@ void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTa
     hipLaunchKernelGGL(k_setup_lines, dim3(1), dim3(64), 0, st, d_g2_first2, t.lines, t.lines_inf);
     hipLaunchKernelGGL(k_setup_lagrange_check, dim3(1), dim3(64), 0, st, t.g1_first2, t.lines, t.lines_inf, d_err);
     hipLaunchKernelGGL(k_setup_roots, dim3(N_FE / 256), dim3(256), 0, st, t.roots);
+    hipLaunchKernelGGL(k_setup_eval_tab, dim3(N_FE / 4 / 256), dim3(256), 0, st, t.roots, t.eval_tab);
     hipLaunchKernelGGL(k_setup_msm_table, dim3(N_FE / 64), dim3(64), 0, st, t.msm_table);
     hipStreamSynchronize(st);
     hipFree(d_g2_first2);

@@ -203,38 +203,63 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
 // cases z == w_i.  Because  prod_j (z - w_j) = z^N - 1,  the same value is
 //         y = (1/N) * sum_i  p_i w_i * prod_{j != i} (z - w_j)
 // which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m).
-// One wave per blob, 64 elements per lane, no LDS and no barrier.  A lane folds its elements into the pair
-//     P = prod_k d_k ,  S = sum_k p_k w_k prod_{j != k} d_j          (d = z - w)
-// by  S <- S d + (p w) P ,  P <- P d   -- 3.5 product-equivalents per element (the two products of S share one reduction),
-// and the wave combines the 64 pairs as  sum_l S_l prod_{m != l} P_m  with one "product of all the others" scan.
-// z inside the domain needs no special case: with d_m = 0 every term but the m-th vanishes and
-// (1/N) p_m w_m prod_{j != m}(w_m - w_j) = p_m, which is what kzg.rs:360-362 returns.
-// Domains: z, w, d, P in Montgomery form; the blob element enters as a plain integer, so p w, S and y are plain: y comes
-// out as the canonical integer with no conversion.  Intermediate products are lazy (< 1.1 r), the last ones canonical.
-__global__ void __launch_bounds__(64, 4) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, int n_per_group, Fr *y_out,
-                                                 uint8_t *records, int *err) {
+// One wave per blob, no LDS and no barrier.  The arithmetic is eval_core.h: the domain is taken four points at a time
+// (w, -w, iw, -iw are the roots of x^4 = w^4), a lane folds its 16 groups into the pair
+//     P = prod_k D_k ,  S = sum_k N_k prod_{l != k} D_l        (D_k = z^4 - w_k^4, N_k the group's numerator)
+// at 8.5 product-equivalents per group, and the wave combines the 64 pairs as  sum_l S_l prod_{m != l} P_m  with one
+// "product of all the others" scan.  Group k = it*64 + lane: a lane reads 128 contiguous bytes, a wave 8 KiB.
+// z inside the domain needs no special case (for z = w_m every term but the m-th vanishes and the m-th equals N p_m,
+// which is what kzg.rs:360-362 returns).  y comes out as the canonical integer with no conversion.
+// Loads: a lane needs the 128 contiguous bytes of its group, but a load instruction whose lanes are 128 bytes apart touches 64
+// cache lines for 1 KiB.  The wave instead moves its 8 KiB per step with 8 fully coalesced global -> LDS loads
+// (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~2,800 instructions
+// without costing registers -- staging it in VGPRs spilled to scratch, and waiting for a scratch reload waits for every older
+// load too: 59 % of the wave cycles were s_waitcnt).  The LDS side of such a load is linear (lane L of instruction q lands in
+// slot 64 q + L), so the bank-spreading XOR is applied on the global side: slot 8 g + s receives chunk 8 g + (s ^ (g & 7)) of
+// the tile (still the same 1 KiB per instruction), and lane g reads its part j back from slot 8 g + (j ^ (g & 7)).
+__device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, uint4 *tile, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int g = 8 * q + (lane >> 3), s = lane & 7;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(blob_step + 8 * g + (s ^ (g & 7))),
+                                         (void __attribute__((address_space(3))) *)(tile + 64 * q), 16, 0, 0);
+    }
+}
+__global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, const EvalGroupTab *tab, int n_per_group,
+                                                 Fr *y_out, uint8_t *records, int *err) {
+    __shared__ uint4 tile[512];
     const int blob_i = blockIdx.x, lane = threadIdx.x;
-    const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
+    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob_i);
+    eval_issue_tile_loads(blob, tile, lane);
     const Fr z = z_in[blob_i];
+    const Fr imag = roots[2];                                     // position 2 holds w^(N/4)
+    Fr z4; fr_sqr(z4, z); fr_sqr(z4, z4);
     Fr P, S;
     bool bad = false;
-    uint32_t w[8]; Fr root;
-    load_blob_element_words(w, blob, lane); root = roots[lane];
+    constexpr int STEPS = N_FE / 4 / 64;
+    EvalGroupTab gn = tab[lane];
 #pragma unroll 1
-    for (int k = 0; k < 64; k++) {
-        uint32_t wn[8]; Fr rootn;
-        const int en = (k < 63 ? k + 1 : k) * 64 + lane;          // next element's loads fly during this one's products
-        load_blob_element_words(wn, blob, en); rootn = roots[en];
-        bad = bad || !fr_words_canonical(w);                      // bytes_to_bls_field (utils.rs:267-271)
-        Fr p, d, q;
-        words_to_limbs<NFR, 8>(p.l, w);
-        fr_sub(d, z, root);
-        fr_mul_lazy(q, p, root);                                  // p_i * w_i   (plain domain)
-        if (k == 0) { P = d; S = q; }
-        else { fr_mul2_lazy(S, S, d, q, P); fr_mul_lazy(P, P, d); }
+    for (int it = 0; it < STEPS; it++) {
+        __builtin_amdgcn_s_waitcnt(0);                            // this step's tile (and table entry) have landed
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint4 cur[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = wn[i];
-        root = rootn;
+        for (int j = 0; j < 8; j++) cur[j] = tile[8 * lane + (j ^ (lane & 7))];
+        const EvalGroupTab g = gn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();   // every lane has its 128 bytes
+        if (it + 1 < STEPS) {                                     // next step's loads fly during this one's products
+            eval_issue_tile_loads(blob + 512 * (it + 1), tile, lane);
+            gn = tab[(it + 1) * 64 + lane];
+        }
+        uint32_t pw[4][8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {                             // big-endian 32 bytes -> 8 little-endian words
+            const uint4 a = cur[2 * e], b = cur[2 * e + 1];
+            pw[e][7] = bswap32(a.x); pw[e][6] = bswap32(a.y); pw[e][5] = bswap32(a.z); pw[e][4] = bswap32(a.w);
+            pw[e][3] = bswap32(b.x); pw[e][2] = bswap32(b.y); pw[e][1] = bswap32(b.z); pw[e][0] = bswap32(b.w);
+            bad = bad || !fr_words_canonical(pw[e]);              // bytes_to_bls_field (utils.rs:267-271)
+        }
+        eval_fold_group4(P, S, it == 0, pw, z, z4, g, imag);
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
     Fr ex, tot;
@@ -342,7 +367,7 @@ void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, con
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, n_per_group, d_y, d_records, d_err);
+    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, t.eval_tab, n_per_group, d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st) {

@@ -10,6 +10,7 @@
 #include "pairing.h"
 #include "sha256.h"
 #include "pairing_coop.h"
+#include "eval_core.h"
 
 namespace kzg {
 
@@ -29,6 +30,7 @@ constexpr int ERR_SETUP_MONOMIAL = 8;      // is_trusted_setup_in_lagrange_form 
 
 struct DeviceTables {
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
+    EvalGroupTab *eval_tab;  // [1024] per group of four domain points: w^-1, w^4 (eval_core.h)
     G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)
     LineCoeff *lines;        // [3][68]: Miller-loop lines of G2_GENERATOR, setup g2[0], setup g2[1]
     int *lines_inf;          // [3] 1 if that G2 point is the point at infinity

@@ -7,6 +7,7 @@
 #include "../../kzg_rust_amd/csrc/pairing.h"
 #include "../../kzg_rust_amd/csrc/sha256.h"
 #include "../../kzg_rust_amd/csrc/pairing_coop.h"
+#include "../../kzg_rust_amd/csrc/eval_core.h"
 #include <vector>
 using namespace kzg;
 extern "C" {
@@ -44,6 +45,37 @@ int hd_fr_mul2(uint8_t *out, const uint8_t *a, const uint8_t *b, const uint8_t *
     Fr l; fr_mul_lazy(l, r, fr_one());          // a lazy value fed to a lazy product ...
     fr_mul(r, l, fr_one());                     // ... and the canonical product that ends the chain
     fr_to_be32(out, r); return 0;
+}
+// y = p(z) through eval_core.h's group-of-four fold, all 1024 groups on one "lane" (the device spreads them over 64 lanes and
+// combines the pairs with a product scan; the fold itself is this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
+int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
+    constexpr int N_FE = 4096;
+    static Fr roots[N_FE]; static EvalGroupTab tab[N_FE / 4]; static bool ready = false;
+    if (!ready) {
+        const uint32_t rootc[NFR] = FR_ROOT4096_INIT;
+        Fr base; for (int k = 0; k < NFR; k++) base.l[k] = rootc[k];
+        Fr acc = fr_one();
+        for (int i = 0; i < N_FE; i++) {
+            uint32_t rev = 0; for (int b = 0; b < 12; b++) rev |= ((i >> b) & 1u) << (11 - b);
+            roots[rev] = acc; fr_mul(acc, acc, base);
+        }
+        for (int k = 0; k < N_FE / 4; k++) { fr_inv(tab[k].inv_root, roots[4 * k]); fr_sqr(tab[k].rho, roots[4 * k]); fr_sqr(tab[k].rho, tab[k].rho); }
+        ready = true;
+    }
+    uint32_t w[8]; be32_to_words(w, z_be);
+    Fr z, z4, P, S; fr_from_words(z, w);
+    fr_sqr(z4, z); fr_sqr(z4, z4);
+    for (int k = 0; k < N_FE / 4; k++) {
+        uint32_t pw[4][8];
+        for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * k + e)); if (!fr_words_canonical(pw[e])) return 1; }
+        eval_fold_group4(P, S, k == 0, pw, z, z4, tab[k], roots[2]);
+    }
+    const uint32_t inv4096[NFR] = FR_INV4096_INIT;
+    Fr k4096, y; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
+    fr_mul(y, S, k4096);                                     // S is plain, k4096 Montgomery: y plain and canonical
+    limbs_to_words<NFR, 8>(w, y.l);
+    for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8; out32[4 * i + 3] = v; }
+    return 0;
 }
 // 0 ok / 1 bad encoding / 2 not on curve / 3 not in subgroup ; out = recompressed point
 int hd_g1_validate(uint8_t *out, const uint8_t *in, int check_subgroup) {

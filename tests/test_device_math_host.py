@@ -190,3 +190,29 @@ def test_g2_decompress_and_pairing(hd, oracle, setup_bytes):
     # e([a]G, Q) == e([a]G, Q) (true) and e([a]G, Q) == e([a+1]G, Q) (false)
     a1G = oracle.g1_mul_add(G1_GEN, ((a + 1) % R).to_bytes(32, "big"))
     assert hd.hd_pairings_verify(C.byref(ok), aG, q1, a1G, q1) == 0 and ok.value == 0
+
+
+def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_blobs):
+    """eval_core.h (what k_eval runs per lane) against the oracle's evaluate_polynomial_in_evaluation_form (kzg.rs:346-389):
+    random z, z = 0 / 1 / r-1, and z INSIDE the domain (first, second, last position and a middle one), where the reference
+    takes its special-case branch and the group fold relies on the polynomial identity instead."""
+    from synth import random_blob, random_field_element
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    w = pow(7, (R_ - 1) // 4096, R_)
+    brp = lambda i: int(format(i, "012b")[::-1], 2)
+    in_domain = [pow(w, brp(pos), R_) for pos in (0, 1, 2, 3, 4, 2049, 4095)]
+    zs = [random_field_element(100 + i) for i in range(4)] + [v.to_bytes(32, "big") for v in [0, 1, R_ - 1] + in_domain]
+    def valid(b):
+        try:
+            return len(b) == 131072 and bool(oracle.blob_to_kzg_commitment(b, oracle_settings))
+        except Exception:
+            return False
+    blobs = [random_blob(4242), next(b for b in golden_blobs if valid(b)), bytes(131072)]
+    out = C.create_string_buffer(32)
+    for blob in blobs:
+        for z in zs:
+            assert hd.hd_eval_poly(out, blob, z) == 0
+            _, y = oracle.compute_kzg_proof(blob, z, oracle_settings)
+            assert out.raw == y, z.hex()
+    bad = bytearray(blobs[0]); bad[32 * 77:32 * 78] = (R_).to_bytes(32, "big")
+    assert hd.hd_eval_poly(out, bytes(bad), zs[0]) == 1
