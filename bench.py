@@ -33,11 +33,12 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PATH_BYTES_PER_BLOB = 131072 + 131072 + 48 + 48
 KERNEL_BYTES_PER_BLOB = {
     "challenge": 16 + 16 + 131072 + 48 + 32,          # the 131,152-byte transcript in, z out
-    "eval": 131072 + 131072 + 32 + 32,                # blob + roots-of-unity sweep + z in, y out
+    "eval": 131072 + 1024 * 72 + 32 + 32,             # blob + the 1024-entry group table (w^-1, w^4) + z in, y out
     "validate_points": 96,
     "points_from_records": 96,
     "rpowers": 160 + 64,
     "lincomb": 2 * 112 + 64 + 2 * 112 / N_PER_BATCH,
+    "lincomb_prep": 2 * 112 + 64, "lincomb_horner": 2 * 33 * 168 / N_PER_BATCH,
     "pairing": (2 * 68 * 3 * 2 * 56 + 2 * 112) / N_PER_BATCH,   # two 68-line tables + two points per batch
 }
 KERNEL_BYTES_PER_BLOB.update({
@@ -196,7 +197,7 @@ def main():
         dom = max(stats, key=lambda f: stats[f][0])
         tot_ms, cnt = stats[dom]
         avg_s = tot_ms / cnt / 1e3
-        blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "pairing", "points_from_records") else blobs_total / cnt
+        blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "lincomb_prep", "lincomb_horner", "pairing", "points_from_records") else blobs_total / cnt
         if args.op != "verify":
             blobs_per_launch = Cc * n_local
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
@@ -238,7 +239,7 @@ def pmc_traffic(kernel_family, blobs_per_launch):
     MI355X_MICROARCH.md, WRITE_SIZE as is; separate passes, collected with this same bench command).  The counters are per
     blob there; scaled to this run's launch size.  None if no summary is committed for that kernel."""
     import glob
-    names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_prep", "k_lc_buckets", "k_lc_horner"],
+    names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets"], "lincomb_prep": ["k_lc_prep"], "lincomb_horner": ["k_lc_horner"],
              "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
              "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "quotient": ["k_quotient"]}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")))

@@ -192,9 +192,15 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     const bool buckets = npg >= 8 && npg <= 128 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
     if (buckets && (rc = w->lc_partials.ensure(lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
     if ((rc = join_side(w))) return rc;                           // the validated points are needed from here on
-    tm.begin("lincomb");
-    if (buckets) launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream);
-    else launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
+    if (buckets) {
+        static const char *names[3] = {"lincomb_prep", "lincomb", "lincomb_horner"};       // "lincomb" = the bucket kernel itself
+        for (int stage = 1; stage <= 3; stage++) {
+            if (stage > 1) tm.end();
+            tm.begin(names[stage - 1]);
+            launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream, stage);
+        }
+    } else tm.begin("lincomb");
+    if (!buckets) launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
     tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);

@@ -59,6 +59,12 @@ __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *recor
 //                     the wave (shuffles, no LDS) -> 2 partial points per wave
 //   k_lincomb_finish  one workgroup per batch: lane c sums the partials of class c and converts to affine (the two
 //                     inversions run side by side) -> (-proof_lincomb, rhs) for the pairing.
+__device__ __forceinline__ G1Jac g1_shfl_down8(const G1Jac &v, int delta) {      // within segments of 8 lanes
+    G1Jac r;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 8); r.y.l[i] = __shfl_down(v.y.l[i], delta, 8); r.z.l[i] = __shfl_down(v.z.l[i], delta, 8); }
+    return r;
+}
 __device__ __forceinline__ G1Jac g1_shfl_xor(const G1Jac &v, int mask) {
     G1Jac r;
 #pragma unroll
@@ -214,9 +220,15 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
             g1_add_mixed(acc, acc, p);
         }
     }
-    // b * acc (b <= 8: 4-bit double-and-add), then sum over the 8 buckets of the task
-    G1Jac r = g1_inf();
-    for (int bit = 3; bit >= 0; bit--) { g1_dbl(r, r); if ((b >> bit) & 1) g1_add(r, r, acc); }
+    // sum_b b * B_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} B_b: a 3-step suffix scan over the task's 8 lanes, then
+    // a 3-step butterfly -- 6 additions, no doublings
+    G1Jac r = acc;
+#pragma unroll 1
+    for (int off = 1; off < 8; off <<= 1) {
+        G1Jac o = g1_shfl_down8(r, off), t;
+        g1_add(t, r, o);
+        if ((lane & 7) + off < 8) r = t;
+    }
 #pragma unroll 1
     for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
     if (b == 1 && w < LC_WINDOWS) S[((size_t)g * 2 + cls) * LC_WINDOWS + w] = r;
@@ -257,16 +269,16 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
     hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
 }
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st) {
+                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st, int stage) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
     G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * groups);
     const int nt = 3 * n_per_group + 1;
-    hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S);
-    hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
+    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S);
+    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;

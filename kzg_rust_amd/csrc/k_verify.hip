@@ -34,17 +34,22 @@ __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { r
 
 constexpr int CH_BLOCKS = 2050;
 // The hashed message puts the blob at offset 32, so compression b covers blob[64b-32, 64b+32): every block straddles two
-// aligned 64-byte sectors of the blob.  Reading "the block's 64 bytes" touches each sector twice (two blocks apart in time:
-// at full-card sizes the second touch misses and HBM fetches double -- 281 KB per 131 KB blob by FETCH_SIZE).  The reader below
-// loads each ALIGNED sector once, one block ahead, uses its lower half now and carries its upper half to the next block.
+// aligned 64-byte sectors of the blob.  Reading "the block's 64 bytes" touches each sector twice, two blocks apart in time, and
+// even aligned 64-byte reads leave the other half of each 128-byte line to a later block: at full-card sizes those second
+// touches miss (FETCH_SIZE: 281 KB, then 191 KB, per 131 KB blob).  The reader below loads each 128-byte LINE once (every
+// second block, one block ahead), uses the lower half of the current sector now and carries its upper half to the next block.
 struct ChallengeReader {
     const uint4 *blob; const uint8_t *cm;
-    uint4 nxt[4];            // sector b (blob[64b, 64b+64)), loaded by prefetch(b)
+    uint4 line[8];           // blob[128 l, 128 l + 128) for l = b >> 1, loaded by prefetch(b) with b even
     uint32_t carry[8];       // upper half of sector b-1, big-endian words
     __device__ __forceinline__ void prefetch(int b) {
-        if (b < 2048) { const uint4 *p = blob + 4 * b; nxt[0] = p[0]; nxt[1] = p[1]; nxt[2] = p[2]; nxt[3] = p[3]; }
+        if (b < 2048 && !(b & 1)) {
+            const uint4 *p = blob + 4 * b;
+#pragma unroll
+            for (int q = 0; q < 8; q++) line[q] = p[q];
+        }
     }
-    // words of compression b; prefetch(b) must have run.  Leaves carry ready for b + 1.
+    // words of compression b; prefetch(b) must have run (and no later prefetch).  Leaves carry ready for b + 1.
     __device__ __forceinline__ void words(uint32_t w[16], int b) {
         if (b == 0) {                                   // domain | u64be(0) | u64be(4096)
             w[0] = 0x4653424cu; w[1] = 0x4f425645u; w[2] = 0x52494659u; w[3] = 0x5f56315fu;   // "FSBLOBVERIFY_V1_"
@@ -54,10 +59,13 @@ struct ChallengeReader {
             for (int k = 0; k < 8; k++) w[k] = carry[k];
         }
         if (b < 2048) {
-            w[8] = bswap32(nxt[0].x); w[9] = bswap32(nxt[0].y); w[10] = bswap32(nxt[0].z); w[11] = bswap32(nxt[0].w);
-            w[12] = bswap32(nxt[1].x); w[13] = bswap32(nxt[1].y); w[14] = bswap32(nxt[1].z); w[15] = bswap32(nxt[1].w);
-            carry[0] = bswap32(nxt[2].x); carry[1] = bswap32(nxt[2].y); carry[2] = bswap32(nxt[2].z); carry[3] = bswap32(nxt[2].w);
-            carry[4] = bswap32(nxt[3].x); carry[5] = bswap32(nxt[3].y); carry[6] = bswap32(nxt[3].z); carry[7] = bswap32(nxt[3].w);
+            uint4 s0, s1, s2, s3;                       // sector b = half (b & 1) of the line
+            if (b & 1) { s0 = line[4]; s1 = line[5]; s2 = line[6]; s3 = line[7]; }
+            else { s0 = line[0]; s1 = line[1]; s2 = line[2]; s3 = line[3]; }
+            w[8] = bswap32(s0.x); w[9] = bswap32(s0.y); w[10] = bswap32(s0.z); w[11] = bswap32(s0.w);
+            w[12] = bswap32(s1.x); w[13] = bswap32(s1.y); w[14] = bswap32(s1.z); w[15] = bswap32(s1.w);
+            carry[0] = bswap32(s2.x); carry[1] = bswap32(s2.y); carry[2] = bswap32(s2.z); carry[3] = bswap32(s2.w);
+            carry[4] = bswap32(s3.x); carry[5] = bswap32(s3.y); carry[6] = bswap32(s3.z); carry[7] = bswap32(s3.w);
         } else if (b == 2048) {                         // ... | commitment[0..32)
             for (int k = 0; k < 8; k++) w[8 + k] = load_be32(cm + 4 * k);
         } else {                                        // commitment[32..48) | 0x80 | zeros | bit length
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
 // load too: 59 % of the wave cycles were s_waitcnt).  The LDS side of such a load is linear (lane L of instruction q lands in
 // slot 64 q + L), so the bank-spreading XOR is applied on the global side: slot 8 g + s receives chunk 8 g + (s ^ (g & 7)) of
 // the tile (still the same 1 KiB per instruction), and lane g reads its part j back from slot 8 g + (j ^ (g & 7)).
+constexpr uint32_t FR_MOD_TOP_WORD = 0x73eda753u;    // r = 0x73eda753 299d7d48 ...
 __device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, uint4 *tile, int lane) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -257,7 +266,12 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
             const uint4 a = cur[2 * e], b = cur[2 * e + 1];
             pw[e][7] = bswap32(a.x); pw[e][6] = bswap32(a.y); pw[e][5] = bswap32(a.z); pw[e][4] = bswap32(a.w);
             pw[e][3] = bswap32(b.x); pw[e][2] = bswap32(b.y); pw[e][1] = bswap32(b.z); pw[e][0] = bswap32(b.w);
-            bad = bad || !fr_words_canonical(pw[e]);              // bytes_to_bls_field (utils.rs:267-271)
+        }
+        // bytes_to_bls_field (utils.rs:267-271): value < r.  The top word settles it unless it EQUALS r's top word.
+        const uint32_t top = max(max(pw[0][7], pw[1][7]), max(pw[2][7], pw[3][7]));
+        if (top >= FR_MOD_TOP_WORD) {
+#pragma unroll 1
+            for (int e = 0; e < 4; e++) bad = bad || !fr_words_canonical(pw[e]);
         }
         eval_fold_group4(P, S, it == 0, pw, z, z4, g, imag);
     }

@@ -65,7 +65,8 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
 size_t lincomb_partials_bytes(int n_per_group, int groups);
 // bucket-method (Pippenger) form of the same sums, for many batches in flight; requires n_per_group <= 128
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                            int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, G1Affine *d_pair_pts, hipStream_t st);
+                            int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, G1Affine *d_pair_pts, hipStream_t st,
+                            int stage = 0 /* 0: all three kernels; 1 prep, 2 buckets, 3 horner (per-kernel timing) */);
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups);
 void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
