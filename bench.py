@@ -43,6 +43,7 @@ KERNEL_BYTES_PER_BLOB = {
 }
 KERNEL_BYTES_PER_BLOB.update({
     "msm_bucket": 4096 * (96 + 32) + 48,              # SURVEY 8(d) B_commit: affine G1 sweep + scalars + output
+    "msm_wide": 22 * 4096 * 128 + 131072,             # one 128-byte table row per (window, scalar) + the scalars
     "msm_finalize": 32 * 168 + 48,
     "digits": 131072 + 131072,
     "quotient": 131072 + 131072 + 147456,
@@ -241,13 +242,13 @@ def pmc_traffic(kernel_family, blobs_per_launch):
     import glob
     names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets"], "lincomb_prep": ["k_lc_prep"], "lincomb_horner": ["k_lc_horner"],
              "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
-             "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "quotient": ["k_quotient"]}
+             "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"]}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")))
     if not files or kernel_family not in names:
         return None, None
     per = json.load(open(files[-1]))["per_kernel"]
     ds = [per[k] for k in names[kernel_family] if k in per]
-    if kernel_family in ("challenge", "msm_bucket"):
+    if kernel_family in ("challenge", "msm_bucket", "msm_wide"):
         ds = ds[:1]                                              # alternative forms of one kernel, not a sequence
     if not ds:
         return None, None

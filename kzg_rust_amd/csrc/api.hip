@@ -81,7 +81,7 @@ struct Workspace {
 struct kzg355_settings {
     int device = 0;
     DeviceTables t{};
-    DevBuf roots, eval_tab, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
+    DevBuf roots, eval_tab, wide, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
@@ -264,16 +264,26 @@ int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes)
     return KZG355_OK;
 }
 
-// MSM over digits already on the device -> 48-byte outputs on the host
-int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, uint8_t *out_host) {
+// MSM -> 48-byte outputs on the host.  Wide-window table form if the handle has the table (scalars straight from the blobs,
+// or from Montgomery field elements for the quotient), else the 8-bit bucket form over a digit buffer.
+int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_t *d_blobs, const Fr *d_scalars) {
     int rc;
     if ((rc = w->partials.ensure(sizeof(G1Jac) * (size_t)n * MSM_WINDOWS))) return rc;
     if ((rc = w->out48.ensure(48 * (size_t)n))) return rc;
     if ((rc = w->h_out.ensure(48 * (size_t)n))) return rc;
-    tm.begin("msm_bucket"); launch_msm_bucket(w->digits.as<uint8_t>(), s->t, n, w->partials.as<G1Jac>(), w->stream); tm.end();
-    tm.begin("msm_finalize"); launch_msm_finalize(w->partials.as<G1Jac>(), n, w->out48.as<uint8_t>(), w->stream); tm.end();
+    if (s->t.wide_table) {
+        tm.begin("msm_wide"); launch_msm_wide(d_blobs, d_scalars, s->t, n, w->partials.as<G1Jac>(), w->err.as<int>(), w->stream); tm.end();
+        tm.begin("msm_finalize"); launch_msm_finalize(w->partials.as<G1Jac>(), n, w->out48.as<uint8_t>(), w->stream, msm_wide_partials_per_blob(n)); tm.end();
+    } else {
+        if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
+        tm.begin("digits");
+        if (d_scalars) launch_digits_from_fr(d_scalars, n, w->digits.as<uint8_t>(), w->stream);
+        else launch_digits_from_blobs(d_blobs, n, w->digits.as<uint8_t>(), w->err.as<int>(), w->stream);
+        tm.end();
+        tm.begin("msm_bucket"); launch_msm_bucket(w->digits.as<uint8_t>(), s->t, n, w->partials.as<G1Jac>(), w->stream); tm.end();
+        tm.begin("msm_finalize"); launch_msm_finalize(w->partials.as<G1Jac>(), n, w->out48.as<uint8_t>(), w->stream); tm.end();
+    }
     HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 48 * (size_t)n, hipMemcpyDeviceToHost, w->stream));
-    (void)out_host;
     return KZG355_OK;
 }
 
@@ -285,13 +295,11 @@ int commit_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, s
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
     int rc;
-    if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
     if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
     Timed tm(s, w);
-    tm.begin("digits"); launch_digits_from_blobs(d_blobs, (int)n, w->digits.as<uint8_t>(), w->err.as<int>(), w->stream); tm.end();
-    if ((rc = msm_to_host(s, w, tm, (int)n, out))) return rc;
+    if ((rc = msm_to_host(s, w, tm, (int)n, d_blobs, nullptr))) return rc;
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
     tm.collect();
@@ -310,10 +318,8 @@ int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_b
     int rc;
     if ((rc = w->y.ensure(sizeof(Fr) * (size_t)n))) return rc;
     if ((rc = w->q.ensure(sizeof(Fr) * (size_t)n * N_FE))) return rc;
-    if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
     tm.begin("quotient"); launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<Fr>(), w->err.as<int>(), w->stream); tm.end();
-    tm.begin("digits"); launch_digits_from_fr(w->q.as<Fr>(), n, w->digits.as<uint8_t>(), w->stream); tm.end();
-    return msm_to_host(s, w, tm, n, nullptr);
+    return msm_to_host(s, w, tm, n, nullptr, w->q.as<Fr>());
 }
 
 int blob_proof_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs) {
@@ -421,6 +427,16 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
     g1b.release(); g2b.release(); err.release();
+    {   // the 23.6 GB wide-window MSM table (KZG355_MSM=bucket keeps the 15 MB 8-bit form only; so does a failed allocation)
+        const char *e = getenv("KZG355_MSM");
+        if (!(e && strcmp(e, "bucket") == 0)) {
+            if (s->wide.ensure(wide_table_bytes()) == KZG355_OK) {
+                s->t.wide_table = s->wide.as<WideRow>();
+                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; } }
+            } else if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; }
+            (void)hipGetLastError();
+        }
+    }
     *out = s;
     return KZG355_OK;
 }
@@ -470,7 +486,7 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     hipSetDevice(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
-    s->roots.release(); s->eval_tab.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
+    s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
 }

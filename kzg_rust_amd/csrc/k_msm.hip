@@ -228,9 +228,9 @@ void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_
     if (wpb == 1) hipLaunchKernelGGL(k_msm_bucket<1>, dim3(n * MSM_WINDOWS), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials, 1);
     else hipLaunchKernelGGL(k_msm_bucket<4>, dim3(n * (MSM_WINDOWS / wpb)), dim3(MSM_THREADS), 0, st, d_digits, t.msm_table, d_partials, wpb);
 }
-void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48, hipStream_t st) {
+void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48, hipStream_t st, int ppb) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_msm_finalize, dim3(n), dim3(64), 0, st, d_partials, d_out48, MSM_WINDOWS / msm_windows_per_block(n));
+    hipLaunchKernelGGL(k_msm_finalize, dim3(n), dim3(64), 0, st, d_partials, d_out48, ppb > 0 ? ppb : MSM_WINDOWS / msm_windows_per_block(n));
 }
 
 }  // namespace kzg

@@ -1,0 +1,190 @@
+// k_msm_wide.hip -- the fixed-base MSM of blob_to_kzg_commitment / compute_*_proof (reference src/utils.rs:367-410
+// g1_lincomb_fast -> blst_p1s_mult_pippenger over the 4096 trusted-setup points; called from src/kzg.rs:397 and :524) with
+// the table sized for an MI355X's 288 GB of HBM instead of a CPU cache:
+//
+//     wide[w][i][m-1] = m * 2^(12 w) * g1_values[i]        w < 22,  i < 4096,  m = 1..2048       (affine, 128-byte rows)
+//
+// = 22 x 4096 x 2048 x 128 B = 23.6 GB, built once by load_trusted_setup.  With signed 12-bit digits d_w in [-2048, 2047]
+//     sum_i s_i P_i = sum_i sum_w sign(d_{w,i}) * wide[w][i][|d_{w,i}| - 1]
+// is a plain sum of 22 x 4096 = 90,112 table rows per blob: no buckets, no doublings, no sorting, no digit buffer -- one
+// 128-byte gather and one mixed addition per row (the 8-bit bucket form in k_msm.hip needs 131,072 additions plus 32 bucket
+// reductions per blob and a 131 KB digit pass).  ~11.5 MB of random 128-byte HBM reads per blob.
+//   k_wide_base / k_wide_rows   setup: row 1 from the 8-bit table (k_setup.hip), then the 2048 multiples in 8 segments of
+//                               256 per (w, i): Jacobian run + in-lane batch inversion (one divstep inversion per 256 rows)
+//   k_msm_wide                  one 256-thread workgroup per (blob, part): lane = scalars i = l, l+256, ...; recodes its scalar
+//                               in registers (canonical check fused), walks the windows with the next row's gather in
+//                               flight, then shuffle butterfly + LDS sum of the workgroup
+// The result is the same group element blst's Pippenger returns, hence the same 48 bytes (utils.rs:221-227).
+#define KZG_MID_INLINE 1
+#include "kernels.h"
+#include "fr_block.h"
+
+namespace kzg {
+
+static_assert(sizeof(WideRow) == 128, "one table row per 128-byte line");
+
+__device__ __forceinline__ G1Jac g1_shfl_xor_w(const G1Jac &v, int mask) {
+    G1Jac r;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask, 64); }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ setup
+// row 1 of every (w, i): 2^(12 w) P_i = 2^r * table8[(12 w) >> 3][i], r = (12 w) & 7 in {0, 4}
+__global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRow *wide, int w_lo, int w_n) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= w_n * N_FE) return;
+    const int w = w_lo + id / N_FE, i = id % N_FE;
+    const int bits = WIDE_BITS * w, w8 = bits >> 3, r = bits & 7;
+    G1Affine q = table8[(size_t)w8 * N_FE + i];
+    if (r) {
+        G1Jac j; g1_from_affine(j, q);
+        for (int k = 0; k < r; k++) g1_dbl(j, j);
+        g1_to_affine(q, j);
+    }
+    WideRow row; row.x = q.x; row.y = q.y;
+    for (int k = 0; k < 4; k++) row.pad[k] = 0;
+    wide[((size_t)w * N_FE + i) * WIDE_ROWS] = row;
+}
+// rows m = 256 seg + 1 .. 256 seg + 256 of (w, i), one lane per (w, i, seg):  Jacobian run acc += Q (parked in `jac`, with
+// the running product of the z's in `pre`), ONE inversion, then backwards: z_k^-1 = inv * pre_{k-1}, inv *= z_k.
+constexpr int WIDE_SEG = 256;
+__global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp *pre, int w_lo, int w_n) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int SEGS = WIDE_ROWS / WIDE_SEG;
+    if (id >= w_n * N_FE * SEGS) return;
+    const int seg = id % SEGS, pi = id / SEGS;
+    const int w = w_lo + pi / N_FE, i = pi % N_FE;
+    WideRow *rows = wide + ((size_t)w * N_FE + i) * WIDE_ROWS;
+    G1Affine q; q.x = rows[0].x; q.y = rows[0].y;
+    G1Jac *myj = jac + (size_t)id * WIDE_SEG;
+    Fp *myp = pre + (size_t)id * WIDE_SEG;
+    // acc = (256 seg) Q
+    G1Jac acc = g1_inf();
+    if (seg) {
+        G1Jac b; g1_from_affine(b, q);
+        for (int k = 0; k < 8; k++) g1_dbl(b, b);                 // 256 Q
+        for (int bit = 2; bit >= 0; bit--) { g1_dbl(acc, acc); if ((seg >> bit) & 1) g1_add(acc, acc, b); }
+    }
+    Fp run = fp_one();
+    for (int k = 0; k < WIDE_SEG; k++) {
+        g1_add_mixed(acc, acc, q);
+        myj[k] = acc;
+        if (!fp_is_zero(acc.z)) fp_mul(run, run, acc.z);          // infinity (only if P_i is) does not enter the product
+        myp[k] = run;
+    }
+    Fp inv; fp_inv(inv, run);
+    for (int k = WIDE_SEG - 1; k >= 0; k--) {
+        const G1Jac p = myj[k];
+        WideRow row;
+        for (int t = 0; t < 4; t++) row.pad[t] = 0;
+        if (fp_is_zero(p.z)) { row.x = fp_zero(); row.y = fp_zero(); }
+        else {
+            Fp zi, zi2, zi3;
+            if (k) fp_mul(zi, inv, myp[k - 1]); else zi = inv;
+            fp_mul(inv, inv, p.z);
+            fp_sqr(zi2, zi); fp_mul(zi3, zi2, zi);
+            fp_mul(row.x, p.x, zi2); fp_mul(row.y, p.y, zi3);
+        }
+        const int m = WIDE_SEG * seg + k;                         // row index m holds (m + 1) Q
+        if (m) rows[m] = row;                                     // row 0 is Q itself (k_wide_base)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the MSM
+// signed 12-bit digits of a 256-bit integer (8 little-endian words): d_w in [-2048, 2047], top digit small and >= 0
+__device__ __forceinline__ int wide_raw_digit(const uint32_t s[8], int w) {
+    const int bit = WIDE_BITS * w, wi = bit >> 5, sh = bit & 31;
+    uint32_t v = s[wi] >> sh;
+    if (sh > 32 - WIDE_BITS && wi + 1 < 8) v |= s[wi + 1] << (32 - sh);
+    return (int)(v & ((1u << WIDE_BITS) - 1));
+}
+
+template <bool FROM_FR>
+__global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr *scalars, const WideRow *wide, G1Jac *partials, int *err,
+                                                   int spl /* scalars per lane */, int parts /* window parts */) {
+    __shared__ G1Jac red[4];
+    const int chunks = N_FE / (256 * spl), wgpb = chunks * parts;
+    const int blob = blockIdx.x / wgpb, wg = blockIdx.x % wgpb, chunk = wg / parts, part = wg % parts;
+    const int tid = threadIdx.x;
+    const int w_lo = (WIDE_WINDOWS * part) / parts, w_hi = (WIDE_WINDOWS * (part + 1)) / parts;
+    G1Jac acc = g1_inf();
+    WideRow cur; bool have = false; bool cur_neg = false;
+    bool bad = false;
+#pragma unroll 1
+    for (int k = 0; k < spl; k++) {
+        const int i = chunk * 256 * spl + k * 256 + tid;
+        uint32_t s[8];
+        if (FROM_FR) fr_to_words(s, scalars[(size_t)blob * N_FE + i]);
+        else { load_blob_element_words(s, blobs + (size_t)BLOB_BYTES * blob, i); bad = bad || !fr_words_canonical(s); }
+        int carry = 0;
+        for (int w = 0; w < w_lo; w++) { const int raw = wide_raw_digit(s, w) + carry; carry = raw > 2047; }
+#pragma unroll 1
+        for (int w = w_lo; w < w_hi; w++) {
+            int d = wide_raw_digit(s, w) + carry;
+            carry = (w < WIDE_WINDOWS - 1) && d > 2047;
+            if (carry) d -= 4096;
+            if (d == 0) continue;
+            const int m = d < 0 ? -d : d;
+            const WideRow nxt = wide[((size_t)w * N_FE + i) * WIDE_ROWS + (m - 1)];      // in flight during the addition below
+            if (have) {
+                G1Affine p; p.x = cur.x; p.y = cur.y;
+                if (cur_neg) fp_neg(p.y, p.y);
+                g1_add_mixed(acc, acc, p);
+            }
+            cur = nxt; cur_neg = d < 0; have = true;
+        }
+    }
+    if (have) {
+        G1Affine p; p.x = cur.x; p.y = cur.y;
+        if (cur_neg) fp_neg(p.y, p.y);
+        g1_add_mixed(acc, acc, p);
+    }
+    if (!FROM_FR && bad && part == 0) atomicOr(&err[blob], ERR_NONCANONICAL_FR);          // blob_to_polynomial (kzg.rs:282-291)
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        G1Jac t = red[0];
+        for (int q = 1; q < 4; q++) { G1Jac o = red[q]; g1_add(t, t, o); }
+        partials[(size_t)blob * wgpb + wg] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+size_t wide_table_bytes() { return sizeof(WideRow) * (size_t)WIDE_WINDOWS * N_FE * WIDE_ROWS; }
+// Builds the table two windows at a time (scratch: 2 x 4096 x 2048 Jacobian points + z products = 3.8 GB, freed afterwards).
+int build_wide_table(DeviceTables t, hipStream_t st) {
+    constexpr int SLAB = 2;
+    const size_t runs = (size_t)SLAB * N_FE * (WIDE_ROWS / WIDE_SEG);
+    G1Jac *jac = nullptr; Fp *pre = nullptr;
+    if (hipMalloc(&jac, sizeof(G1Jac) * runs * WIDE_SEG) != hipSuccess) return 1;
+    if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { hipFree(jac); return 1; }
+    for (int w = 0; w < WIDE_WINDOWS; w += SLAB) {
+        const int wn = w + SLAB <= WIDE_WINDOWS ? SLAB : WIDE_WINDOWS - w;
+        hipLaunchKernelGGL(k_wide_base, dim3((wn * N_FE + 63) / 64), dim3(64), 0, st, t.msm_table, t.wide_table, w, wn);
+        hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((wn * N_FE * (WIDE_ROWS / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, t.wide_table, jac, pre, w, wn);
+    }
+    const hipError_t e = hipStreamSynchronize(st);
+    hipFree(jac); hipFree(pre);
+    return e == hipSuccess && hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// scalars per lane / window parts for n blobs: one workgroup per blob once the card is full, 32 per blob for a lone blob
+void msm_wide_shape(int n, int *spl, int *parts) {
+    if (n >= 1024) { *spl = 16; *parts = 1; }
+    else if (n >= 128) { *spl = 4; *parts = 1; }
+    else if (n >= 16) { *spl = 1; *parts = 1; }
+    else { *spl = 1; *parts = 2; }
+}
+int msm_wide_partials_per_blob(int n) { int spl, parts; msm_wide_shape(n, &spl, &parts); return N_FE / (256 * spl) * parts; }
+void launch_msm_wide(const uint8_t *d_blobs, const Fr *d_scalars, DeviceTables t, int n, G1Jac *d_partials, int *d_err, hipStream_t st) {
+    if (n <= 0) return;
+    int spl, parts; msm_wide_shape(n, &spl, &parts);
+    const int wgpb = N_FE / (256 * spl) * parts;
+    if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, d_partials, d_err, spl, parts);
+    else hipLaunchKernelGGL(k_msm_wide<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, d_partials, d_err, spl, parts);
+}
+
+}  // namespace kzg

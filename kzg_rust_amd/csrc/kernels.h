@@ -20,6 +20,10 @@ constexpr int RECORD_BYTES = 160;          // C | z | y | proof  (utils.rs:454-4
 constexpr int MSM_WINDOW_BITS = 8;
 constexpr int MSM_WINDOWS = 32;            // 32 x 8 bits cover the 255-bit scalars
 constexpr int MSM_BUCKETS = 128;           // signed digits in [-127, 128]
+// wide-window form of the same MSM (k_msm_wide.hip): 22 signed 12-bit digits, every multiple 1..2048 tabulated
+constexpr int WIDE_BITS = 12;
+constexpr int WIDE_WINDOWS = 22;
+constexpr int WIDE_ROWS = 2048;
 constexpr int N_G2 = 65;
 
 // error bits accumulated on the device; any bit => the call returns Err (reference: `?` on each step)
@@ -28,9 +32,12 @@ constexpr int ERR_NONCANONICAL_FR = 2;     // bytes_to_bls_field failed (utils.r
 constexpr int ERR_SETUP_POINT = 4;         // load_trusted_setup: bad g1/g2 bytes (kzg.rs:863, 878)
 constexpr int ERR_SETUP_MONOMIAL = 8;      // is_trusted_setup_in_lagrange_form (kzg.rs:823-826)
 
+struct alignas(128) WideRow { Fp x, y; uint32_t pad[4]; };       // one affine point per 128-byte line
+
 struct DeviceTables {
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
     EvalGroupTab *eval_tab;  // [1024] per group of four domain points: w^-1, w^4 (eval_core.h)
+    WideRow *wide_table;        // [22][4096][2048] multiples m * 2^(12w) * g1_values[i], 23.6 GB; null: 8-bit bucket form only
     G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)
     LineCoeff *lines;        // [3][68]: Miller-loop lines of G2_GENERATOR, setup g2[0], setup g2[1]
     int *lines_inf;          // [3] 1 if that G2 point is the point at infinity
@@ -74,11 +81,18 @@ void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups,
 // ---- k_pairing.hip
 void launch_lines_to_w(DeviceTables t, hipStream_t st);
 
+// ---- k_msm_wide.hip
+size_t wide_table_bytes();
+int build_wide_table(DeviceTables t, hipStream_t st);                 // needs t.msm_table; 0 on success
+int msm_wide_partials_per_blob(int n);
+// scalars from blobs (canonical check fused, err per blob) or, if d_scalars != null, from Montgomery field elements
+void launch_msm_wide(const uint8_t *d_blobs, const Fr *d_scalars, DeviceTables t, int n, G1Jac *d_partials /* [n][msm_wide_partials_per_blob(n)] */,
+                     int *d_err, hipStream_t st);
 // ---- k_msm.hip
 void launch_digits_from_blobs(const uint8_t *d_blobs, int n, uint8_t *d_digits /* [n][32][4096] */, int *d_err /* per blob */, hipStream_t st);
 void launch_digits_from_fr(const Fr *d_scalars /* [n][4096] Montgomery */, int n, uint8_t *d_digits, hipStream_t st);
 void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_partials /* [n][32] */, hipStream_t st);
-void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48 /* [n][48] */, hipStream_t st);
+void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48 /* [n][48] */, hipStream_t st, int ppb = 0 /* partials per blob; 0: bucket form */);
 
 // ---- k_prove.hip
 // quotient polynomial q(X) = (p(X) - y)/(X - z) in evaluation form (kzg.rs:461-523) for n blobs; also y.

@@ -384,3 +384,26 @@ def test_challenge_kernel_forms_match_oracle(form, kz, setup_bytes, random_set, 
             assert rec[160 * i + 80:160 * i + 112] == inter["y"][j], f"y[{i}]"
     finally:
         s.free()
+
+
+def test_msm_bucket_form_matches_wide_table_form(kz, setup_bytes, settings, random_set, oracle, oracle_settings):
+    """Commitments and proofs through the 8-bit bucket MSM (KZG355_MSM=bucket: the form a handle falls back to when the 23.6 GB
+    wide-window table cannot be allocated) equal the default form's and the oracle's, for 1, 5 and all blobs per call (the
+    launch shapes differ with the count)."""
+    g1, g2 = setup_bytes
+    os.environ["KZG355_MSM"] = "bucket"
+    try:
+        sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_MSM"]
+    try:
+        blobs, cs, ps = random_set
+        B = [kz.Blob(b) for b in blobs]
+        for n in (1, 5, len(blobs)):
+            for s in (sb, settings):
+                got = kz.Kzg.blob_to_kzg_commitment_many(B[:n], s)
+                assert [c.to_bytes() for c in got] == cs[:n]
+                gp = kz.Kzg.compute_blob_kzg_proof_many(B[:n], [kz.KzgCommitment(c) for c in cs[:n]], s)
+                assert [p.to_bytes() for p in gp] == ps[:n]
+    finally:
+        sb.free()
