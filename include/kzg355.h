@@ -56,7 +56,9 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
 /* Kzg::load_trusted_setup (kzg.rs:1005 -> 45-78 -> 833-899).  g1: n1*48 bytes, g2: n2*96 bytes, compressed,
  * Lagrange form, file order.  n1 != 4096 or n2 != 65 -> INVALID_TRUSTED_SETUP; bad point / monomial form -> BADARGS.
  * Builds the device-resident tables (roots of unity, bit-reversed G1 table and its per-window multiples,
- * Miller-loop line tables of the two G2 points the verify path uses). */
+ * Miller-loop line tables of the two G2 points the verify path uses) -- including the 23.6 GB wide-window MSM table
+ * (every multiple 1..2048 of 2^(12w) * g1[i]); if that allocation fails, or with KZG355_MSM=bucket in the environment,
+ * only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results). */
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
 /* Kzg::load_trusted_setup_file (kzg.rs:995 -> 906-979): "4096\n65\n" + hex lines. */
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out);
