@@ -285,13 +285,38 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
             units += 1
         t_total += time.perf_counter() - t0
         reps += 1
+    # the stronger baseline SURVEY 8(d) asks for: every core of this box's share, one batch (or blob) per thread
+    # (ctypes releases the GIL; the oracle holds no mutable state in its settings)
+    import threading
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    done = [0] * cores
+    t_end = time.perf_counter() + 6.0
+    def worker(k):
+        j = k
+        while time.perf_counter() < t_end:
+            if op == "verify":
+                o.verify_blob_kzg_proof_batch(blobs, cs, ps, so); done[k] += n
+            elif op == "commit":
+                o.blob_to_kzg_commitment(blobs[j % n], so); done[k] += 1
+            else:
+                o.compute_blob_kzg_proof(blobs[j % n], cs[j % n], so); done[k] += 1
+            j += cores
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    for t in th: t.start()
+    for t in th: t.join()
+    all_cores = sum(done) / (time.perf_counter() - t0)
     o.free_trusted_setup(so)
     what = {"verify": "verify_blob_kzg_proof_batch(n=64) on the bench's first batch", "commit": "blob_to_kzg_commitment on blobs of the first batch",
             "proof": "compute_blob_kzg_proof on blobs of the first batch"}[op]
     return {"value": units / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; restatement in portable C, not blst "
                       f"(blst's asm is likely 1.5-3x faster per core)",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "note": "same work, one call per thread, ~6 s"}}
 
 
 if __name__ == "__main__":

@@ -407,3 +407,34 @@ def test_msm_bucket_form_matches_wide_table_form(kz, setup_bytes, settings, rand
                 assert [p.to_bytes() for p in gp] == ps[:n]
     finally:
         sb.free()
+
+
+@pytest.mark.parametrize("n", [64, 512])
+def test_batch_fixtures_stage_by_stage(n, kz, settings):
+    """The committed n = 64 / n = 512 batches (tests/golden/batch{n}.json, oracle-derived from the seeded bench recipe; SURVEY 8c
+    item 3): the product reproduces every commitment and proof bit for bit, the stage-1 records carry the fixture's z_i and
+    y_i, the batch verifies, the swapped twin does not -- and the same 512 blobs as eight batches of 64 verify in one launch."""
+    import json
+    import torch
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"batch{n}.json")))
+    first = fx["first_index"]
+    blobs = [random_blob(first + i) for i in range(n)]
+    B = [kz.Blob(b) for b in blobs]
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, settings)
+    assert [c.to_bytes().hex() for c in cs] == fx["commitments"]
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, settings)
+    assert [p.to_bytes().hex() for p in ps] == fx["proofs"]
+    rec = _records_of(kz, settings, blobs, [c.to_bytes() for c in cs], [p.to_bytes() for p in ps])
+    for i in range(n):
+        assert rec[160 * i + 48:160 * i + 80].hex() == fx["z"][i], f"z[{i}]"
+        assert rec[160 * i + 80:160 * i + 112].hex() == fx["y"][i], f"y[{i}]"
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, ps, settings) is fx["expect"]
+    a, b = fx["swapped_pair"]
+    sw = list(ps); sw[a], sw[b] = sw[b], sw[a]
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, sw, settings) is fx["expect_swapped"]
+    if n == 512:
+        groups = [(B[64 * g:64 * g + 64], cs[64 * g:64 * g + 64], ps[64 * g:64 * g + 64]) for g in range(8)]
+        assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, settings) == [True] * 8
+        groups[a // 64] = (groups[a // 64][0], groups[a // 64][1], sw[64 * (a // 64):64 * (a // 64) + 64])
+        assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, settings) == [g != a // 64 for g in range(8)]
+    torch.cuda.synchronize()

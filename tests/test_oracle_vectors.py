@@ -16,3 +16,24 @@ def test_oracle_matches_reference_vectors(fn, golden_vectors, golden_blobs, orac
     n, failures = run_function(fn, golden_vectors, oracle, oracle_settings, golden_blobs)
     assert n == EXPECTED_COUNTS[fn]
     assert not failures, "\n".join(failures)
+
+
+def test_batch64_fixture_consistent_with_oracle(oracle, oracle_settings):
+    """tests/golden/batch64.json (self-golden, see make_batch_fixtures.py): the committed commitments / proofs / z / y / r and
+    pairing inputs are what the oracle computes today from the seeded blobs -- guards the fixture against drift."""
+    import json, os
+    from synth import random_blob
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "batch64.json")))
+    n, first = fx["n"], fx["first_index"]
+    blobs = [random_blob(first + i) for i in range(n)]
+    cs = [bytes.fromhex(c) for c in fx["commitments"]]; ps = [bytes.fromhex(p) for p in fx["proofs"]]
+    for i in (0, 31, 63):
+        assert oracle.blob_to_kzg_commitment(blobs[i], oracle_settings) == cs[i]
+        assert oracle.compute_blob_kzg_proof(blobs[i], cs[i], oracle_settings) == ps[i]
+    inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+    assert inter["ok"] is True
+    assert [z.hex() for z in inter["z"]] == fx["z"] and [y.hex() for y in inter["y"]] == fx["y"]
+    assert inter["r"].hex() == fx["r"] and inter["proof_lincomb"].hex() == fx["proof_lincomb"] and inter["rhs"].hex() == fx["rhs"]
+    a, b = fx["swapped_pair"]
+    ps[a], ps[b] = ps[b], ps[a]
+    assert oracle.verify_blob_kzg_proof_batch(blobs, cs, ps, oracle_settings) is False
