@@ -438,3 +438,56 @@ def test_batch_fixtures_stage_by_stage(n, kz, settings):
         groups[a // 64] = (groups[a // 64][0], groups[a // 64][1], sw[64 * (a // 64):64 * (a // 64) + 64])
         assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, settings) == [g != a // 64 for g in range(8)]
     torch.cuda.synchronize()
+
+
+def test_differential_batch_mutations(kz, settings, oracle, oracle_settings, random_set):
+    """Differential test of verify_blob_kzg_proof_batch against the oracle on mutated batches of 1..6 blobs: honest, a field
+    element of a blob pushed to r / r-1 / 2^256-1, a blob byte flipped, proofs swapped, a commitment replaced by another
+    blob's, by infinity, by an off-curve / out-of-subgroup x, flag bits corrupted.  Ok(true) / Ok(false) / Err must agree."""
+    import random
+    from oracle.oracle import OracleError
+    rnd = random.Random(4844)
+    blobs, cs, ps = random_set
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+    def case():
+        n = rnd.randrange(1, 7)
+        idx = rnd.sample(range(len(blobs)), n)
+        B, Cm, Pr = [blobs[i] for i in idx], [cs[i] for i in idx], [ps[i] for i in idx]
+        k = rnd.randrange(10)
+        j = rnd.randrange(n)
+        if k == 1:
+            v = rnd.choice([R, R - 1, (1 << 256) - 1, R + 5])
+            b = bytearray(B[j]); e = rnd.randrange(4096); b[32 * e:32 * e + 32] = v.to_bytes(32, "big"); B[j] = bytes(b)
+        elif k == 2:
+            b = bytearray(B[j]); b[rnd.randrange(131072) | 1] ^= 1 << rnd.randrange(8); B[j] = bytes(b)   # odd offsets: never the zeroed top byte
+        elif k == 3 and n > 1:
+            a = (j + 1) % n; Pr[j], Pr[a] = Pr[a], Pr[j]
+        elif k == 4:
+            Cm[j] = cs[(idx[j] + 1) % len(cs)]
+        elif k == 5:
+            Cm[j] = bytes([0xC0]) + bytes(47)
+        elif k == 6:
+            x = bytearray(rnd.randrange(1 << 381).to_bytes(48, "big")); x[0] = (x[0] & 0x1F) | 0x80 | (0x20 if rnd.random() < .5 else 0)
+            if rnd.random() < .5: Cm[j] = bytes(x)
+            else: Pr[j] = bytes(x)
+        elif k == 7:
+            x = bytearray(Pr[j]); x[0] ^= rnd.choice([0x80, 0x40, 0x20]); Pr[j] = bytes(x)
+        elif k == 8:
+            x = bytearray(Pr[j]); x[rnd.randrange(1, 48)] ^= 1 << rnd.randrange(8); Pr[j] = bytes(x)
+        return B, Cm, Pr
+
+    seen = {True: 0, False: 0, None: 0}
+    for _ in range(60):
+        B, Cm, Pr = case()
+        try:
+            want = oracle.verify_blob_kzg_proof_batch(B, Cm, Pr, oracle_settings)
+        except OracleError:
+            want = None
+        try:
+            got = kz.Kzg.verify_blob_kzg_proof_batch([kz.Blob(b) for b in B], [kz.KzgCommitment(c) for c in Cm], [kz.KzgProof(p) for p in Pr], settings)
+        except kz.Error:
+            got = None
+        assert got == want, (len(B), got, want)
+        seen[want] += 1
+    assert seen[True] >= 3 and seen[False] >= 8 and seen[None] >= 8, seen
