@@ -189,7 +189,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->lc_partials.ensure(lincomb_partials_bytes(npg, groups)))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
     // windowed per-term form (shortest chain) for few batches, bucket method (least issue work) when many are in flight
-    const bool buckets = npg >= 8 && npg <= 128 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
+    const bool buckets = npg >= 8 && npg <= 4096 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
     if (buckets && (rc = w->lc_partials.ensure(lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
     if ((rc = join_side(w))) return rc;                           // the validated points are needed from here on
     if (buckets) {

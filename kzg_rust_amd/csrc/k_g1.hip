@@ -170,8 +170,12 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
     }
 }
 
-__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S) {
-    __shared__ uint16_t lists[8][520];           // per task: item | sign << 15, grouped by bucket
+// Lists: per task, item | sign << 15 grouped by bucket.  In LDS up to 128 blobs per batch; beyond that (multi-GPU batches of
+// 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~6,600 instructions either way.
+constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
+__host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
+__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
+    __shared__ uint16_t lists_lds[8][LC_LDS_LIST];
     __shared__ int cnt[8][9], start[8][9], cursor[8][9];
     const int g = blockIdx.x / (2 * LC_WAVES_PER_CLASS), wv = blockIdx.x % (2 * LC_WAVES_PER_CLASS), lane = threadIdx.x;
     const int cls = wv < LC_WAVES_PER_CLASS ? 1 : 0;
@@ -190,6 +194,9 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
         if (lane == 0) S[((size_t)g * 2 + cls) * LC_WINDOWS + w0] = acc;
         return;
     }
+    const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
+    const int stride = in_lds ? LC_LDS_LIST : lc_list_stride(n);
+    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + (size_t)blockIdx.x * 8 * stride;
     for (int q = lane; q < 72; q += 64) cnt[q / 9][q % 9] = 0;
     __syncthreads();
     for (int tk = 0; tk < 8; tk++) {
@@ -205,16 +212,17 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
         if (w >= LC_WINDOWS) break;
         for (int j = lo + lane; j < hi; j += 64) {
             const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
-            if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk][pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
+            if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk * stride + pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
         }
     }
+    __threadfence_block();                       // the global-slab form is read back by other lanes of this wave
     __syncthreads();
     const int tk = lane >> 3, b = (lane & 7) + 1, w = w0 + tk;
     G1Jac acc = g1_inf();
     if (w < LC_WINDOWS) {
         const int s0 = start[tk][b], c = cnt[tk][b];
         for (int q = 0; q < c; q++) {
-            const uint32_t v = lists[tk][s0 + q];
+            const uint32_t v = in_lds ? lists[tk * stride + s0 + q] : __builtin_nontemporal_load(&lists[tk * stride + s0 + q]);
             G1Affine p = it[v & 0x7fff];
             if (v & 0x8000) fp_neg(p.y, p.y);
             g1_add_mixed(acc, acc, p);
@@ -275,14 +283,16 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
     G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * groups);
+    uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists);
     if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
-    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 256;
+    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * lc_list_stride(n_per_group) * sizeof(uint16_t);
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;

@@ -70,7 +70,7 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
                     int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, G1Affine *d_pair_pts /* [group][2] */,
                     hipStream_t st);
 size_t lincomb_partials_bytes(int n_per_group, int groups);
-// bucket-method (Pippenger) form of the same sums, for many batches in flight; requires n_per_group <= 128
+// bucket-method (Pippenger) form of the same sums, for many batches in flight; n_per_group <= 4096 (item indices are 15-bit)
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                             int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, G1Affine *d_pair_pts, hipStream_t st,
                             int stage = 0 /* 0: all three kernels; 1 prep, 2 buckets, 3 horner (per-kernel timing) */);

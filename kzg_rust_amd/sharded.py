@@ -8,8 +8,11 @@ combination challenge r, a hash over ALL (C_i, z_i, y_i, proof_i) (utils.rs:454-
   stage 1 (per rank, its shard)        -> 160-byte records  C_i | z_i | y_i | proof_i      (no communication)
   ONE all-gather of the records         (torch.distributed; backend "nccl" = RCCL over xGMI; 10 KiB per rank per batch:
                                          latency-bound, so a single collective and no bandwidth-optimal ring design)
-  ONE all-reduce(MAX) of the per-batch status word, so an Err on any rank is an Err everywhere (the `?` semantics)
-  stage 2 (replicated on every rank)   -> r-powers, the three linear combinations, the pairing  (cheap, no 2nd exchange)
+  stage 2 (per rank, its share of the BATCHES: every rank now holds every record) -> r-powers, the linear combinations,
+                                         the pairing.  On the GPU stage 2 costs about a third of stage 1, so replicating it on
+                                         every rank would cap the scaling; splitting it by batch keeps the work per rank constant.
+  ONE all-reduce(MAX) of the per-batch verdict / status words, so every rank returns every verdict and an Err on any rank
+                                         is an Err everywhere (the `?` semantics)
 
 The compute stages are delegated to an `engine` with two methods, so that the orchestration (partitioning, gather
 order, status merging) is testable on CPU with gloo; the product engine is HipEngine (C ABI of libkzg355.so).
@@ -69,14 +72,20 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         status = [a or b for a, b in zip(st_local, st2)]
         return [o and s == 0 for o, s in zip(ok, status)], status
     nloc = groups * n_local * RECORD
+    rank = dist.get_rank(group)
     gathered = torch.empty(world * nloc, dtype=torch.uint8, device=rec.device)
     dist.all_gather_into_tensor(gathered, rec, group=group)         # the ONE data-path collective
-    st = torch.tensor(st_local, dtype=torch.int32, device=rec.device)
-    dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)          # status merge
-    # [rank][batch][n_local*160] -> [batch][rank][n_local*160]
-    recs = gathered.view(world, groups, n_local * RECORD).permute(1, 0, 2).contiguous().view(-1)
-    if rec.is_cuda:
-        torch.cuda.synchronize(rec.device)
-    ok, st2 = engine.verify_records(recs, n_local * world, groups)
-    status = [int(a) or b for a, b in zip(st.tolist(), st2)]
-    return [o and s == 0 for o, s in zip(ok, status)], status
+    # this rank's share of the batches: [rank][batch][n_local*160] -> [batch in share][rank][n_local*160]
+    g_lo, g_hi = (groups * rank) // world, (groups * (rank + 1)) // world
+    code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
+    code[:groups] = torch.tensor(st_local, dtype=torch.int32, device=rec.device)
+    if g_hi > g_lo:
+        recs = gathered.view(world, groups, n_local * RECORD)[:, g_lo:g_hi, :].permute(1, 0, 2).contiguous().view(-1)
+        if rec.is_cuda:
+            torch.cuda.synchronize(rec.device)
+        ok, st2 = engine.verify_records(recs, n_local * world, g_hi - g_lo)
+        code[groups + g_lo:groups + g_hi] = torch.tensor([1 + int(o) + 256 * int(s) for o, s in zip(ok, st2)], dtype=torch.int32, device=rec.device)
+    dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)        # verdicts of every share + status merge, one small collective
+    code = code.tolist()
+    status = [int(code[g]) or (code[groups + g] >> 8) for g in range(groups)]
+    return [((code[groups + g] & 0xFF) == 2) and status[g] == 0 for g in range(groups)], status

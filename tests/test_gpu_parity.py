@@ -342,6 +342,15 @@ def test_bucket_lincomb_matches_windowed(kz, setup_bytes, settings, oracle, orac
         res = kz.Kzg.verify_blob_kzg_proof_batch_many(groups, sb)
         assert [r is True for r in res] == [g != 5 for g in range(8)]
         assert oracle.verify_blob_kzg_proof_batch(blobs[:16], [c.to_bytes() for c in cs[:16]], [p.to_bytes() for p in ps[:16]], oracle_settings) is True
+        # a multi-GPU sized batch (64 blobs x 8 ranks): the per-task lists no longer fit LDS and live in a global slab
+        import json
+        fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "batch512.json")))
+        B5 = [kz.Blob(random_blob(fx["first_index"] + i)) for i in range(512)]
+        C5 = [kz.KzgCommitment(bytes.fromhex(c)) for c in fx["commitments"]]; P5 = [kz.KzgProof(bytes.fromhex(p)) for p in fx["proofs"]]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B5, C5, P5, sb) is True
+        a, b = fx["swapped_pair"]
+        P5[a], P5[b] = P5[b], P5[a]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B5, C5, P5, sb) is False
     finally:
         sb.free()
 
