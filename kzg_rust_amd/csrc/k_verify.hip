@@ -304,42 +304,99 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
 }
 
 // ------------------------------------------------------------------------------------------------ r powers
-// One lane per batch.  Transcript: "RCKZGBATCH___V1_" | u64be(4096) | u64be(n) | n records  (utils.rs:439-463).
+// One wave per batch.  Transcript: "RCKZGBATCH___V1_" | u64be(4096) | u64be(n) | n records  (utils.rs:439-463).
 // Emits, as plain 256-bit integers (8 LE words): a_i = r^i, b_i = r^i z_i, and c = sum r^i y_i.
+// The hash is one serial chain per batch, but the message schedule of a block does not depend on the chaining state: the 64
+// lanes expand 64 blocks at once (W[t] + K[t] to LDS), then lane 0 runs the rounds of those blocks (~930 instructions each,
+// the irreducible chain).  The powers are spread over the lanes: lane l starts at r^l and steps by r^64.
+__constant__ uint32_t SHA_K[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u,
+    0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u,
+    0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u,
+    0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
+    0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
 __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
                                                  uint32_t *scal_c, int *err) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
+    __shared__ uint32_t wk[64][64];                  // [t][block of the chunk]
+    __shared__ uint32_t digest[8];
+    const int g = blockIdx.x, lane = threadIdx.x;
     const uint8_t *rec = records + (size_t)RECORD_BYTES * n * g;
     Fr r = fr_one();
     if (n > 1) {   // for n == 1 only r^0 = 1 is used (the reference takes the single-proof path, kzg.rs:658-660)
-        Sha256 s; sha256_init(s);
         const uint32_t total_words = 8u + 40u * (uint32_t)n;            // message length / 4
         const uint32_t nblocks = (total_words * 4u + 9u + 63u) / 64u;
         const uint64_t bits = (uint64_t)total_words * 32u;
-        for (uint32_t b = 0; b < nblocks; b++) {
-            uint32_t w[16];
-            for (int t = 0; t < 16; t++) {
-                const uint32_t idx = 16u * b + (uint32_t)t;
-                uint32_t v;
-                if (idx < 8u) {
-                    const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)N_FE, 0u, (uint32_t)n};
-                    v = hdr[idx];                                       // "RCKZGBATCH___V1_" | 4096 | n
-                } else if (idx < total_words) v = load_be32(rec + 4 * (size_t)(idx - 8u));
-                else if (idx == total_words) v = 0x80000000u;
-                else if (idx == 16u * nblocks - 2u) v = (uint32_t)(bits >> 32);
-                else if (idx == 16u * nblocks - 1u) v = (uint32_t)bits;
-                else v = 0u;
-                w[t] = v;
+        uint32_t h0 = 0x6a09e667u, h1 = 0xbb67ae85u, h2 = 0x3c6ef372u, h3 = 0xa54ff53au, h4 = 0x510e527fu, h5 = 0x9b05688cu, h6 = 0x1f83d9abu, h7 = 0x5be0cd19u;
+        for (uint32_t b0 = 0; b0 < nblocks; b0 += 64) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            if (b < nblocks) {                                          // this lane expands block b
+                uint32_t w[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const uint32_t idx = 16u * b + (uint32_t)t;
+                    uint32_t v;
+                    if (idx < 8u) {
+                        const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)N_FE, 0u, (uint32_t)n};
+                        v = hdr[idx];                                   // "RCKZGBATCH___V1_" | 4096 | n
+                    } else if (idx < total_words) v = load_be32(rec + 4 * (size_t)(idx - 8u));
+                    else if (idx == total_words) v = 0x80000000u;
+                    else if (idx == 16u * nblocks - 2u) v = (uint32_t)(bits >> 32);
+                    else if (idx == 16u * nblocks - 1u) v = (uint32_t)bits;
+                    else v = 0u;
+                    w[t] = v;
+                }
+#pragma unroll
+                for (int t = 0; t < 64; t++) {
+                    if (t >= 16) {
+                        const uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                        const uint32_t s0 = xor3(ror(w15, 7), ror(w15, 18), w15 >> 3);
+                        const uint32_t s1 = xor3(ror(w2, 17), ror(w2, 19), w2 >> 10);
+                        w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+                    }
+                    wk[t][lane] = w[t & 15] + SHA_K[t];
+                }
             }
-            sha256_block(s, w);
+            __syncthreads();
+            if (lane == 0) {
+                const uint32_t cnt = nblocks - b0 < 64u ? nblocks - b0 : 64u;
+#pragma unroll 1
+                for (uint32_t q = 0; q < cnt; q++) {
+                    uint32_t a = h0, bb = h1, c = h2, d = h3, e = h4, f = h5, gg = h6, h = h7;
+#pragma unroll
+                    for (int t = 0; t < 64; t++) {
+                        const uint32_t t1 = h + xor3(ror(e, 6), ror(e, 11), ror(e, 25)) + ch3(e, f, gg) + wk[t][q];
+                        const uint32_t t2 = xor3(ror(a, 2), ror(a, 13), ror(a, 22)) + maj3(a, bb, c);
+                        h = gg; gg = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                    }
+                    h0 += a; h1 += bb; h2 += c; h3 += d; h4 += e; h5 += f; h6 += gg; h7 += h;
+                }
+            }
+            __syncthreads();
         }
-        uint32_t dw[8]; sha256_digest_to_words(dw, s);
+        if (lane == 0) { digest[0] = h7; digest[1] = h6; digest[2] = h5; digest[3] = h4; digest[4] = h3; digest[5] = h2; digest[6] = h1; digest[7] = h0; }
+        __syncthreads();
+        uint32_t dw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dw[k] = digest[k];
         fr_from_words(r, dw);                                           // hash_to_bls_field (utils.rs:472)
     }
-    Fr pw = fr_one(), csum = fr_zero();
+    // lane l: r^l by square-and-multiply over its 6 index bits; step r^64
+    Fr pw = fr_one(), r64 = r;
+#pragma unroll 1
+    for (int bit = 5; bit >= 0; bit--) {
+        Fr t;
+        fr_sqr(pw, pw);
+        fr_mul(t, pw, r);
+        fr_select(pw, (lane >> bit) & 1, pw, t);
+        fr_sqr(r64, r64);
+    }
+    Fr csum = fr_zero();
     bool bad = false;
-    for (int i = 0; i < n; i++) {
+#pragma unroll 1
+    for (int i = lane; i < n; i += 64) {
         uint32_t zw[8], yw[8];
         be32_to_words(zw, rec + (size_t)RECORD_BYTES * i + 48);
         be32_to_words(yw, rec + (size_t)RECORD_BYTES * i + 80);
@@ -350,10 +407,14 @@ __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, i
         fr_to_words(ow, pw); for (int k = 0; k < 8; k++) pa[k] = ow[k];
         fr_mul(t, pw, z); fr_to_words(ow, t); for (int k = 0; k < 8; k++) pb[k] = ow[k];
         fr_mul(t, pw, y); fr_add(csum, csum, t);
-        fr_mul(pw, pw, r);
+        fr_mul(pw, pw, r64);
     }
-    uint32_t ow[8]; fr_to_words(ow, csum);
-    for (int k = 0; k < 8; k++) scal_c[8 * (size_t)g + k] = ow[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(csum, off); fr_add(csum, csum, o); }
+    if (lane == 0) {
+        uint32_t ow[8]; fr_to_words(ow, csum);
+        for (int k = 0; k < 8; k++) scal_c[8 * (size_t)g + k] = ow[k];
+    }
     if (bad) atomicOr(&err[g], ERR_NONCANONICAL_FR);
 }
 
@@ -386,7 +447,7 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st) {
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
+    hipLaunchKernelGGL(k_rpowers, dim3(groups), dim3(64), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
 }
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
