@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=2048,
+    ap.add_argument("--batches-per-step", "--concurrent", dest="concurrent", type=int, default=None,
                     help="independent 64-blob batches verified by one step (one launch set)")
     ap.add_argument("--op", choices=["verify", "commit", "proof"], default="verify",
                     help="verify = the headline metric; commit / proof = secondary single-GPU metrics (BASELINE.json configs[1], [2])")
@@ -94,8 +94,9 @@ def main():
     assert s.device == local_rank
 
     K, W = max(1, args.steps), max(0, args.warmup)
-    if args.op != "verify" and args.concurrent == 1024:
-        args.concurrent = 64                      # MSM-bound ops: 4096 blobs per step keep the default run short
+    if args.concurrent is None:
+        # verify: 2048 batches = 131,072 blobs = 17 GB per launch set; MSM-bound ops and the PCIe-inclusive variant: 256 batches
+        args.concurrent = 2048 if (args.op == "verify" and not args.host_inputs) else 256
     Cc = max(1, args.concurrent)
     n_local = N_PER_BATCH
     # ---- untimed setup: Cc distinct batches per step; this rank owns blobs [rank*64, rank*64+64) of each batch.
