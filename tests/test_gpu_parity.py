@@ -500,3 +500,39 @@ def test_differential_batch_mutations(kz, settings, oracle, oracle_settings, ran
         assert got == want, (len(B), got, want)
         seen[want] += 1
     assert seen[True] >= 3 and seen[False] >= 8 and seen[None] >= 8, seen
+
+
+def test_msm_launch_shapes_agree(kz, settings, random_set):
+    """The wide-table MSM picks its launch shape by blob count (1 or 2 window parts, 1 / 4 / 16 scalars per lane): 1024 blobs in
+    one call (16 scalars per lane, one workgroup per blob) must give the commitments and proofs of the same blobs sent in
+    calls of 64 and of 200 (other shapes), and the first ones must be the oracle's (random_set)."""
+    import torch
+    blobs, cs, ps = random_set
+    n = 1024
+    dev = torch.device("cuda", settings.device)
+    reps = (n + len(blobs) - 1) // len(blobs)
+    tb = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev).repeat(reps)[:n * 131072].contiguous()
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    noise = torch.randint(0, 256, (n * 131072,), dtype=torch.uint8, generator=g).to(dev)
+    noise.view(n * 4096, 32)[:, 0] = 0                          # keep every element canonical
+    tb[len(blobs) * 131072:] = noise[len(blobs) * 131072:]      # first len(blobs) blobs stay the oracle-checked ones
+    L = kz.kzg.lib()
+
+    def commit(lo, hi):
+        out = C.create_string_buffer(48 * (hi - lo)); st = (C.c_int * (hi - lo))()
+        assert L.kzg355_blob_to_kzg_commitment_many_device(out, st, tb.data_ptr() + lo * 131072, hi - lo, settings.handle) == 0
+        return out.raw
+
+    def prove(lo, hi, c):
+        tc = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev)
+        out = C.create_string_buffer(48 * (hi - lo)); st = (C.c_int * (hi - lo))()
+        assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr() + lo * 131072, tc.data_ptr(), hi - lo, settings.handle) == 0
+        return out.raw
+
+    c_all = commit(0, n)
+    assert [c_all[48 * i:48 * i + 48] for i in range(len(blobs))] == cs
+    assert b"".join(commit(lo, lo + 64) for lo in range(0, n, 64)) == c_all
+    assert b"".join(commit(lo, min(lo + 200, n)) for lo in range(0, n, 200)) == c_all
+    p_all = prove(0, n, c_all)
+    assert [p_all[48 * i:48 * i + 48] for i in range(len(blobs))] == ps
+    assert b"".join(prove(lo, lo + 64, c_all[48 * lo:48 * (lo + 64)]) for lo in range(0, n, 64)) == p_all
