@@ -99,6 +99,49 @@ KZG_G1_MID void g1_add(G1Jac &r, const G1Jac &a, const G1Jac &b) {
     r.x = X3; r.y = Y3; r.z = Z3;
 }
 
+// Extended Jacobian ("XYZZ") accumulator: x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2; infinity: ZZ = 0.  Its mixed addition is
+// 8M + 2S (madd-2008-s) against 8M + 3S for the Jacobian form above, at the price of one more coordinate: the form the
+// accumulation loops use (wide-table MSM, bucket lincomb); everything else stays Jacobian.
+struct G1X { Fp x, y, zz, zzz; };
+KZG_HD G1X g1x_inf() { G1X r; r.x = fp_zero(); r.y = fp_zero(); r.zz = fp_zero(); r.zzz = fp_zero(); return r; }
+KZG_HD bool g1x_is_inf(const G1X &a) { return fp_is_zero(a.zz); }
+// Complete: handles a or b at infinity and b = +-a (doubling of the affine point, mdbl-2008-s-1 with a = 0).
+KZG_G1_MID void g1x_add_mixed(G1X &r, const G1X &a, const G1Affine &b) {
+    if (g1a_is_inf(b)) { r = a; return; }
+    if (g1x_is_inf(a)) { r.x = b.x; r.y = b.y; r.zz = fp_one(); r.zzz = fp_one(); return; }
+    Fp U2, S2, P, R, PP, PPP, Q, t;
+    fp_mul(U2, b.x, a.zz);
+    fp_mul(S2, b.y, a.zzz);
+    fp_sub(P, U2, a.x);
+    fp_sub(R, S2, a.y);
+    if (fp_is_zero(P)) {
+        if (!fp_is_zero(R)) { r = g1x_inf(); return; }
+        Fp U, V, W, S, M;
+        fp_dbl(U, b.y); fp_sqr(V, U); fp_mul(W, U, V); fp_mul(S, b.x, V);
+        fp_sqr(M, b.x); fp_dbl(t, M); fp_add(M, M, t);
+        Fp X3, Y3;
+        fp_sqr(X3, M); fp_sub(X3, X3, S); fp_sub(X3, X3, S);
+        fp_sub(t, S, X3); fp_mul(Y3, M, t); fp_mul(t, W, b.y); fp_sub(Y3, Y3, t);
+        r.x = X3; r.y = Y3; r.zz = V; r.zzz = W;
+        return;
+    }
+    fp_sqr(PP, P); fp_mul(PPP, P, PP); fp_mul(Q, a.x, PP);
+    Fp X3, Y3;
+    fp_sqr(X3, R); fp_sub(X3, X3, PPP); fp_sub(X3, X3, Q); fp_sub(X3, X3, Q);
+    fp_sub(t, Q, X3); fp_mul(Y3, R, t);
+    fp_mul(t, a.y, PPP); fp_sub(Y3, Y3, t);
+    fp_mul(r.zz, a.zz, PP);
+    fp_mul(r.zzz, a.zzz, PPP);
+    r.x = X3; r.y = Y3;
+}
+// -> Jacobian without an inversion: take Z' = ZZ, then Z'^2 = ZZ^2 gives X' = X * ZZ and Z'^3 = ZZ^3 = ZZZ^2 gives Y' = Y * ZZZ.
+KZG_G1_MID void g1x_to_jac(G1Jac &r, const G1X &a) {
+    if (g1x_is_inf(a)) { r = g1_inf(); return; }
+    fp_mul(r.x, a.x, a.zz);
+    fp_mul(r.y, a.y, a.zzz);
+    r.z = a.zz;
+}
+
 KZG_G1_MID void g1_to_affine(G1Affine &r, const G1Jac &a) {
     if (g1_is_inf(a)) { r = g1a_inf(); return; }
     Fp zi, zi2, zi3;

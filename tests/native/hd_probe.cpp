@@ -97,6 +97,13 @@ int hd_g1_mul_add(uint8_t *out, const uint8_t *p, const uint8_t *k_be, const uin
     if (q) { if (g1_decompress(qa, q)) return 1; g1_add_mixed(r, r, qa); }
     g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
 }
+// out = sum of n compressed points accumulated in the extended-Jacobian (XYZZ) form the MSM / bucket kernels use
+int hd_g1x_sum(uint8_t *out, const uint8_t *pts48, int n) {
+    G1X acc = g1x_inf();
+    for (int i = 0; i < n; i++) { G1Affine p; if (g1_decompress(p, pts48 + 48 * i)) return 1; g1x_add_mixed(acc, acc, p); }
+    G1Jac j; g1x_to_jac(j, acc);
+    G1Affine a; g1_to_affine(a, j); g1_compress_affine(out, a); return 0;
+}
 // out = P + Q using the Jacobian+Jacobian routine (both lifted with a non-trivial z)
 int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
     G1Affine pa, qa, ra; G1Jac pj, qj, r;

@@ -216,3 +216,26 @@ def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_b
             assert out.raw == y, z.hex()
     bad = bytearray(blobs[0]); bad[32 * 77:32 * 78] = (R_).to_bytes(32, "big")
     assert hd.hd_eval_poly(out, bytes(bad), zs[0]) == 1
+
+
+def test_g1_xyzz_accumulator(hd, oracle, setup_bytes):
+    """g1x_add_mixed (8M + 2S extended-Jacobian mixed addition): sums with repeats (P + P: the doubling branch), P - P
+    (infinity), infinity operands and ordinary points agree with the Jacobian routines."""
+    g1, _ = setup_bytes
+    P = [g1[48 * i:48 * i + 48] for i in range(6)]
+    inf = bytes([0xC0]) + bytes(47)
+    def neg(p):
+        return bytes([p[0] ^ 0x20]) + p[1:]
+    def ref_sum(pts):                                    # chain of the probe's Jacobian + mixed additions
+        acc = inf
+        for q in pts:
+            out = C.create_string_buffer(48)
+            assert hd.hd_g1_mul_add(out, acc, (1).to_bytes(32, "big"), q) == 0
+            acc = out.raw
+        return acc
+    cases = [[P[0]], [P[0], P[0]], [P[0], neg(P[0])], [inf, P[1]], [P[1], inf, P[2]], [P[0], P[0], P[0], neg(P[0])],
+             [P[0], P[1], P[2], P[3], P[4], P[5]], [P[3], neg(P[3]), P[3]], [inf, inf], [P[2], P[4], neg(P[2]), neg(P[4])]]
+    for pts in cases:
+        out = C.create_string_buffer(48)
+        assert hd.hd_g1x_sum(out, b"".join(pts), len(pts)) == 0
+        assert out.raw == ref_sum(pts), [p.hex()[:8] for p in pts]
