@@ -130,7 +130,7 @@ template <int N> KZG_HD void mont_mul(uint32_t *r, const uint32_t *a, const uint
 // Montgomery square: the N(N+1)/2 distinct limb products (cross terms against a pre-doubled copy) go to 2N column
 // accumulators, then the same word-by-word reduction.  N(N+1)/2 + N^2 limb products instead of 2 N^2 (Fp: 301 vs 392).
 // Columns stay below 2^64: at most N products of < 2^59 plus N of < 2^58 each, N <= 14.
-template <int N> KZG_HD void mont_sqr(uint32_t *r, const uint32_t *a, const uint32_t *m, const uint32_t inv) {
+template <int N, bool LAZY = false> KZG_HD void mont_sqr(uint32_t *r, const uint32_t *a, const uint32_t *m, const uint32_t inv) {
     static_assert(N <= 14, "column accumulators sized for at most 14 limbs");
     uint64_t acc[2 * N];
     uint32_t a2[N];
@@ -156,8 +156,13 @@ template <int N> KZG_HD void mont_sqr(uint32_t *r, const uint32_t *a, const uint
 #pragma unroll
     for (int j = 0; j < N; j++) {
         c += acc[N + j];
-        t[j] = (uint32_t)c & LMASK;
+        t[j] = (LAZY && j == N - 1) ? (uint32_t)c : ((uint32_t)c & LMASK);
         c >>= LB;
+    }
+    if (LAZY) {
+#pragma unroll
+        for (int j = 0; j < N; j++) r[j] = t[j];
+        return;
     }
     uint32_t s[N];
     const uint32_t br = ul_sub<N>(s, t, m);
@@ -296,6 +301,46 @@ KZG_HD_NOINLINE void fp_sqr(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP>(r.
 #else
 KZG_HD void fp_sqr(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP>(r.l, a.l, FP_MOD, FP_INVW); }
 #endif
+// ---- lazy (unreduced) Fp: R = 2^406 leaves 25 bits above p, so values may run up to a few dozen p between reductions.
+// Products of operands a < 2^6 p, b < 2^6 p come out below p (1 + 2^-13) without the final conditional subtraction; sums are
+// plain limb additions with carry normalisation; differences add a multiple of p first.  Used by the accumulation loops of the
+// MSM / bucket kernels (g1x_add_mixed_lazy), which spend ~15 % of a canonical addition in those subtractions and selects.
+KZG_HD void fp_mul_lz(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul_lazy<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }
+KZG_HD void fp_sqr_lz(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP, true>(r.l, a.l, FP_MOD, FP_INVW); }
+// r = a + (kp - b), kp a multiple of p above b: limbs normalised (signed carries), the top limb keeps the excess
+KZG_HD void fp_sub_lz(Fp &r, const Fp &a, const Fp &b, const uint32_t *kp) {
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) {
+        const int32_t t = (int32_t)a.l[i] + (int32_t)kp[i] - (int32_t)b.l[i] + c;
+        if (i < NFP - 1) { c = t >> LB; r.l[i] = (uint32_t)t & LMASK; }
+        else r.l[i] = (uint32_t)t;
+    }
+}
+// r = a + b + b2 (b2 optional second addend), normalised
+KZG_HD void fp_add_lz(Fp &r, const Fp &a, const Fp &b) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { const uint32_t t = a.l[i] + b.l[i] + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
+}
+// value < 16 p -> canonical
+KZG_HD void fp_canon16(Fp &r, const Fp &a) {
+    const uint32_t m8[NFP] = FP_MOD8_INIT, m4[NFP] = FP_MOD4_INIT, m2[NFP] = FP_MOD2_INIT, m1[NFP] = FP_MOD_INIT;
+    uint32_t v[NFP], s[NFP];
+#pragma unroll
+    for (int i = 0; i < NFP; i++) v[i] = a.l[i];
+    const uint32_t *ms[4] = {m8, m4, m2, m1};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t br = ul_sub<NFP>(s, v, ms[k]);
+#pragma unroll
+        for (int i = 0; i < NFP; i++) v[i] = br ? v[i] : s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NFP; i++) r.l[i] = v[i];
+}
+// could the lazy value v in (0, 16p) be a multiple of p?  exact filter on the low limb: v = j p  =>  j = v0 * p^-1 mod 2^29
+KZG_HD bool fp_maybe_zero_lz(const Fp &v) { return ((v.l[0] * FP_PINVW) & LMASK) < 16u; }
 KZG_HD void fp_select(Fp &r, bool take_b, const Fp &a, const Fp &b) {
 #pragma unroll
     for (int i = 0; i < NFP; i++) r.l[i] = take_b ? b.l[i] : a.l[i];

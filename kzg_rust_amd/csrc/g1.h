@@ -134,6 +134,52 @@ KZG_G1_MID void g1x_add_mixed(G1X &r, const G1X &a, const G1Affine &b) {
     fp_mul(r.zzz, a.zzz, PPP);
     r.x = X3; r.y = Y3;
 }
+// The same addition on LAZY coordinates, for the accumulation loops: no conditional subtraction after any product, sum or
+// difference.  Invariant of the accumulator (in and out): X < 8p, Y < 4p, ZZ, ZZZ < 2p (limbs normalised); b canonical.
+//   U2, S2 < 2p;  P = U2 + 8p - X in (0, 10p);  R = S2 + 4p - Y in (0, 6p);  PP, PPP, Q < 2p
+//   X3 = R^2 + (2p - PPP) + 2 (2p - Q) in (0, 8p);  Y3 = R (Q + 8p - X3) + (2p - Y PPP) in (0, 4p);  ZZ3, ZZZ3 < 2p
+// `started` replaces the ZZ == 0 test (a lazy zero need not be all-zero limbs).  Anything unusual -- b at infinity, or P
+// possibly = 0 mod p (exact low-limb filter, one chance in 2^25 for a random P) -- goes through the canonical routine above.
+KZG_G1_MID void g1x_add_mixed_lazy(G1X &acc, bool &started, const G1Affine &b) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m4[NFP] = FP_MOD4_INIT, m8[NFP] = FP_MOD8_INIT;
+    if (!started) {
+        if (g1a_is_inf(b)) return;
+        acc.x = b.x; acc.y = b.y; acc.zz = fp_one(); acc.zzz = fp_one(); started = true;
+        return;
+    }
+    Fp U2, S2, P, R;
+    fp_mul_lz(U2, b.x, acc.zz);
+    fp_mul_lz(S2, b.y, acc.zzz);
+    fp_sub_lz(P, U2, acc.x, m8);
+    fp_sub_lz(R, S2, acc.y, m4);
+    if (fp_maybe_zero_lz(P) || g1a_is_inf(b)) {                  // rare: redo canonically (doubling / inverse / no-op)
+        G1X c; fp_canon16(c.x, acc.x); fp_canon16(c.y, acc.y); fp_canon16(c.zz, acc.zz); fp_canon16(c.zzz, acc.zzz);
+        g1x_add_mixed(c, c, b);                                   // complete; c is canonical, hence within the invariant
+        acc = c;
+        started = !g1x_is_inf(c);
+        return;
+    }
+    Fp PP, PPP, Q, t, u;
+    fp_sqr_lz(PP, P); fp_mul_lz(PPP, P, PP); fp_mul_lz(Q, acc.x, PP);
+    Fp X3, Y3;
+    fp_sqr_lz(X3, R);
+    fp_sub_lz(t, X3, PPP, m2);                                    // R^2 + 2p - PPP        in (0, 4p)
+    fp_sub_lz(u, t, Q, m2);                                       //  ... + 2p - Q         in (0, 6p)
+    fp_sub_lz(X3, u, Q, m2);                                      //  ... + 2p - Q         in (0, 8p)
+    fp_sub_lz(t, Q, X3, m8);                                      // Q + 8p - X3           in (0, 10p)
+    fp_mul_lz(Y3, R, t);
+    fp_mul_lz(t, acc.y, PPP);
+    fp_sub_lz(Y3, Y3, t, m2);                                     // in (0, 4p)
+    fp_mul_lz(acc.zz, acc.zz, PP);
+    fp_mul_lz(acc.zzz, acc.zzz, PPP);
+    acc.x = X3; acc.y = Y3;
+}
+// lazy accumulator -> canonical XYZZ (infinity if nothing was added)
+KZG_G1_MID void g1x_from_lazy(G1X &r, const G1X &acc, bool started) {
+    if (!started) { r = g1x_inf(); return; }
+    fp_canon16(r.x, acc.x); fp_canon16(r.y, acc.y); fp_canon16(r.zz, acc.zz); fp_canon16(r.zzz, acc.zzz);
+}
+
 // -> Jacobian without an inversion: take Z' = ZZ, then Z'^2 = ZZ^2 gives X' = X * ZZ and Z'^3 = ZZ^3 = ZZZ^2 gives Y' = Y * ZZZ.
 KZG_G1_MID void g1x_to_jac(G1Jac &r, const G1X &a) {
     if (g1x_is_inf(a)) { r = g1_inf(); return; }

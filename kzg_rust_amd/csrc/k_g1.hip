@@ -218,17 +218,18 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
     __threadfence_block();                       // the global-slab form is read back by other lanes of this wave
     __syncthreads();
     const int tk = lane >> 3, b = (lane & 7) + 1, w = w0 + tk;
-    G1X accx = g1x_inf();                            // extended-Jacobian accumulator: 8M + 2S per item
+    G1X accx = g1x_inf(); bool started = false;      // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
     if (w < LC_WINDOWS) {
         const int s0 = start[tk][b], c = cnt[tk][b];
         for (int q = 0; q < c; q++) {
             const uint32_t v = in_lds ? lists[tk * stride + s0 + q] : __builtin_nontemporal_load(&lists[tk * stride + s0 + q]);
             G1Affine p = it[v & 0x7fff];
             if (v & 0x8000) fp_neg(p.y, p.y);
-            g1x_add_mixed(accx, accx, p);
+            g1x_add_mixed_lazy(accx, started, p);
         }
     }
-    G1Jac acc; g1x_to_jac(acc, accx);
+    G1Jac acc;
+    { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
     // sum_b b * B_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} B_b: a 3-step suffix scan over the task's 8 lanes, then
     // a 3-step butterfly -- 6 additions, no doublings
     G1Jac r = acc;

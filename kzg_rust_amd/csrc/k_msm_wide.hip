@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
     const int blob = blockIdx.x / wgpb, wg = blockIdx.x % wgpb, chunk = wg / parts, part = wg % parts;
     const int tid = threadIdx.x;
     const int w_lo = (WIDE_WINDOWS * part) / parts, w_hi = (WIDE_WINDOWS * (part + 1)) / parts;
-    G1X accx = g1x_inf();                                         // extended-Jacobian accumulator: 8M + 2S per row
+    G1X accx = g1x_inf(); bool started = false;                   // lazy extended-Jacobian accumulator: 8M + 2S per row, no reductions
     WideRow cur; bool have = false; bool cur_neg = false;
     bool bad = false;
 #pragma unroll 1
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
             if (have) {
                 G1Affine p; p.x = cur.x; p.y = cur.y;
                 if (cur_neg) fp_neg(p.y, p.y);
-                g1x_add_mixed(accx, accx, p);
+                g1x_add_mixed_lazy(accx, started, p);
             }
             cur = nxt; cur_neg = d < 0; have = true;
         }
@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
     if (have) {
         G1Affine p; p.x = cur.x; p.y = cur.y;
         if (cur_neg) fp_neg(p.y, p.y);
-        g1x_add_mixed(accx, accx, p);
+        g1x_add_mixed_lazy(accx, started, p);
     }
-    G1Jac acc; g1x_to_jac(acc, accx);
+    G1Jac acc;
+    { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
     if (!FROM_FR && bad && part == 0) atomicOr(&err[blob], ERR_NONCANONICAL_FR);          // blob_to_polynomial (kzg.rs:282-291)
 #pragma unroll 1
     for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }

@@ -104,6 +104,14 @@ int hd_g1x_sum(uint8_t *out, const uint8_t *pts48, int n) {
     G1Jac j; g1x_to_jac(j, acc);
     G1Affine a; g1_to_affine(a, j); g1_compress_affine(out, a); return 0;
 }
+// the same through the lazy (unreduced) addition of the accumulation loops
+int hd_g1x_sum_lazy(uint8_t *out, const uint8_t *pts48, int n) {
+    G1X acc = g1x_inf(); bool started = false;
+    for (int i = 0; i < n; i++) { G1Affine p; if (g1_decompress(p, pts48 + 48 * i)) return 1; g1x_add_mixed_lazy(acc, started, p); }
+    G1X c; g1x_from_lazy(c, acc, started);
+    G1Jac j; g1x_to_jac(j, c);
+    G1Affine a; g1_to_affine(a, j); g1_compress_affine(out, a); return 0;
+}
 // out = P + Q using the Jacobian+Jacobian routine (both lifted with a non-trivial z)
 int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
     G1Affine pa, qa, ra; G1Jac pj, qj, r;

@@ -239,3 +239,13 @@ def test_g1_xyzz_accumulator(hd, oracle, setup_bytes):
         out = C.create_string_buffer(48)
         assert hd.hd_g1x_sum(out, b"".join(pts), len(pts)) == 0
         assert out.raw == ref_sum(pts), [p.hex()[:8] for p in pts]
+        assert hd.hd_g1x_sum_lazy(out, b"".join(pts), len(pts)) == 0          # lazy form: same sums, incl. the rare branches
+        assert out.raw == ref_sum(pts), [p.hex()[:8] for p in pts]
+    # a long lazy chain (bounds of the unreduced coordinates must hold for any length) against the canonical chain
+    import random
+    rnd = random.Random(5)
+    allp = [g1[48 * i:48 * i + 48] for i in range(4096)]
+    pts = [rnd.choice(allp) if rnd.random() < .9 else neg(rnd.choice(allp)) for _ in range(600)]
+    a, b = C.create_string_buffer(48), C.create_string_buffer(48)
+    assert hd.hd_g1x_sum(a, b"".join(pts), len(pts)) == 0 and hd.hd_g1x_sum_lazy(b, b"".join(pts), len(pts)) == 0
+    assert a.raw == b.raw
