@@ -336,6 +336,19 @@ def test_bucket_lincomb_matches_windowed(kz, setup_bytes, settings, oracle, orac
             assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], bad, sb) is False
             badc = list(cs[:n]); badc[0] = cs[1]
             assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], badc, ps[:n], sb) is False
+        # points at infinity inside a bucket-form batch: the all-zero blob has C = proof = infinity (0xc0 00...), a constant blob has
+        # proof = infinity; both are valid and must stay valid next to ordinary blobs
+        zero = kz.Blob(bytes(131072)); const = kz.Blob((bytes(31) + b"\x05") * 4096)
+        inf = bytes([0xC0]) + bytes(47)
+        c_const = kz.Kzg.blob_to_kzg_commitment(const, settings)
+        assert kz.Kzg.blob_to_kzg_commitment(zero, settings).to_bytes() == inf
+        assert kz.Kzg.compute_blob_kzg_proof(const, c_const, settings).to_bytes() == inf
+        Bi = B[:9] + [zero, const, zero]; Ci = cs[:9] + [kz.KzgCommitment(inf), c_const, kz.KzgCommitment(inf)]
+        Pi = ps[:9] + [kz.KzgProof(inf), kz.KzgProof(inf), kz.KzgProof(inf)]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(Bi, Ci, Pi, sb) is True
+        assert kz.Kzg.verify_blob_kzg_proof_batch(Bi, Ci, Pi, settings) is True
+        Ci[10] = cs[0]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(Bi, Ci, Pi, sb) is False
         # many batches in one launch (the throughput entry point), one of them wrong
         groups = [(B[16 * g:16 * g + 16], cs[16 * g:16 * g + 16], ps[16 * g:16 * g + 16]) for g in range(8)]
         groups[5] = (groups[5][0], groups[5][1], list(reversed(groups[5][2])))
