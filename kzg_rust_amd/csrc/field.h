@@ -323,15 +323,15 @@ KZG_HD void fp_add_lz(Fp &r, const Fp &a, const Fp &b) {
 #pragma unroll
     for (int i = 0; i < NFP; i++) { const uint32_t t = a.l[i] + b.l[i] + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
 }
-// value < 16 p -> canonical
-KZG_HD void fp_canon16(Fp &r, const Fp &a) {
-    const uint32_t m8[NFP] = FP_MOD8_INIT, m4[NFP] = FP_MOD4_INIT, m2[NFP] = FP_MOD2_INIT, m1[NFP] = FP_MOD_INIT;
+// value < 64 p -> canonical
+KZG_HD void fp_canon64(Fp &r, const Fp &a) {
+    const uint32_t m32[NFP] = FP_MOD32_INIT, m16[NFP] = FP_MOD16_INIT, m8[NFP] = FP_MOD8_INIT, m4[NFP] = FP_MOD4_INIT, m2[NFP] = FP_MOD2_INIT, m1[NFP] = FP_MOD_INIT;
     uint32_t v[NFP], s[NFP];
 #pragma unroll
     for (int i = 0; i < NFP; i++) v[i] = a.l[i];
-    const uint32_t *ms[4] = {m8, m4, m2, m1};
+    const uint32_t *ms[6] = {m32, m16, m8, m4, m2, m1};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 6; k++) {
         const uint32_t br = ul_sub<NFP>(s, v, ms[k]);
 #pragma unroll
         for (int i = 0; i < NFP; i++) v[i] = br ? v[i] : s[i];
@@ -339,8 +339,9 @@ KZG_HD void fp_canon16(Fp &r, const Fp &a) {
 #pragma unroll
     for (int i = 0; i < NFP; i++) r.l[i] = v[i];
 }
-// could the lazy value v in (0, 16p) be a multiple of p?  exact filter on the low limb: v = j p  =>  j = v0 * p^-1 mod 2^29
-KZG_HD bool fp_maybe_zero_lz(const Fp &v) { return ((v.l[0] * FP_PINVW) & LMASK) < 16u; }
+KZG_HD void fp_canon16(Fp &r, const Fp &a) { fp_canon64(r, a); }
+// could the lazy value v in [0, 64p) be a multiple of p?  exact filter on the low limb: v = j p  =>  j = v0 * p^-1 mod 2^29
+KZG_HD bool fp_maybe_zero_lz(const Fp &v) { return ((v.l[0] * FP_PINVW) & LMASK) < 64u; }
 KZG_HD void fp_select(Fp &r, bool take_b, const Fp &a, const Fp &b) {
 #pragma unroll
     for (int i = 0; i < NFP; i++) r.l[i] = take_b ? b.l[i] : a.l[i];
@@ -375,8 +376,27 @@ KZG_HD void fp_pow(Fp &r, const Fp &a, const uint32_t *e) {
 KZG_HD void fp_inv_fermat(Fp &r, const Fp &a) { const uint32_t e[12] = FP_EXP_INV_INIT; fp_pow(r, a, e); }
 // sqrt for p = 3 mod 4: a^((p+1)/4); false if a is not a square
 KZG_HD bool fp_sqrt(Fp &r, const Fp &a) {
+    // a^((p+1)/4), p = 3 mod 4.  Left-to-right over the 379-bit exponent with a sliding window of two bits ({a, a^3}: 378
+    // squarings + 143 products instead of + 228) on lazy products (no reduction below p until the end).
     const uint32_t e[12] = FP_EXP_SQRT_INIT;
-    Fp s, chk; fp_pow(s, a, e); fp_sqr(chk, s);
+    Fp a3, acc;
+    fp_sqr_lz(a3, a); fp_mul_lz(a3, a3, a);
+    bool started = false;
+    int i = 383;
+    while (i >= 0 && !((e[i >> 5] >> (i & 31)) & 1)) i--;
+    while (i >= 0) {
+        const bool b1 = (e[i >> 5] >> (i & 31)) & 1;
+        if (!b1) { fp_sqr_lz(acc, acc); i--; continue; }
+        const bool b0 = i >= 1 && ((e[(i - 1) >> 5] >> ((i - 1) & 31)) & 1);
+        if (b0) {
+            if (started) { fp_sqr_lz(acc, acc); fp_sqr_lz(acc, acc); fp_mul_lz(acc, acc, a3); } else { acc = a3; started = true; }
+            i -= 2;
+        } else {
+            if (started) { fp_sqr_lz(acc, acc); fp_mul_lz(acc, acc, a); } else { acc = a; started = true; }
+            i--;
+        }
+    }
+    Fp s, chk; fp_canon64(s, acc); fp_sqr(chk, s);
     r = s;
     return fp_eq(chk, a);
 }

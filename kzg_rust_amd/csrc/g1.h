@@ -210,19 +210,69 @@ KZG_HD void g1_mul_words(G1Jac &r, const G1Affine &p, const uint32_t *k, int nwo
 }
 
 // [|x|]P for the BLS parameter |x| = 0xd201000000010000 (64 bits, Hamming weight 6); P Jacobian.
+// ---- lazy (unreduced) Jacobian doubling / addition for the dependent chains (subgroup test, Horner, window ladders): no
+// reduction below p after any product, sum or difference; every routine states the bounds it needs and restores
+// (in units of p, limbs normalised).  Multiples of p are added before differences; products tolerate operands up to 64p.
+//   g1_dbl_lazy : in  X, Y, Z < 32p                      out X < 26p, Y < 18p, Z < 4p     (infinity stays Z = 0 mod p)
+//   g1_add_lazy : in  acc X, Y, Z < 32p, b canonical     out X < 8p,  Y < 4p,  Z < 2p
+//                 acc possibly at infinity / b = +-acc are caught by exact low-limb filters and redone canonically.
+KZG_G1_MID void g1_dbl_lazy(G1Jac &r, const G1Jac &p) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT, m16[NFP] = FP_MOD16_INIT, m32[NFP] = FP_MOD32_INIT;
+    Fp A, B, C, D, E, F, t, u;
+    fp_sqr_lz(A, p.x);
+    fp_sqr_lz(B, p.y);
+    fp_sqr_lz(C, B);
+    fp_add_lz(t, p.x, B); fp_sqr_lz(t, t);                       // (X + B)^2                      < 2p
+    fp_sub_lz(u, t, A, m2); fp_sub_lz(t, u, C, m2);              //  ... - A - C + 4p              in (0, 6p)
+    fp_add_lz(D, t, t);                                          // D                              < 12p
+    fp_add_lz(E, A, A); fp_add_lz(E, E, A);                      // E = 3A                         < 6p
+    fp_sqr_lz(F, E);
+    fp_mul_lz(u, p.y, p.z);                                      // before x, y are overwritten (r may alias p)
+    Fp X3, Y3;
+    fp_sub_lz(t, F, D, m16); fp_sub_lz(X3, t, D, m8);            // F - 2D + 24p                   in (0, 26p)
+    fp_sub_lz(t, D, X3, m32);                                    // D - X3 + 32p                   in (6p, 44p)
+    fp_mul_lz(Y3, E, t);
+    fp_add_lz(C, C, C); fp_add_lz(C, C, C); fp_add_lz(C, C, C);  // 8C                             < 16p
+    fp_sub_lz(r.y, Y3, C, m16);                                  //                                in (0, 18p)
+    r.x = X3;
+    fp_add_lz(r.z, u, u);                                        //                                < 4p
+}
+KZG_G1_MID void g1_add_lazy(G1Jac &r, const G1Jac &a, const G1Jac &b) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT;
+    Fp Z1Z1, Z2Z2, U1, U2, S1, S2, H, R;
+    fp_sqr_lz(Z1Z1, a.z); fp_sqr_lz(Z2Z2, b.z);
+    fp_mul_lz(U1, a.x, Z2Z2); fp_mul_lz(U2, b.x, Z1Z1);
+    fp_mul_lz(S1, a.y, b.z); fp_mul_lz(S1, S1, Z2Z2);
+    fp_mul_lz(S2, b.y, a.z); fp_mul_lz(S2, S2, Z1Z1);
+    fp_sub_lz(H, U2, U1, m2);                                    // in (0, 4p)
+    fp_sub_lz(R, S2, S1, m2);
+    if (fp_maybe_zero_lz(H) || fp_maybe_zero_lz(a.z) || g1_is_inf(b)) {          // rare: the complete canonical addition
+        G1Jac c; fp_canon64(c.x, a.x); fp_canon64(c.y, a.y); fp_canon64(c.z, a.z);
+        g1_add(r, c, b);
+        return;
+    }
+    Fp HH, HHH, V, t, u;
+    fp_sqr_lz(HH, H); fp_mul_lz(HHH, H, HH); fp_mul_lz(V, U1, HH);
+    Fp X3, Y3, Z3;
+    fp_sqr_lz(X3, R);
+    fp_sub_lz(t, X3, HHH, m2); fp_sub_lz(u, t, V, m2); fp_sub_lz(X3, u, V, m2);        // in (0, 8p)
+    fp_sub_lz(t, V, X3, m8);                                                            // in (0, 10p)
+    fp_mul_lz(Y3, R, t);
+    fp_mul_lz(t, S1, HHH); fp_sub_lz(Y3, Y3, t, m2);                                    // in (0, 4p)
+    fp_mul_lz(Z3, a.z, b.z); fp_mul_lz(Z3, Z3, H);
+    r.x = X3; r.y = Y3; r.z = Z3;
+}
+KZG_HD void g1_canon_lazy(G1Jac &r, const G1Jac &a) { fp_canon64(r.x, a.x); fp_canon64(r.y, a.y); fp_canon64(r.z, a.z); }
+
+// [|x|] P for the BLS parameter |x| = 0xd201000000010000 (weight 6), lazy chain, canonical result.  p canonical.
 KZG_HD void g1_mul_x_abs(G1Jac &r, const G1Jac &p) {
     G1Jac acc = p;                       // top bit
     for (int i = 62; i >= 0; i--) {
-        g1_dbl(acc, acc);
-        if ((BLS_X_ABS >> i) & 1) g1_add(acc, acc, p);
+        g1_dbl_lazy(acc, acc);
+        if ((BLS_X_ABS >> i) & 1) g1_add_lazy(acc, acc, p);
     }
-    r = acc;
+    g1_canon_lazy(r, acc);
 }
-
-// Subgroup membership (the predicate blst_p1_in_g1 decides, utils.rs:303):  P in G1  <=>  phi(P) == -[x^2]P,
-// phi(x,y) = (beta x, y).  "=>": phi acts on G1 as the eigenvalue -x^2 (checked on the generator by gen_constants.py).
-// "<=": phi^2 + phi + 1 = 0 on E, so phi(P) = [-x^2]P forces [x^4 - x^2 + 1]P = [r]P = infinity, and the r-torsion
-// of E(Fp) is exactly G1.  Two sparse 64-bit multiplications instead of one dense 255-bit one.
 KZG_HD bool g1_in_subgroup(const G1Affine &p) {
     if (g1a_is_inf(p)) return true;
     G1Jac pj, t;

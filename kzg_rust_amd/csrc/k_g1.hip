@@ -249,11 +249,13 @@ __global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1
     if (id >= 2 * groups) return;
     const int g = id >> 1, cls = id & 1;
     const G1Jac *s = S + ((size_t)g * 2 + cls) * LC_WINDOWS;
-    G1Jac acc = s[LC_WINDOWS - 1];
-    for (int w = LC_WINDOWS - 2; w >= 0; w--) {
-        g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc);
-        G1Jac v = s[w]; g1_add(acc, acc, v);
+    G1Jac acc = s[LC_WINDOWS - 1];                   // lazy chain (g1.h): no reductions until the end
+#pragma unroll 1
+    for (int k = 4 * (LC_WINDOWS - 1) - 1; k >= 0; k--) {         // one doubling body, one addition body
+        g1_dbl_lazy(acc, acc);
+        if ((k & 3) == 0) { G1Jac v = s[k >> 2]; g1_add_lazy(acc, acc, v); }
     }
+    g1_canon_lazy(acc, acc);
     G1Affine a; g1_to_affine(a, acc);
     if (cls == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[2 * (size_t)g + cls] = a;

@@ -112,6 +112,26 @@ int hd_g1x_sum_lazy(uint8_t *out, const uint8_t *pts48, int n) {
     G1Jac j; g1x_to_jac(j, c);
     G1Affine a; g1_to_affine(a, j); g1_compress_affine(out, a); return 0;
 }
+// Horner sum_i 16^i P_i (i = n-1 .. 0) with the lazy doubling / addition chain (lazy = 1) or the canonical one; the points
+// enter as Jacobian with a non-trivial z (doubled once and halved back is overkill: lifted by z = x-coordinate of P_0)
+int hd_horner(uint8_t *out, const uint8_t *pts48, int n, int lazy) {
+    std::vector<G1Jac> v(n);
+    for (int i = 0; i < n; i++) {
+        G1Affine p; if (g1_decompress(p, pts48 + 48 * i)) return 1;
+        g1_from_affine(v[i], p);
+        if (!g1a_is_inf(p)) {                                  // (x, y, 1) -> (x l^2, y l^3, l), l = 5 + i
+            Fp l = fp_one(), t; for (int k = 0; k < 4 + i; k++) fp_add(l, l, fp_one());
+            fp_sqr(t, l); fp_mul(v[i].x, v[i].x, t); fp_mul(t, t, l); fp_mul(v[i].y, v[i].y, t); v[i].z = l;
+        }
+    }
+    G1Jac acc = v[n - 1];
+    for (int w = n - 2; w >= 0; w--) {
+        if (lazy) { for (int k = 0; k < 4; k++) g1_dbl_lazy(acc, acc); g1_add_lazy(acc, acc, v[w]); }
+        else { for (int k = 0; k < 4; k++) g1_dbl(acc, acc); g1_add(acc, acc, v[w]); }
+    }
+    if (lazy) g1_canon_lazy(acc, acc);
+    G1Affine a; g1_to_affine(a, acc); g1_compress_affine(out, a); return 0;
+}
 // out = P + Q using the Jacobian+Jacobian routine (both lifted with a non-trivial z)
 int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
     G1Affine pa, qa, ra; G1Jac pj, qj, r;

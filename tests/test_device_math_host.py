@@ -249,3 +249,39 @@ def test_g1_xyzz_accumulator(hd, oracle, setup_bytes):
     a, b = C.create_string_buffer(48), C.create_string_buffer(48)
     assert hd.hd_g1x_sum(a, b"".join(pts), len(pts)) == 0 and hd.hd_g1x_sum_lazy(b, b"".join(pts), len(pts)) == 0
     assert a.raw == b.raw
+
+
+def test_subgroup_check_on_small_order_and_random_curve_points(hd):
+    """The lazy [x^2]P chain behind g1_in_subgroup must agree with [r]P == infinity (return code 99 flags a disagreement) on
+    points that are ON the curve but OUTSIDE G1: random curve points (order divisible by cofactor primes) and points of small
+    order 3, 11, 33 (the chain runs through infinity and P = +-Q additions there), plus their sums with G1 points."""
+    import random
+    from oracle import pyref as pr
+    rnd = random.Random(381)
+    H = 0x396c8c005555e1568c00aaab0000aaab                 # cofactor of E(Fp)
+    def random_curve_point():
+        while True:
+            x = rnd.randrange(pr.P)
+            y2 = (x * x * x + 4) % pr.P
+            y = pow(y2, (pr.P + 1) // 4, pr.P)
+            if y * y % pr.P == y2:
+                return (x, y)
+    n_out = 0
+    gen = pr.g1_uncompress(bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"))
+    for trial in range(12):
+        T = random_curve_point()
+        cands = [T]
+        full = pr.g1_mul(T, pr.R)                          # kills the G1 component: order divides the cofactor
+        for q in (3, 11, 33):
+            S = pr.g1_mul(full, H // q) if full is not None else None
+            if S is not None:
+                cands += [S, pr.g1_add(S, gen), pr.g1_add(S, pr.g1_mul(gen, 12345))]
+        for pt in cands:
+            if pt is None:
+                continue
+            out = C.create_string_buffer(48)
+            rc = hd.hd_g1_validate(out, pr.g1_compress(pt), 1)
+            in_g1 = pr.g1_mul(pt, pr.R) is None
+            assert rc == (0 if in_g1 else 3), (trial, rc, in_g1)
+            n_out += not in_g1
+    assert n_out >= 20
