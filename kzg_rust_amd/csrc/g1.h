@@ -356,15 +356,22 @@ KZG_HD void g1_mul128_w4(G1Jac &r, const G1Affine &p, const uint32_t k[4], uint3
     e4[4] = (uint32_t)c;                                   // 0 or 1: the 33rd digit (unbiased)
     G1Jac acc = g1_inf();
     if (e4[4]) w4_load(acc, tab, 0, lane);                 // top digit 1 -> P
-    for (int nib = 31; nib >= 0; nib--) {
-        g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc); g1_dbl(acc, acc);
-        const int d = (int)((e4[nib >> 3] >> (4 * (nib & 7))) & 15u) - 8;
-        const int mag = d < 0 ? -d : d;
-        G1Jac q = g1_inf();
-        if (mag) { w4_load(q, tab, mag - 1, lane); if (d < 0) fp_neg(q.y, q.y); }
-        g1_add(acc, acc, q);
+    // lazy chain (no reductions until the end); one doubling body and one addition body in the instruction stream
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int step = 127; step >= 0; step--) {
+        g1_dbl_lazy(acc, acc);
+        if ((step & 3) == 0) {
+            const int nib = step >> 2;
+            const int d = (int)((e4[nib >> 3] >> (4 * (nib & 7))) & 15u) - 8;
+            const int mag = d < 0 ? -d : d;
+            G1Jac q = g1_inf();
+            if (mag) { w4_load(q, tab, mag - 1, lane); if (d < 0) fp_neg(q.y, q.y); }
+            g1_add_lazy(acc, acc, q);
+        }
     }
-    r = acc;
+    g1_canon_lazy(r, acc);
 }
 
 // ZCash compressed encoding of an affine point ((0,0) = infinity)
