@@ -128,7 +128,8 @@ KZG_HD void wide_double(uint64_t *acc) {
 #pragma unroll
     for (int i = 0; i < 2 * NFP; i++) acc[i] <<= 1;
 }
-// Montgomery reduction of a carried accumulator holding T < 16 p^2:  r = T / 2^406 mod p, canonical.
+// Montgomery reduction of a carried accumulator holding T < 2^20 p^2:  r = T / 2^406 mod p, LAZY: r < p (1 + 2^-5), not
+// reduced below p (the coefficients of an Fp12W stay unreduced, < 32p, between operations; see coop_fold).
 KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
     const uint32_t m[NFP] = FP_MOD_INIT;
 #pragma unroll
@@ -138,13 +139,9 @@ KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
         for (int j = 0; j < NFP; j++) acc[i + j] += (uint64_t)q * m[j];
         acc[i + 1] += acc[i] >> LB;
     }
-    uint32_t t[NFP], s[NFP];
     uint64_t c = 0;
 #pragma unroll
-    for (int j = 0; j < NFP; j++) { c += acc[NFP + j]; t[j] = (uint32_t)c & LMASK; c >>= LB; }
-    const uint32_t br = ul_sub<NFP>(s, t, m);
-#pragma unroll
-    for (int j = 0; j < NFP; j++) r.l[j] = br ? t[j] : s[j];
+    for (int j = 0; j < NFP; j++) { c += acc[NFP + j]; r.l[j] = j < NFP - 1 ? ((uint32_t)c & LMASK) : (uint32_t)c; c >>= LB; }
 }
 
 // ---------------------------------------------------------------------------------- cooperative Fp12 operations
@@ -153,16 +150,19 @@ KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
 //     k >= 6:  c_k = d_k + 2 (d_{k+12} + d_{k+6})           (d_23 = 0)
 // written without lane-dependent branches (a wave would execute every branch body one after the other).
 KZG_HD void coop_fold(Fp12W &dst, const Fp *d, int k) {
+    // lazy: d_s < 2p in, c_k < 18p out (k <= 5: d_k + 16p - 2 (v + 2x) with v, x < 2p; k >= 6: d_k + 2 (v + x) < 10p)
+    const uint32_t m16[NFP] = FP_MOD16_INIT;
     const bool low = k <= 5;
     const Fp zero = fp_zero();
-    Fp v, x, y;
+    Fp v, x, y, s2, lo, hi;
     fp_select(v, k <= 10, zero, d[k + 12 <= 22 ? k + 12 : 22]);            // d_{k+12} or 0
     fp_select(x, low, d[low ? 0 : k + 6], d[k <= 4 ? k + 18 : 0]);          // low: d_{k+18} (k <= 4), else d_{k+6}
     if (k == 5) x = zero;
-    fp_dbl(y, x); fp_select(x, low, x, y);                                  // low: 2 d_{k+18}
-    fp_add(v, v, x); fp_dbl(v, v);                                          // 2 ( ... )
-    fp_neg(y, v); fp_select(v, low, v, y);
-    fp_add(dst.c[k], d[k], v);
+    fp_add_lz(y, x, x); fp_select(x, low, x, y);                            // low: 2 d_{k+18}
+    fp_add_lz(v, v, x); fp_add_lz(s2, v, v);                                // 2 ( ... )            < 12p
+    fp_sub_lz(lo, d[k], s2, m16);                                           // d_k + 16p - 2 (...)  in (4p, 18p)
+    fp_add_lz(hi, d[k], s2);                                                //                      < 14p
+    fp_select(dst.c[k], low, hi, lo);
 }
 
 // Phases 1 and 2 of every product.  Phase 1: every lane accumulates its <= 3 limb products (unreduced 64-bit columns),
@@ -225,7 +225,12 @@ KZG_HD void coop_set_one(Fp12W &dst) {
 // conjugation = p^6-power Frobenius: w -> -w
 KZG_HD void coop_conj(Fp12W &dst, const Fp12W &a) {
     COOP_LANES(lane) {
-        if (lane < 12) { Fp t = a.c[lane]; if (lane & 1) fp_neg(t, t); dst.c[lane] = t; }
+        if (lane < 12) {                                         // odd k: 32p - a_k (coefficients are lazy, < 32p)
+            const uint32_t m32[NFP] = FP_MOD32_INIT;
+            Fp t = a.c[lane];
+            if (lane & 1) { const Fp z = fp_zero(); fp_sub_lz(t, z, t, m32); }
+            dst.c[lane] = t;
+        }
     }
     COOP_SYNC();
 }
@@ -238,9 +243,10 @@ KZG_HD void coop_frob(Fp12W &dst, const Fp12W &a, const Fp *tabA, const Fp *tabB
     COOP_LANES(lane) {
         if (lane < 12) {
             Fp x, y;
-            fp_mul(x, a.c[lane], tabA[lane]);
-            if (lane < 6) { fp_mul(y, a.c[lane + 6], tabB[lane]); fp_dbl(y, y); fp_sub(x, x, y); }
-            else { fp_mul(y, a.c[lane - 6], tabB[lane]); fp_add(x, x, y); }
+            const uint32_t m4[NFP] = FP_MOD4_INIT;
+            fp_mul_lz(x, a.c[lane], tabA[lane]);
+            if (lane < 6) { fp_mul_lz(y, a.c[lane + 6], tabB[lane]); fp_add_lz(y, y, y); fp_sub_lz(x, x, y, m4); }
+            else { fp_mul_lz(y, a.c[lane - 6], tabB[lane]); fp_add_lz(x, x, y); }
             dst.c[lane] = x;
         }
     }
@@ -252,7 +258,8 @@ KZG_HD bool coop_is_one(CoopMem &m, const Fp12W &a) {
     COOP_LANES(lane) {
         if (lane < 12) {
             const Fp want = lane == 0 ? fp_one() : fp_zero();
-            if (!fp_eq(a.c[lane], want)) m.flag = 0;
+            Fp c; fp_canon64(c, a.c[lane]);
+            if (!fp_eq(c, want)) m.flag = 0;
         }
     }
     COOP_SYNC();
@@ -265,9 +272,10 @@ KZG_HD void coop_fp6_inv(Fp12W &x) {
         if (lane == 0) {
             Fp6 n, ni;
             Fp2 *nc[3] = {&n.c0, &n.c1, &n.c2};
-            for (int j = 0; j < 3; j++) {              // (x0 + x1 u) v^j  <-  w^(2j): x0 - x1, w^(2j+6): x1
-                nc[j]->c1 = x.c[2 * j + 6];
-                fp_add(nc[j]->c0, x.c[2 * j], x.c[2 * j + 6]);
+            for (int j = 0; j < 3; j++) {              // (x0 + x1 u) v^j  <-  w^(2j): x0 - x1, w^(2j+6): x1   (lazy -> canonical first)
+                Fp lo, hi; fp_canon64(lo, x.c[2 * j]); fp_canon64(hi, x.c[2 * j + 6]);
+                nc[j]->c1 = hi;
+                fp_add(nc[j]->c0, lo, hi);
             }
             fp6_inv(ni, n);
             const Fp2 *ic[3] = {&ni.c0, &ni.c1, &ni.c2};
@@ -286,7 +294,7 @@ struct FrobTables { Fp a1[12], b1[12], a2[12]; };     // power-1 tables and the 
 // p^2-power Frobenius: gamma = xi^((p^2-1)/6) is a 6th root of unity in Fp, so it is a plain coefficient scaling.
 KZG_HD void coop_frob2(Fp12W &dst, const Fp12W &a, const Fp *tab) {
     COOP_LANES(lane) {
-        if (lane < 12) { Fp x; fp_mul(x, a.c[lane], tab[lane]); dst.c[lane] = x; }
+        if (lane < 12) { Fp x; fp_mul_lz(x, a.c[lane], tab[lane]); dst.c[lane] = x; }
     }
     COOP_SYNC();
 }
