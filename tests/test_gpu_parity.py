@@ -549,3 +549,25 @@ def test_msm_launch_shapes_agree(kz, settings, random_set):
     p_all = prove(0, n, c_all)
     assert [p_all[48 * i:48 * i + 48] for i in range(len(blobs))] == ps
     assert b"".join(prove(lo, lo + 64, c_all[48 * lo:48 * (lo + 64)]) for lo in range(0, n, 64)) == p_all
+
+
+def test_wide_table_digit_extremes(kz, settings, oracle, oracle_settings):
+    """Scalars built to hit the corners of the signed 12-bit recoding of the wide-table MSM: every window 0x800 (digit -2048 with a
+    carry chain through all 22 windows), 0x7ff (largest positive digit), 0xfff / 0x001 alternating, a lone top-window bit, and
+    r - 1 next to 0 and 1 -- commitments and proofs must be the oracle's."""
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    def windows(vals):                       # little-endian list of 12-bit window values -> scalar reduced below r
+        return sum(v << (12 * i) for i, v in enumerate(vals)) % R
+    pats = [windows([0x800] * 21), windows([0x7FF] * 21), windows([0xFFF, 0x001] * 10 + [0xFFF]), 1 << 252, (1 << 252) - 1,
+            R - 1, 0, 1, windows([0x800] * 20 + [0x7FF]), windows([0] * 20 + [0x800]), (1 << 254) + (1 << 12) - 1]
+    assert all(0 <= p < R for p in pats)
+    blobs = [b"".join(pats[(i + s) % len(pats)].to_bytes(32, "big") for i in range(4096)) for s in (0, 3)]
+    blobs.append(pats[0].to_bytes(32, "big") * 4096)
+    cs = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], settings)
+    for b, c in zip(blobs, cs):
+        assert c.to_bytes() == oracle.blob_to_kzg_commitment(b, oracle_settings)
+    ps = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], cs, settings)
+    for b, c, p in zip(blobs, cs, ps):
+        assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
+    one = kz.Kzg.blob_to_kzg_commitment(kz.Blob(blobs[0]), settings)          # the lone-blob launch shape (two window parts)
+    assert one.to_bytes() == cs[0].to_bytes()
