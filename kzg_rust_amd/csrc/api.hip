@@ -430,7 +430,10 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     {   // the 23.6 GB wide-window MSM table (KZG355_MSM=bucket keeps the 15 MB 8-bit form only; so does a failed allocation)
         const char *e = getenv("KZG355_MSM");
         if (!(e && strcmp(e, "bucket") == 0)) {
-            if (s->wide.ensure(wide_table_bytes()) == KZG355_OK) {
+            int bits = 12;
+            if (const char *b = getenv("KZG355_MSM_BITS")) { const int v = atoi(b); if (v >= 10 && v <= 14) bits = v; }
+            s->t.wide = wide_shape(bits);
+            if (s->wide.ensure(wide_table_bytes(s->t.wide)) == KZG355_OK) {
                 s->t.wide_table = s->wide.as<WideRow>();
                 if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; } }
             } else if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; }

@@ -2,11 +2,12 @@
 // g1_lincomb_fast -> blst_p1s_mult_pippenger over the 4096 trusted-setup points; called from src/kzg.rs:397 and :524) with
 // the table sized for an MI355X's 288 GB of HBM instead of a CPU cache:
 //
-//     wide[w][i][m-1] = m * 2^(12 w) * g1_values[i]        w < 22,  i < 4096,  m = 1..2048       (affine, 128-byte rows)
+//     wide[w][i][m-1] = m * 2^(c w) * g1_values[i]        w < ceil(256 / c),  i < 4096,  m = 1..2^(c-1)     (affine, 128-byte rows)
 //
-// = 22 x 4096 x 2048 x 128 B = 23.6 GB, built once by load_trusted_setup.  With signed 12-bit digits d_w in [-2048, 2047]
+// c = 12: 22 x 4096 x 2048 x 128 B = 23.6 GB (c = 13: 42.9 GB, c = 14: 81.6 GB; KZG355_MSM_BITS), built once by
+// load_trusted_setup.  With signed c-bit digits d_w in [-2^(c-1), 2^(c-1) - 1]
 //     sum_i s_i P_i = sum_i sum_w sign(d_{w,i}) * wide[w][i][|d_{w,i}| - 1]
-// is a plain sum of 22 x 4096 = 90,112 table rows per blob: no buckets, no doublings, no sorting, no digit buffer -- one
+// is a plain sum of ceil(256 / c) x 4096 table rows per blob (90,112 for c = 12): no buckets, no doublings, no sorting, no digit buffer -- one
 // 128-byte gather and one mixed addition per row (the 8-bit bucket form in k_msm.hip needs 131,072 additions plus 32 bucket
 // reductions per blob and a 131 KB digit pass).  ~11.5 MB of random 128-byte HBM reads per blob.
 //   k_wide_base / k_wide_rows   setup: row 1 from the 8-bit table (k_setup.hip), then the 2048 multiples in 8 segments of
@@ -31,12 +32,12 @@ __device__ __forceinline__ G1Jac g1_shfl_xor_w(const G1Jac &v, int mask) {
 }
 
 // ------------------------------------------------------------------------------------------------ setup
-// row 1 of every (w, i): 2^(12 w) P_i = 2^r * table8[(12 w) >> 3][i], r = (12 w) & 7 in {0, 4}
-__global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRow *wide, int w_lo, int w_n) {
+// row 1 of every (w, i): 2^(c w) P_i = 2^r * table8[(c w) >> 3][i], r = (c w) & 7
+__global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRow *wide, WideShape ws, int w_lo, int w_n) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= w_n * N_FE) return;
     const int w = w_lo + id / N_FE, i = id % N_FE;
-    const int bits = WIDE_BITS * w, w8 = bits >> 3, r = bits & 7;
+    const int bits = ws.bits * w, w8 = bits >> 3, r = bits & 7;
     G1Affine q = table8[(size_t)w8 * N_FE + i];
     if (r) {
         G1Jac j; g1_from_affine(j, q);
@@ -45,18 +46,18 @@ __global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRo
     }
     WideRow row; row.x = q.x; row.y = q.y;
     for (int k = 0; k < 4; k++) row.pad[k] = 0;
-    wide[((size_t)w * N_FE + i) * WIDE_ROWS] = row;
+    wide[((size_t)w * N_FE + i) * ws.rows] = row;
 }
 // rows m = 256 seg + 1 .. 256 seg + 256 of (w, i), one lane per (w, i, seg):  Jacobian run acc += Q (parked in `jac`, with
 // the running product of the z's in `pre`), ONE inversion, then backwards: z_k^-1 = inv * pre_{k-1}, inv *= z_k.
 constexpr int WIDE_SEG = 256;
-__global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp *pre, int w_lo, int w_n) {
+__global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp *pre, WideShape ws, int w_lo, int w_n) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int SEGS = WIDE_ROWS / WIDE_SEG;
+    const int SEGS = ws.rows / WIDE_SEG;
     if (id >= w_n * N_FE * SEGS) return;
     const int seg = id % SEGS, pi = id / SEGS;
     const int w = w_lo + pi / N_FE, i = pi % N_FE;
-    WideRow *rows = wide + ((size_t)w * N_FE + i) * WIDE_ROWS;
+    WideRow *rows = wide + ((size_t)w * N_FE + i) * ws.rows;
     G1Affine q; q.x = rows[0].x; q.y = rows[0].y;
     G1Jac *myj = jac + (size_t)id * WIDE_SEG;
     Fp *myp = pre + (size_t)id * WIDE_SEG;
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp 
     if (seg) {
         G1Jac b; g1_from_affine(b, q);
         for (int k = 0; k < 8; k++) g1_dbl(b, b);                 // 256 Q
-        for (int bit = 2; bit >= 0; bit--) { g1_dbl(acc, acc); if ((seg >> bit) & 1) g1_add(acc, acc, b); }
+        for (int bit = 5; bit >= 0; bit--) { g1_dbl(acc, acc); if ((seg >> bit) & 1) g1_add(acc, acc, b); }      // seg < 64
     }
     Fp run = fp_one();
     for (int k = 0; k < WIDE_SEG; k++) {
@@ -94,21 +95,23 @@ __global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp 
 
 // ------------------------------------------------------------------------------------------------ the MSM
 // signed 12-bit digits of a 256-bit integer (8 little-endian words): d_w in [-2048, 2047], top digit small and >= 0
-__device__ __forceinline__ int wide_raw_digit(const uint32_t s[8], int w) {
-    const int bit = WIDE_BITS * w, wi = bit >> 5, sh = bit & 31;
+__device__ __forceinline__ int wide_raw_digit(const uint32_t s[8], int w, int bits) {
+    const int bit = bits * w, wi = bit >> 5, sh = bit & 31;
+    if (wi >= 8) return 0;
     uint32_t v = s[wi] >> sh;
-    if (sh > 32 - WIDE_BITS && wi + 1 < 8) v |= s[wi + 1] << (32 - sh);
-    return (int)(v & ((1u << WIDE_BITS) - 1));
+    if (sh > 32 - bits && wi + 1 < 8) v |= s[wi + 1] << (32 - sh);
+    return (int)(v & ((1u << bits) - 1));
 }
 
 template <bool FROM_FR>
-__global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr *scalars, const WideRow *wide, G1Jac *partials, int *err,
+__global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr *scalars, const WideRow *wide, WideShape ws, G1Jac *partials, int *err,
                                                    int spl /* scalars per lane */, int parts /* window parts */) {
     __shared__ G1Jac red[4];
     const int chunks = N_FE / (256 * spl), wgpb = chunks * parts;
     const int blob = blockIdx.x / wgpb, wg = blockIdx.x % wgpb, chunk = wg / parts, part = wg % parts;
     const int tid = threadIdx.x;
-    const int w_lo = (WIDE_WINDOWS * part) / parts, w_hi = (WIDE_WINDOWS * (part + 1)) / parts;
+    const int w_lo = (ws.windows * part) / parts, w_hi = (ws.windows * (part + 1)) / parts;
+    const int half = ws.rows;                                    // 2^(c-1): digits run over [-half, half - 1]
     G1X accx = g1x_inf(); bool started = false;                   // lazy extended-Jacobian accumulator: 8M + 2S per row, no reductions
     WideRow cur; bool have = false; bool cur_neg = false;
     bool bad = false;
@@ -119,15 +122,15 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
         if (FROM_FR) fr_to_words(s, scalars[(size_t)blob * N_FE + i]);
         else { load_blob_element_words(s, blobs + (size_t)BLOB_BYTES * blob, i); bad = bad || !fr_words_canonical(s); }
         int carry = 0;
-        for (int w = 0; w < w_lo; w++) { const int raw = wide_raw_digit(s, w) + carry; carry = raw > 2047; }
+        for (int w = 0; w < w_lo; w++) { const int raw = wide_raw_digit(s, w, ws.bits) + carry; carry = raw >= half; }
 #pragma unroll 1
         for (int w = w_lo; w < w_hi; w++) {
-            int d = wide_raw_digit(s, w) + carry;
-            carry = (w < WIDE_WINDOWS - 1) && d > 2047;
-            if (carry) d -= 4096;
+            int d = wide_raw_digit(s, w, ws.bits) + carry;
+            carry = (w < ws.windows - 1) && d >= half;
+            if (carry) d -= 2 * half;
             if (d == 0) continue;
             const int m = d < 0 ? -d : d;
-            const WideRow nxt = wide[((size_t)w * N_FE + i) * WIDE_ROWS + (m - 1)];      // in flight during the addition below
+            const WideRow nxt = wide[((size_t)w * N_FE + i) * ws.rows + (m - 1)];      // in flight during the addition below
             if (have) {
                 G1Affine p; p.x = cur.x; p.y = cur.y;
                 if (cur_neg) fp_neg(p.y, p.y);
@@ -156,18 +159,19 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-size_t wide_table_bytes() { return sizeof(WideRow) * (size_t)WIDE_WINDOWS * N_FE * WIDE_ROWS; }
-// Builds the table two windows at a time (scratch: 2 x 4096 x 2048 Jacobian points + z products = 3.8 GB, freed afterwards).
+size_t wide_table_bytes(WideShape ws) { return sizeof(WideRow) * (size_t)ws.windows * N_FE * ws.rows; }
+// Builds the table one or two windows at a time; the scratch is freed afterwards.
 int build_wide_table(DeviceTables t, hipStream_t st) {
-    constexpr int SLAB = 2;
-    const size_t runs = (size_t)SLAB * N_FE * (WIDE_ROWS / WIDE_SEG);
+    const WideShape ws = t.wide;
+    const int SLAB = ws.rows <= 2048 ? 2 : 1;                      // scratch: SLAB x 4096 x rows Jacobian points + z products (3.8 GB at c = 12)
+    const size_t runs = (size_t)SLAB * N_FE * (ws.rows / WIDE_SEG);
     G1Jac *jac = nullptr; Fp *pre = nullptr;
     if (hipMalloc(&jac, sizeof(G1Jac) * runs * WIDE_SEG) != hipSuccess) return 1;
     if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { hipFree(jac); return 1; }
-    for (int w = 0; w < WIDE_WINDOWS; w += SLAB) {
-        const int wn = w + SLAB <= WIDE_WINDOWS ? SLAB : WIDE_WINDOWS - w;
-        hipLaunchKernelGGL(k_wide_base, dim3((wn * N_FE + 63) / 64), dim3(64), 0, st, t.msm_table, t.wide_table, w, wn);
-        hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)((wn * N_FE * (WIDE_ROWS / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, t.wide_table, jac, pre, w, wn);
+    for (int w = 0; w < ws.windows; w += SLAB) {
+        const int wn = w + SLAB <= ws.windows ? SLAB : ws.windows - w;
+        hipLaunchKernelGGL(k_wide_base, dim3((wn * N_FE + 63) / 64), dim3(64), 0, st, t.msm_table, t.wide_table, ws, w, wn);
+        hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)wn * N_FE * (ws.rows / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, t.wide_table, jac, pre, ws, w, wn);
     }
     const hipError_t e = hipStreamSynchronize(st);
     hipFree(jac); hipFree(pre);
@@ -185,8 +189,8 @@ void launch_msm_wide(const uint8_t *d_blobs, const Fr *d_scalars, DeviceTables t
     if (n <= 0) return;
     int spl, parts; msm_wide_shape(n, &spl, &parts);
     const int wgpb = N_FE / (256 * spl) * parts;
-    if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, d_partials, d_err, spl, parts);
-    else hipLaunchKernelGGL(k_msm_wide<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, d_partials, d_err, spl, parts);
+    if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
+    else hipLaunchKernelGGL(k_msm_wide<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
 }
 
 }  // namespace kzg

@@ -20,10 +20,10 @@ constexpr int RECORD_BYTES = 160;          // C | z | y | proof  (utils.rs:454-4
 constexpr int MSM_WINDOW_BITS = 8;
 constexpr int MSM_WINDOWS = 32;            // 32 x 8 bits cover the 255-bit scalars
 constexpr int MSM_BUCKETS = 128;           // signed digits in [-127, 128]
-// wide-window form of the same MSM (k_msm_wide.hip): 22 signed 12-bit digits, every multiple 1..2048 tabulated
-constexpr int WIDE_BITS = 12;
-constexpr int WIDE_WINDOWS = 22;
-constexpr int WIDE_ROWS = 2048;
+// wide-window form of the same MSM (k_msm_wide.hip): signed c-bit digits, every multiple 1..2^(c-1) tabulated; c is chosen when
+// the handle is created (12: 22 windows, 23.6 GB; 13: 20 windows, 42.9 GB; 14: 19 windows, 81.6 GB)
+struct WideShape { int bits, windows, rows; };
+inline WideShape wide_shape(int bits) { WideShape w; w.bits = bits; w.windows = (256 + bits - 1) / bits; w.rows = 1 << (bits - 1); return w; }
 constexpr int N_G2 = 65;
 
 // error bits accumulated on the device; any bit => the call returns Err (reference: `?` on each step)
@@ -37,6 +37,7 @@ struct alignas(128) WideRow { Fp x, y; uint32_t pad[4]; };       // one affine p
 struct DeviceTables {
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
     EvalGroupTab *eval_tab;  // [1024] per group of four domain points: w^-1, w^4 (eval_core.h)
+    WideShape wide;          // shape of wide_table
     WideRow *wide_table;        // [22][4096][2048] multiples m * 2^(12w) * g1_values[i], 23.6 GB; null: 8-bit bucket form only
     G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)
     LineCoeff *lines;        // [3][68]: Miller-loop lines of G2_GENERATOR, setup g2[0], setup g2[1]
@@ -82,7 +83,7 @@ void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups,
 void launch_lines_to_w(DeviceTables t, hipStream_t st);
 
 // ---- k_msm_wide.hip
-size_t wide_table_bytes();
+size_t wide_table_bytes(WideShape ws);
 int build_wide_table(DeviceTables t, hipStream_t st);                 // needs t.msm_table; 0 on success
 int msm_wide_partials_per_blob(int n);
 // scalars from blobs (canonical check fused, err per blob) or, if d_scalars != null, from Montgomery field elements

@@ -418,17 +418,22 @@ def test_msm_bucket_form_matches_wide_table_form(kz, setup_bytes, settings, rand
         sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
     finally:
         del os.environ["KZG355_MSM"]
+    os.environ["KZG355_MSM_BITS"] = "13"                 # a wider window of the table form (20 windows, 42.9 GB)
+    try:
+        s13 = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_MSM_BITS"]
     try:
         blobs, cs, ps = random_set
         B = [kz.Blob(b) for b in blobs]
         for n in (1, 5, len(blobs)):
-            for s in (sb, settings):
+            for s in (sb, settings, s13):
                 got = kz.Kzg.blob_to_kzg_commitment_many(B[:n], s)
                 assert [c.to_bytes() for c in got] == cs[:n]
                 gp = kz.Kzg.compute_blob_kzg_proof_many(B[:n], [kz.KzgCommitment(c) for c in cs[:n]], s)
                 assert [p.to_bytes() for p in gp] == ps[:n]
     finally:
-        sb.free()
+        sb.free(); s13.free()
 
 
 @pytest.mark.parametrize("n", [64, 512])
