@@ -520,7 +520,7 @@ def test_differential_batch_mutations(kz, settings, oracle, oracle_settings, ran
     assert seen[True] >= 3 and seen[False] >= 8 and seen[None] >= 8, seen
 
 
-def test_msm_launch_shapes_agree(kz, settings, random_set):
+def test_msm_launch_shapes_agree(kz, settings, random_set, setup_bytes):
     """The wide-table MSM picks its launch shape by blob count (1 or 2 window parts, 1 / 4 / 16 scalars per lane): 1024 blobs in
     one call (16 scalars per lane, one workgroup per blob) must give the commitments and proofs of the same blobs sent in
     calls of 64 and of 200 (other shapes), and the first ones must be the oracle's (random_set)."""
@@ -554,6 +554,20 @@ def test_msm_launch_shapes_agree(kz, settings, random_set):
     p_all = prove(0, n, c_all)
     assert [p_all[48 * i:48 * i + 48] for i in range(len(blobs))] == ps
     assert b"".join(prove(lo, lo + 64, c_all[48 * lo:48 * (lo + 64)]) for lo in range(0, n, 64)) == p_all
+    # and the independent 8-bit bucket kernels give the same 1024 commitments and proofs
+    g1, g2 = setup_bytes
+    os.environ["KZG355_MSM"] = "bucket"
+    try:
+        sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_MSM"]
+    try:
+        out = C.create_string_buffer(48 * n); st = (C.c_int * n)()
+        assert L.kzg355_blob_to_kzg_commitment_many_device(out, st, tb.data_ptr(), n, sb.handle) == 0 and out.raw == c_all
+        tc = torch.frombuffer(bytearray(c_all), dtype=torch.uint8).to(dev)
+        assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr(), tc.data_ptr(), n, sb.handle) == 0 and out.raw == p_all
+    finally:
+        sb.free()
 
 
 def test_wide_table_digit_extremes(kz, settings, oracle, oracle_settings):
