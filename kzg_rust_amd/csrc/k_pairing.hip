@@ -1,7 +1,7 @@
 // k_pairing.hip -- the pairing check of verify_kzg_proof_batch (reference src/utils.rs:189-214, called at kzg.rs:625)
 // as a wave-cooperative kernel: one 64-lane wave per batch, Fp12 coefficients spread over the lanes
 // (pairing_coop.h).  ~20x shorter dependent chain than the one-lane-per-batch kernel in k_verify.hip.
-#define KZG_MID_INLINE 1     // everything inline: no stack objects, no scratch (the out-of-line tower routines cost 1.5 KB of scratch per lane)
+#define KZG_FP_MUL_NOINLINE 1   // tower routines out of line: the interpreter bodies stay small (fully inlined, the kernel was ~6x larger and 25 % slower: 6.4 vs 4.85 ms per 2048 batches)
 #include "kernels.h"
 
 namespace kzg {
