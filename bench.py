@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="time the host-buffer drop-in entry point (H2D over PCIe inside the timed region); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-path", action="store_true",
+                    help="run the multi-GPU code path (two-stage HipEngine driver of sharded.py) even at world size 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,12 +148,12 @@ def main():
             rc = L.kzg355_verify_blob_kzg_proof_batch_many(ok, stg, h_blobs.ctypes.data_as(C.c_char_p), commitments, proofs, n_local, g, s.handle)
             assert rc == 0, rc
             assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
-        elif world == 1:
+        elif world == 1 and not args.sharded_path:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
             assert rc == 0, rc
             assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
         else:
-            # stage 1 on the local shard -> ONE all-gather of the 160-byte records (RCCL over xGMI) -> stage 2 replicated
+            # stage 1 on the local shard -> ONE all-gather of the 160-byte records (RCCL over xGMI) -> stage 2 on this rank's share of the batches
             oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
