@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 constexpr int LC_DIG_STRIDE = 36;
 constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
 __host__ __device__ inline int lc_items(int n) { return 2 * (3 * n + 1); }
-constexpr int LC_WAVES_PER_CLASS = 5;   // 33 windows / 8 tasks per wave
+constexpr int LC_WAVES_PER_CLASS = 3;   // windows 0-15, 16-31, and the carry window
 
 __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b, const uint32_t *scal_c, int n,
                                                  G1Affine *items, int8_t *digits) {
@@ -171,15 +171,22 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
 }
 
 // Lists: per task, item | sign << 15 grouped by bucket.  In LDS up to 128 blobs per batch; beyond that (multi-GPU batches of
-// 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~6,600 instructions either way.
+// 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~5,000 instructions either way.
+// Balance: a bucket list has 30 +- 5 items (258 items over 8 buckets), and with one list per lane a wave runs as long as its
+// longest list (~43).  So a wave takes SIXTEEN windows = 128 lists, ranks them by length and gives lane i the i-th longest
+// and the i-th shortest: every lane walks ~61 items.  The 128 bucket sums go through a global staging slab and are then
+// weighted and summed per window, 64 at a time.
+constexpr int LC_TASKS = 16;                     // windows per regular wave
 constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
 __host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
-__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
-    __shared__ uint16_t lists_lds[8][LC_LDS_LIST];
-    __shared__ int cnt[8][9], start[8][9], cursor[8][9];
+__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists, G1Jac *stage) {
+    __shared__ uint16_t lists_lds[LC_TASKS][LC_LDS_LIST];
+    __shared__ int cnt[LC_TASKS][9], start[LC_TASKS][9], cursor[LC_TASKS][9];
+    __shared__ uint8_t order[8 * LC_TASKS];
     const int g = blockIdx.x / (2 * LC_WAVES_PER_CLASS), wv = blockIdx.x % (2 * LC_WAVES_PER_CLASS), lane = threadIdx.x;
     const int cls = wv < LC_WAVES_PER_CLASS ? 1 : 0;
-    const int w0 = (wv % LC_WAVES_PER_CLASS) * 8;
+    const int sub = wv % LC_WAVES_PER_CLASS;                              // 0, 1: windows 16 sub .. 16 sub + 15;  2: the carry window
+    const int w0 = sub * LC_TASKS;
     const int ni = lc_items(n);
     const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;       // item range of the class (terms t < n are class 0)
     const G1Affine *it = items + (size_t)g * ni;
@@ -196,52 +203,77 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
     }
     const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
     const int stride = in_lds ? LC_LDS_LIST : lc_list_stride(n);
-    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + (size_t)blockIdx.x * 8 * stride;
-    for (int q = lane; q < 72; q += 64) cnt[q / 9][q % 9] = 0;
+    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + (size_t)blockIdx.x * LC_TASKS * stride;
+    for (int q = lane; q < 9 * LC_TASKS; q += 64) cnt[q / 9][q % 9] = 0;
     __syncthreads();
-    for (int tk = 0; tk < 8; tk++) {
+#pragma unroll 1
+    for (int tk = 0; tk < LC_TASKS; tk++) {
         const int w = w0 + tk;
-        if (w >= LC_WINDOWS) break;
         for (int j = lo + lane; j < hi; j += 64) { const int d = dg[(size_t)j * LC_DIG_STRIDE + w]; if (d) atomicAdd(&cnt[tk][d < 0 ? -d : d], 1); }
     }
     __syncthreads();
-    if (lane < 8) { int run = 0; for (int b = 1; b <= 8; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
+    if (lane < LC_TASKS) { int run = 0; for (int b = 1; b <= 8; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
     __syncthreads();
-    for (int tk = 0; tk < 8; tk++) {
+#pragma unroll 1
+    for (int tk = 0; tk < LC_TASKS; tk++) {
         const int w = w0 + tk;
-        if (w >= LC_WINDOWS) break;
         for (int j = lo + lane; j < hi; j += 64) {
             const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
             if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk * stride + pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
         }
     }
-    __threadfence_block();                       // the global-slab form is read back by other lanes of this wave
+    // rank the 128 lists by length (ties by index): order[rank] = list
+#pragma unroll 1
+    for (int L = lane; L < 8 * LC_TASKS; L += 64) {
+        const int len = cnt[L >> 3][(L & 7) + 1];
+        int rank = 0;
+        for (int M = 0; M < 8 * LC_TASKS; M++) { const int lm = cnt[M >> 3][(M & 7) + 1]; rank += (lm > len) || (lm == len && M < L); }
+        order[rank] = (uint8_t)L;
+    }
+    __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    const int tk = lane >> 3, b = (lane & 7) + 1, w = w0 + tk;
-    G1X accx = g1x_inf(); bool started = false;      // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
-    if (w < LC_WINDOWS) {
+    G1Jac *my_stage = stage + (size_t)blockIdx.x * 8 * LC_TASKS;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {           // the i-th longest list, then the i-th shortest
+        const int L = order[pass == 0 ? lane : 8 * LC_TASKS - 1 - lane];
+        const int tk = L >> 3, b = (L & 7) + 1;
         const int s0 = start[tk][b], c = cnt[tk][b];
+        G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
+#pragma unroll 1
         for (int q = 0; q < c; q++) {
             const uint32_t v = in_lds ? lists[tk * stride + s0 + q] : __builtin_nontemporal_load(&lists[tk * stride + s0 + q]);
             G1Affine p = it[v & 0x7fff];
             if (v & 0x8000) fp_neg(p.y, p.y);
             g1x_add_mixed_lazy(accx, started, p);
         }
+        G1X cx; g1x_from_lazy(cx, accx, started);
+        G1Jac acc; g1x_to_jac(acc, cx);
+        my_stage[L] = acc;
     }
-    G1Jac acc;
-    { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
-    // sum_b b * B_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} B_b: a 3-step suffix scan over the task's 8 lanes, then
-    // a 3-step butterfly -- 6 additions, no doublings
-    G1Jac r = acc;
+    __threadfence_block();
+    __syncthreads();
+    // per window: sum_b b * B_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} B_b: a 3-step suffix scan over the window's 8
+    // lanes, then a 3-step butterfly -- 6 additions, no doublings; 8 windows per round
 #pragma unroll 1
-    for (int off = 1; off < 8; off <<= 1) {
-        G1Jac o = g1_shfl_down8(r, off), t;
-        g1_add(t, r, o);
-        if ((lane & 7) + off < 8) r = t;
+    for (int round = 0; round < 2; round++) {
+        const int L = 64 * round + lane;
+        G1Jac r;
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(my_stage + L);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(G1Jac) / 4); k++) dst[k] = __builtin_nontemporal_load(src + k);
+        }
+#pragma unroll 1
+        for (int off = 1; off < 8; off <<= 1) {
+            G1Jac o = g1_shfl_down8(r, off), t;
+            g1_add(t, r, o);
+            if ((lane & 7) + off < 8) r = t;
+        }
+#pragma unroll 1
+        for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
+        if ((lane & 7) == 0) S[((size_t)g * 2 + cls) * LC_WINDOWS + w0 + (L >> 3)] = r;
     }
-#pragma unroll 1
-    for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
-    if (b == 1 && w < LC_WINDOWS) S[((size_t)g * 2 + cls) * LC_WINDOWS + w] = r;
 }
 
 __global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
@@ -287,16 +319,18 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
     G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * groups);
-    uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
+    G1Jac *bstage = reinterpret_cast<G1Jac *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
+    uint16_t *glists = reinterpret_cast<uint16_t *>(bstage + (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * LC_TASKS);
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists, bstage);
     if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
-    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * lc_list_stride(n_per_group) * sizeof(uint16_t);
-    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
+    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 2 * LC_WAVES_PER_CLASS * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
+    const size_t stage = (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * LC_TASKS * sizeof(G1Jac);
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + stage + lists;
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
