@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 // batch; the bucket method shares the doublings:
 //   k_lc_prep     one lane per term: GLV split, signed 4-bit recoding of both halves (33 digits in [-8, 8]),
 //                 the two points P and -phi(P)                                    -> items[2(3n+1)], digits[item][33]
-//   k_lc_buckets  one wave = 8 (window, class) tasks x 8 buckets: LDS counting sort of the class's items by |digit|,
-//                 lane (task, b) adds up its list (mixed additions), weights by b, 8-lane butterfly -> S[class][window]
-//   k_lc_horner   one lane per (batch, class): Horner over the 33 windows (4 doublings + 1 addition each), to affine
+//   k_lc_buckets  one wave = 16 windows of one class x 8 buckets = 128 lists: LDS counting sort of the class's items by
+//                 |digit|, every lane adds up two lists (longest + shortest)        -> bucket sums B[class][window][b]
+//   k_lc_horner   one lane per (batch, class, b): Horner over the 33 windows (4 doublings + 1 addition each), then the
+//                 weights b over the 8 lanes of a class (suffix scan + butterfly), to affine
 // ~2.3x less issue work per batch than the windowed form above; its dependent chain is no shorter (the Horner tail),
 // so it is used when many batches are in flight and the windowed form otherwise.
 constexpr int LC_DIG_STRIDE = 36;
@@ -174,12 +175,14 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
 // 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~5,000 instructions either way.
 // Balance: a bucket list has 30 +- 5 items (258 items over 8 buckets), and with one list per lane a wave runs as long as its
 // longest list (~43).  So a wave takes SIXTEEN windows = 128 lists, ranks them by length and gives lane i the i-th longest
-// and the i-th shortest: every lane walks ~61 items.  The 128 bucket sums go through a global staging slab and are then
-// weighted and summed per window, 64 at a time.
+// and the i-th shortest: every lane walks ~61 items.  The bucket sums B[window][b] are NOT weighted here: since
+//   sum_w 16^w sum_b b B[w][b] = sum_b b ( sum_w 16^w B[w][b] ),
+// the Horner kernel runs one chain per bucket index (8 lanes per class instead of 1: same latency) and applies the weights b
+// once per class -- 6 additions per class instead of 6 per window (a quarter of this kernel's work before).
 constexpr int LC_TASKS = 16;                     // windows per regular wave
 constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
 __host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
-__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists, G1Jac *stage) {
+__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
     __shared__ uint16_t lists_lds[LC_TASKS][LC_LDS_LIST];
     __shared__ int cnt[LC_TASKS][9], start[LC_TASKS][9], cursor[LC_TASKS][9];
     __shared__ uint8_t order[8 * LC_TASKS];
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
             if (dg[(size_t)j * LC_DIG_STRIDE + w0]) { G1Affine p = it[j]; g1_add_mixed(acc, acc, p); }
 #pragma unroll 1
         for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
-        if (lane == 0) S[((size_t)g * 2 + cls) * LC_WINDOWS + w0] = acc;
+        if (lane == 0) S[(((size_t)g * 2 + cls) * LC_WINDOWS + w0) * 8] = acc;          // bucket 1 of the carry window
         return;
     }
     const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
     }
     __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    G1Jac *my_stage = stage + (size_t)blockIdx.x * 8 * LC_TASKS;
+    G1Jac *out = S + ((size_t)g * 2 + cls) * LC_WINDOWS * 8;       // bucket sums [window][bucket - 1]; weighted by the Horner kernel
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {           // the i-th longest list, then the i-th shortest
         const int L = order[pass == 0 ? lane : 8 * LC_TASKS - 1 - lane];
@@ -248,49 +251,39 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
         }
         G1X cx; g1x_from_lazy(cx, accx, started);
         G1Jac acc; g1x_to_jac(acc, cx);
-        my_stage[L] = acc;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // per window: sum_b b * B_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} B_b: a 3-step suffix scan over the window's 8
-    // lanes, then a 3-step butterfly -- 6 additions, no doublings; 8 windows per round
-#pragma unroll 1
-    for (int round = 0; round < 2; round++) {
-        const int L = 64 * round + lane;
-        G1Jac r;
-        {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(my_stage + L);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-            for (int k = 0; k < (int)(sizeof(G1Jac) / 4); k++) dst[k] = __builtin_nontemporal_load(src + k);
-        }
-#pragma unroll 1
-        for (int off = 1; off < 8; off <<= 1) {
-            G1Jac o = g1_shfl_down8(r, off), t;
-            g1_add(t, r, o);
-            if ((lane & 7) + off < 8) r = t;
-        }
-#pragma unroll 1
-        for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
-        if ((lane & 7) == 0) S[((size_t)g * 2 + cls) * LC_WINDOWS + w0 + (L >> 3)] = r;
+        out[(size_t)(w0 + tk) * 8 + (b - 1)] = acc;
     }
 }
 
 __global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 2 * groups) return;
-    const int g = id >> 1, cls = id & 1;
-    const G1Jac *s = S + ((size_t)g * 2 + cls) * LC_WINDOWS;
-    G1Jac acc = s[LC_WINDOWS - 1];                   // lazy chain (g1.h): no reductions until the end
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, bucket - 1): 8-lane segments never straddle a wave
+    const int lane = threadIdx.x;
+    const bool live = id < 16 * groups;
+    const int gc = live ? id >> 3 : 0, bi = id & 7;               // gc = 2 g + class
+    const G1Jac *s = S + (size_t)gc * LC_WINDOWS * 8;
+    G1Jac acc = g1_inf();
+    if (live && bi == 0) acc = s[(size_t)(LC_WINDOWS - 1) * 8];   // the carry window has the single bucket 1
+    // lazy chain (g1.h): no reductions until the end; one doubling body, one addition body
 #pragma unroll 1
-    for (int k = 4 * (LC_WINDOWS - 1) - 1; k >= 0; k--) {         // one doubling body, one addition body
+    for (int k = 4 * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
         g1_dbl_lazy(acc, acc);
-        if ((k & 3) == 0) { G1Jac v = s[k >> 2]; g1_add_lazy(acc, acc, v); }
+        if ((k & 3) == 0) { G1Jac v = live ? s[(size_t)(k >> 2) * 8 + bi] : g1_inf(); g1_add_lazy(acc, acc, v); }
     }
     g1_canon_lazy(acc, acc);
-    G1Affine a; g1_to_affine(a, acc);
-    if (cls == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
-    pair_pts[2 * (size_t)g + cls] = a;
+    // sum_b b * A_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} A_b: 3-step suffix scan over the 8 lanes, 3-step butterfly
+    G1Jac r = acc;
+#pragma unroll 1
+    for (int off = 1; off < 8; off <<= 1) {
+        G1Jac o = g1_shfl_down8(r, off), t;
+        g1_add(t, r, o);
+        if ((lane & 7) + off < 8) r = t;
+    }
+#pragma unroll 1
+    for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
+    if (!live || bi != 0) return;
+    G1Affine a; g1_to_affine(a, r);
+    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[gc] = a;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -318,19 +311,17 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
     G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
-    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * groups);
-    G1Jac *bstage = reinterpret_cast<G1Jac *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
-    uint16_t *glists = reinterpret_cast<uint16_t *>(bstage + (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * LC_TASKS);
+    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * 8 * groups);
+    uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists, bstage);
-    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists);
+    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((16 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 2 * LC_WAVES_PER_CLASS * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
-    const size_t stage = (size_t)groups * 2 * LC_WAVES_PER_CLASS * 8 * LC_TASKS * sizeof(G1Jac);
-    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + stage + lists;
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * 8 * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
