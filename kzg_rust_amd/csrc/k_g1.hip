@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 constexpr int LC_DIG_STRIDE = 36;
 constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
 __host__ __device__ inline int lc_items(int n) { return 2 * (3 * n + 1); }
-constexpr int LC_WAVES_PER_CLASS = 3;   // windows 0-15, 16-31, and the carry window
+constexpr int LC_WAVES_PER_CLASS = 2;   // windows 0-15 and 16-31 (the carry window has its own small kernel)
 
 __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b, const uint32_t *scal_c, int n,
                                                  G1Affine *items, int8_t *digits) {
@@ -182,31 +182,40 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
 constexpr int LC_TASKS = 16;                     // windows per regular wave
 constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
 __host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
-__global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
-    __shared__ uint16_t lists_lds[LC_TASKS][LC_LDS_LIST];
-    __shared__ int cnt[LC_TASKS][9], start[LC_TASKS][9], cursor[LC_TASKS][9];
-    __shared__ uint8_t order[8 * LC_TASKS];
-    const int g = blockIdx.x / (2 * LC_WAVES_PER_CLASS), wv = blockIdx.x % (2 * LC_WAVES_PER_CLASS), lane = threadIdx.x;
-    const int cls = wv < LC_WAVES_PER_CLASS ? 1 : 0;
-    const int sub = wv % LC_WAVES_PER_CLASS;                              // 0, 1: windows 16 sub .. 16 sub + 15;  2: the carry window
+// the carry digit (0 or 1) of every item: a single bucket holding about half of the class -> one wave per (batch, class)
+__global__ void __launch_bounds__(64) k_lc_carry(const G1Affine *items, const int8_t *digits, int n, G1Jac *S) {
+    const int g = blockIdx.x >> 1, cls = blockIdx.x & 1, lane = threadIdx.x;
+    const int ni = lc_items(n), w0 = LC_WINDOWS - 1;
+    const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;
+    const G1Affine *it = items + (size_t)g * ni;
+    const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
+    G1Jac acc = g1_inf();
+    for (int j = lo + lane; j < hi; j += 64)
+        if (dg[(size_t)j * LC_DIG_STRIDE + w0]) { G1Affine p = it[j]; g1_add_mixed(acc, acc, p); }
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
+    if (lane == 0) S[(((size_t)g * 2 + cls) * LC_WINDOWS + w0) * 8] = acc;          // bucket 1 of the carry window
+}
+// One 256-thread workgroup per batch: its four waves are (class 1, windows 0-15), (class 1, 16-31), (class 0, 0-15),
+// (class 0, 16-31) -- one per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see k_pairing.hip), each
+// with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach the same number of times.
+__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
+    __shared__ uint16_t lists_all[4][LC_TASKS][LC_LDS_LIST];
+    __shared__ int cnt_all[4][LC_TASKS][9], start_all[4][LC_TASKS][9], cursor_all[4][LC_TASKS][9];
+    __shared__ uint8_t order_all[4][8 * LC_TASKS];
+    const int g = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cls = wid < 2 ? 1 : 0, sub = wid & 1;
     const int w0 = sub * LC_TASKS;
+    uint16_t (*lists_lds)[LC_LDS_LIST] = lists_all[wid];
+    int (*cnt)[9] = cnt_all[wid], (*start)[9] = start_all[wid], (*cursor)[9] = cursor_all[wid];
+    uint8_t *order = order_all[wid];
     const int ni = lc_items(n);
     const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;       // item range of the class (terms t < n are class 0)
     const G1Affine *it = items + (size_t)g * ni;
     const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
-    if (w0 == LC_WINDOWS - 1) {
-        // the carry digit (0 or 1): a single bucket holding about half of the items -> spread it over the whole wave
-        G1Jac acc = g1_inf();
-        for (int j = lo + lane; j < hi; j += 64)
-            if (dg[(size_t)j * LC_DIG_STRIDE + w0]) { G1Affine p = it[j]; g1_add_mixed(acc, acc, p); }
-#pragma unroll 1
-        for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
-        if (lane == 0) S[(((size_t)g * 2 + cls) * LC_WINDOWS + w0) * 8] = acc;          // bucket 1 of the carry window
-        return;
-    }
     const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
     const int stride = in_lds ? LC_LDS_LIST : lc_list_stride(n);
-    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + (size_t)blockIdx.x * LC_TASKS * stride;
+    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + ((size_t)blockIdx.x * 4 + wid) * LC_TASKS * stride;
     for (int q = lane; q < 9 * LC_TASKS; q += 64) cnt[q / 9][q % 9] = 0;
     __syncthreads();
 #pragma unroll 1
@@ -242,10 +251,18 @@ __global__ void __launch_bounds__(64) k_lc_buckets(const G1Affine *items, const 
         const int tk = L >> 3, b = (L & 7) + 1;
         const int s0 = start[tk][b], c = cnt[tk][b];
         G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
+        // the list entry two steps ahead and the point one step ahead are in flight during an addition (with the lists in the
+        // global slab each step would otherwise wait for two dependent loads)
+        const uint16_t *lst = lists + tk * stride + s0;
+        auto entry = [&](int q) -> uint32_t { return q < c ? (in_lds ? (uint32_t)lst[q] : (uint32_t)__builtin_nontemporal_load(lst + q)) : 0u; };
+        uint32_t v0 = entry(0), v1 = entry(1);
+        G1Affine pn = it[v0 & 0x7fff];
 #pragma unroll 1
         for (int q = 0; q < c; q++) {
-            const uint32_t v = in_lds ? lists[tk * stride + s0 + q] : __builtin_nontemporal_load(&lists[tk * stride + s0 + q]);
-            G1Affine p = it[v & 0x7fff];
+            G1Affine p = pn;
+            const uint32_t v = v0;
+            v0 = v1; v1 = entry(q + 2);
+            pn = it[v0 & 0x7fff];                    // next point (index 0 when past the end: a harmless in-range load)
             if (v & 0x8000) fp_neg(p.y, p.y);
             g1x_add_mixed_lazy(accx, started, p);
         }
@@ -315,7 +332,10 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups * 2 * LC_WAVES_PER_CLASS), dim3(64), 0, st, items, digits, n_per_group, S, glists);
+    if (stage == 0 || stage == 2) {
+        hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists);
+        hipLaunchKernelGGL(k_lc_carry, dim3(2 * groups), dim3(64), 0, st, items, digits, n_per_group, S);
+    }
     if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((16 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {

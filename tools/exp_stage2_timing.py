@@ -34,5 +34,14 @@ for world in (1, 2, 4, 8):
     ok = (C.c_bool * gm)(); st2 = (C.c_int * gm)()
     ms2 = t(lambda: L.kzg355_verify_records_device(ok, st2, rec.data_ptr(), n * world, gm, s.handle))
     assert all(ok[i] for i in range(gm))
+    if os.environ.get("KERNELS"):
+        L.kzg355_reset_kernel_stats(s.handle); s.set_kernel_timing(True)
+        L.kzg355_verify_records_device(ok, st2, rec.data_ptr(), n * world, gm, s.handle); s.set_kernel_timing(False)
+        parts = []
+        for fam in ("points_from_records", "rpowers", "lincomb_prep", "lincomb", "lincomb_horner", "pairing"):
+            tot, cnt = C.c_double(), C.c_long()
+            L.kzg355_kernel_ms_stats(s.handle, fam.encode(), C.byref(tot), C.byref(cnt))
+            if cnt.value: parts.append(f"{fam} {tot.value / cnt.value:.2f}")
+        print("   stage 2 kernels (ms):", ", ".join(parts))
     print(f"stage 2 as at world={world}: {gm} batches of {n * world}: {ms2:.1f} ms   -> est. step {ms1 + ms2:.1f} ms, {G * n * world / (ms1 + ms2) * 1e3 / 1e6:.2f} M blobs/s aggregate (without the all-gather)")
 s.free()
