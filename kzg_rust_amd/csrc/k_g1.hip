@@ -13,7 +13,7 @@ namespace kzg {
 
 // ------------------------------------------------------------------------------------------------ points
 // thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
-__global__ void __launch_bounds__(64) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+__global__ void __launch_bounds__(256) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
                                                          G1Affine *pts, int *err) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
                             hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err);
+    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
     if (n_total <= 0) return;
