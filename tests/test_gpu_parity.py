@@ -590,3 +590,34 @@ def test_wide_table_digit_extremes(kz, settings, oracle, oracle_settings):
         assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
     one = kz.Kzg.blob_to_kzg_commitment(kz.Blob(blobs[0]), settings)          # the lone-blob launch shape (two window parts)
     assert one.to_bytes() == cs[0].to_bytes()
+
+
+def test_launch_shape_sweep(kz, settings):
+    """Odd launch sizes through the device entry points: batch sizes 1..1600 x batch counts 1..200 (both lincomb forms, both hash
+    forms, every MSM shape).  Honest batches verify; swapping two proofs inside the LAST batch turns exactly that verdict false;
+    commitments / proofs of a prefix do not depend on how many blobs the call carries."""
+    import torch
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+    NB = 1600
+    gen = torch.Generator(device=dev); gen.manual_seed(99)
+    tb = torch.randint(0, 256, (NB, 4096, 32), dtype=torch.uint8, device=dev, generator=gen); tb[:, :, 0] = 0
+    tb = tb.reshape(-1).contiguous()
+    out = C.create_string_buffer(48 * NB); st = (C.c_int * NB)()
+    assert L.kzg355_blob_to_kzg_commitment_many_device(out, st, tb.data_ptr(), NB, settings.handle) == 0
+    cs = out.raw; tc = torch.frombuffer(bytearray(cs), dtype=torch.uint8).to(dev)
+    assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr(), tc.data_ptr(), NB, settings.handle) == 0
+    ps = out.raw; tp = torch.frombuffer(bytearray(ps), dtype=torch.uint8).to(dev)
+    for n in (1, 2, 15, 16, 17, 127, 128, 129, 1023, 1024, 1025):
+        o2 = C.create_string_buffer(48 * n)
+        assert L.kzg355_blob_to_kzg_commitment_many_device(o2, st, tb.data_ptr(), n, settings.handle) == 0 and o2.raw == cs[:48 * n], n
+        assert L.kzg355_compute_blob_kzg_proof_many_device(o2, st, tb.data_ptr(), tc.data_ptr(), n, settings.handle) == 0 and o2.raw == ps[:48 * n], n
+    for npg, G in ((1, 1), (1, 70), (2, 33), (3, 65), (7, 200), (8, 64), (9, 63), (31, 51), (64, 1), (64, 2), (64, 3), (64, 25), (65, 24),
+                   (100, 16), (127, 12), (128, 12), (129, 12), (200, 8), (512, 3), (1600, 1)):
+        ok = (C.c_bool * G)(); stg = (C.c_int * G)()
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), npg, G, settings.handle)
+        assert rc == 0 and all(ok[i] for i in range(G)) and not any(stg[i] for i in range(G)), (npg, G, rc)
+        if npg > 1:
+            bad = tp.clone(); j = (npg * G - 1) * 48; k = (npg * (G - 1)) * 48
+            tmp = bad[j:j + 48].clone(); bad[j:j + 48] = bad[k:k + 48]; bad[k:k + 48] = tmp
+            rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, tb.data_ptr(), tc.data_ptr(), bad.data_ptr(), npg, G, settings.handle)
+            assert rc == 0 and [ok[i] for i in range(G)] == [True] * (G - 1) + [False], (npg, G)
