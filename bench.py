@@ -246,17 +246,22 @@ def pmc_traffic(kernel_family, blobs_per_launch):
     names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets"], "lincomb_prep": ["k_lc_prep"], "lincomb_horner": ["k_lc_horner"],
              "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
              "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"]}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")))
-    if not files or kernel_family not in names:
+    import re
+    def version(f):                                               # .../rNN/pmc_traffic[_tag]_vK.json -> (NN, K)
+        m = re.search(r"r(\d+)[/\\]pmc_traffic.*_v(\d+)\.json$", f)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")), key=version, reverse=True)
+    if kernel_family not in names:
         return None, None
-    per = json.load(open(files[-1]))["per_kernel"]
-    ds = [per[k] for k in names[kernel_family] if k in per]
-    if kernel_family in ("challenge", "msm_bucket", "msm_wide"):
-        ds = ds[:1]                                              # alternative forms of one kernel, not a sequence
-    if not ds:
-        return None, None
-    per_blob = sum(d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"] for d in ds)
-    return per_blob * blobs_per_launch, os.path.relpath(files[-1], ROOT)
+    for f in files:                                               # newest summary that has this kernel
+        per = json.load(open(f))["per_kernel"]
+        ds = [per[k] for k in names[kernel_family] if k in per]
+        if kernel_family in ("challenge", "msm_bucket", "msm_wide"):
+            ds = ds[:1]                                          # alternative forms of one kernel, not a sequence
+        if ds:
+            per_blob = sum(d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"] for d in ds)
+            return per_blob * blobs_per_launch, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
