@@ -248,8 +248,8 @@ def pmc_traffic(kernel_family, blobs_per_launch):
              "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"]}
     import re
     def version(f):                                               # .../rNN/pmc_traffic[_tag]_vK.json -> (NN, K)
-        m = re.search(r"r(\d+)[/\\]pmc_traffic.*_v(\d+)\.json$", f)
-        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        m = re.search(r"r(\d+)[/\\]pmc_traffic(_\w+?)?_v(\d+)\.json$", f)
+        return (int(m.group(1)), int(m.group(3)), 0 if m.group(2) else 1) if m else (0, 0, 0)     # untagged (verify) summary first
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")), key=version, reverse=True)
     if kernel_family not in names:
         return None, None
