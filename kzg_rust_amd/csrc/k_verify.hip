@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, i
                     if (idx < 8u) {
                         const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)N_FE, 0u, (uint32_t)n};
                         v = hdr[idx];                                   // "RCKZGBATCH___V1_" | 4096 | n
-                    } else if (idx < total_words) v = load_be32(rec + 4 * (size_t)(idx - 8u));
+                    } else if (idx < total_words) v = bswap32(reinterpret_cast<const uint32_t *>(rec)[idx - 8u]);   // records are 4-byte aligned
                     else if (idx == total_words) v = 0x80000000u;
                     else if (idx == 16u * nblocks - 2u) v = (uint32_t)(bits >> 32);
                     else if (idx == 16u * nblocks - 1u) v = (uint32_t)bits;
