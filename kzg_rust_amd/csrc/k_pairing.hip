@@ -17,14 +17,15 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Aff
     __shared__ CoopMem mems[PAIRING_WAVES];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g_raw = blockIdx.x * PAIRING_WAVES + wid;
-    const int g = g_raw < groups ? g_raw : groups - 1;            // a tail wave redoes the last batch and writes nothing
+    if (g_raw >= groups) return;                                  // the waves of a workgroup never synchronise with each other
+    const int g = g_raw;
     CoopMem &mem = mems[wid];
     G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
     if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
     if (lines_inf[0]) p2 = g1a_inf();
     // ML([tau]G2, -proof_lincomb) * ML(G2, rhs): lines_w[2] = setup g2[1] = [tau]G2, lines_w[0] = G2 generator
     const bool r = coop_pairing_check(mem, prog, n_insn, scheds, lines_w + 2 * N_LINES, p1, lines_w, p2, *frob);
-    if (lane == 0 && g_raw < groups) ok[g] = r ? 1 : 0;
+    if (lane == 0) ok[g] = r ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, LineW *lines_w, int n) {

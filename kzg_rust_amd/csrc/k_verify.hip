@@ -318,11 +318,21 @@ __constant__ uint32_t SHA_K[64] = {
     0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
     0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
     0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
-__global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
-                                                 uint32_t *scal_c, int *err) {
-    __shared__ uint32_t wk[64][64];                  // [t][block of the chunk]
-    __shared__ uint32_t digest[8];
-    const int g = blockIdx.x, lane = threadIdx.x;
+// Four batches (waves) per workgroup, one per SIMD of the CU it lands on (one-wave workgroups of long chains are placed
+// unevenly); the waves share nothing: each keeps to its own LDS slice behind wave-local fences.
+#define RP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+__global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
+                                                  uint32_t *scal_c, int *err) {
+    __shared__ uint32_t wk_all[4][64][64];           // per wave: [t][block of the chunk]
+    __shared__ uint32_t digest_all[4][8];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g_raw = blockIdx.x * 4 + wid;
+    if (g_raw >= groups) return;                                  // (the waves only synchronise with themselves)
+    const int g = g_raw;
+    const bool live = true;
+    uint32_t (*wk)[64] = wk_all[wid];
+    uint32_t *digest = digest_all[wid];
     const uint8_t *rec = records + (size_t)RECORD_BYTES * n * g;
     Fr r = fr_one();
     if (n > 1) {   // for n == 1 only r^0 = 1 is used (the reference takes the single-proof path, kzg.rs:658-660)
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, i
                     wk[t][lane] = w[t & 15] + SHA_K[t];
                 }
             }
-            __syncthreads();
+            RP_WAVE_SYNC();
             if (lane == 0) {
                 const uint32_t cnt = nblocks - b0 < 64u ? nblocks - b0 : 64u;
 #pragma unroll 1
@@ -374,10 +384,10 @@ __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, i
                     h0 += a; h1 += bb; h2 += c; h3 += d; h4 += e; h5 += f; h6 += gg; h7 += h;
                 }
             }
-            __syncthreads();
+            RP_WAVE_SYNC();
         }
         if (lane == 0) { digest[0] = h7; digest[1] = h6; digest[2] = h5; digest[3] = h4; digest[4] = h3; digest[5] = h2; digest[6] = h1; digest[7] = h0; }
-        __syncthreads();
+        RP_WAVE_SYNC();
         uint32_t dw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) dw[k] = digest[k];
@@ -404,18 +414,18 @@ __global__ void __launch_bounds__(64) k_rpowers(const uint8_t *records, int n, i
         Fr z, y, t; fr_from_words(z, zw); fr_from_words(y, yw);
         uint32_t *pa = scal_a + 8 * ((size_t)g * n + i), *pb = scal_b + 8 * ((size_t)g * n + i);
         uint32_t ow[8];
-        fr_to_words(ow, pw); for (int k = 0; k < 8; k++) pa[k] = ow[k];
-        fr_mul(t, pw, z); fr_to_words(ow, t); for (int k = 0; k < 8; k++) pb[k] = ow[k];
+        fr_to_words(ow, pw); if (live) for (int k = 0; k < 8; k++) pa[k] = ow[k];
+        fr_mul(t, pw, z); fr_to_words(ow, t); if (live) for (int k = 0; k < 8; k++) pb[k] = ow[k];
         fr_mul(t, pw, y); fr_add(csum, csum, t);
         fr_mul(pw, pw, r64);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(csum, off); fr_add(csum, csum, o); }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         uint32_t ow[8]; fr_to_words(ow, csum);
         for (int k = 0; k < 8; k++) scal_c[8 * (size_t)g + k] = ow[k];
     }
-    if (bad) atomicOr(&err[g], ERR_NONCANONICAL_FR);
+    if (bad && live) atomicOr(&err[g], ERR_NONCANONICAL_FR);
 }
 
 // ------------------------------------------------------------------------------------------------ pairing
@@ -447,7 +457,7 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st) {
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_rpowers, dim3(groups), dim3(64), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + 3) / 4), dim3(256), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
 }
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
