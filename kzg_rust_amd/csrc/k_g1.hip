@@ -196,21 +196,20 @@ __global__ void __launch_bounds__(64) k_lc_carry(const G1Affine *items, const in
     for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
     if (lane == 0) S[(((size_t)g * 2 + cls) * LC_WINDOWS + w0) * 8] = acc;          // bucket 1 of the carry window
 }
-// One 256-thread workgroup per batch: its four waves are (class 1, windows 0-15), (class 1, 16-31), (class 0, 0-15),
-// (class 0, 16-31) -- one per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see k_pairing.hip), each
+// One 256-thread workgroup per batch: wave j takes the windows 8 j .. 8 j + 7 of both classes -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see k_pairing.hip), each
 // with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach the same number of times.
 __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
     __shared__ uint16_t lists_all[4][LC_TASKS][LC_LDS_LIST];
     __shared__ int cnt_all[4][LC_TASKS][9], start_all[4][LC_TASKS][9], cursor_all[4][LC_TASKS][9];
     __shared__ uint8_t order_all[4][8 * LC_TASKS];
     const int g = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int cls = wid < 2 ? 1 : 0, sub = wid & 1;
-    const int w0 = sub * LC_TASKS;
+    // wave `wid`: windows 8 wid .. 8 wid + 7 of BOTH classes: tasks 0-7 are class 1 (2 (2n+1) items), tasks 8-15 class 0 (2n items), so
+    // the four waves carry equal work and the length ranking below pairs every long class-1 list with a short class-0 list
+    const int w0 = wid * 8;
     uint16_t (*lists_lds)[LC_LDS_LIST] = lists_all[wid];
     int (*cnt)[9] = cnt_all[wid], (*start)[9] = start_all[wid], (*cursor)[9] = cursor_all[wid];
     uint8_t *order = order_all[wid];
     const int ni = lc_items(n);
-    const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;       // item range of the class (terms t < n are class 0)
     const G1Affine *it = items + (size_t)g * ni;
     const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
     const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
@@ -220,7 +219,7 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
     __syncthreads();
 #pragma unroll 1
     for (int tk = 0; tk < LC_TASKS; tk++) {
-        const int w = w0 + tk;
+        const int w = w0 + (tk & 7), lo = tk < 8 ? 2 * n : 0, hi = tk < 8 ? ni : 2 * n;      // item range of the task's class (terms t < n are class 0)
         for (int j = lo + lane; j < hi; j += 64) { const int d = dg[(size_t)j * LC_DIG_STRIDE + w]; if (d) atomicAdd(&cnt[tk][d < 0 ? -d : d], 1); }
     }
     __syncthreads();
@@ -228,7 +227,7 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
     __syncthreads();
 #pragma unroll 1
     for (int tk = 0; tk < LC_TASKS; tk++) {
-        const int w = w0 + tk;
+        const int w = w0 + (tk & 7), lo = tk < 8 ? 2 * n : 0, hi = tk < 8 ? ni : 2 * n;
         for (int j = lo + lane; j < hi; j += 64) {
             const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
             if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk * stride + pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
@@ -244,7 +243,7 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
     }
     __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    G1Jac *out = S + ((size_t)g * 2 + cls) * LC_WINDOWS * 8;       // bucket sums [window][bucket - 1]; weighted by the Horner kernel
+    G1Jac *out = S + (size_t)g * 2 * LC_WINDOWS * 8;               // bucket sums [class][window][bucket - 1]; weighted by the Horner kernel
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {           // the i-th longest list, then the i-th shortest
         const int L = order[pass == 0 ? lane : 8 * LC_TASKS - 1 - lane];
@@ -268,7 +267,7 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
         }
         G1X cx; g1x_from_lazy(cx, accx, started);
         G1Jac acc; g1x_to_jac(acc, cx);
-        out[(size_t)(w0 + tk) * 8 + (b - 1)] = acc;
+        out[((size_t)(tk < 8 ? 1 : 0) * LC_WINDOWS + w0 + (tk & 7)) * 8 + (b - 1)] = acc;
     }
 }
 

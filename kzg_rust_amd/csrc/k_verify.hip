@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, 
     __shared__ uint32_t wk_all[4][64][64];           // per wave: [t][block of the chunk]
     __shared__ uint32_t digest_all[4][8];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g_raw = blockIdx.x * 4 + wid;
+    const int g_raw = blockIdx.x * (int)(blockDim.x >> 6) + wid;
     if (g_raw >= groups) return;                                  // (the waves only synchronise with themselves)
     const int g = g_raw;
     const bool live = true;
@@ -457,7 +457,10 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st) {
     if (groups <= 0) return;
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + 3) / 4), dim3(256), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
+    // four waves per workgroup once there are more batches than CUs can take one each (even placement); below that one wave per
+    // workgroup: four of these LDS-latency-bound single-lane chains on one CU slow each other down (512-blob batches: 3x)
+    const int wpw = groups > 512 ? 4 : 1;
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
 }
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
