@@ -47,7 +47,8 @@ enum {
     KZG355_INVALID_BYTES_LENGTH = 3,  /* Error::InvalidBytesLength kzg.rs:17 */
     KZG355_INVALID_HEX = 4,           /* Error::InvalidHexFormat   kzg.rs:19 */
     KZG355_INVALID_TRUSTED_SETUP = 5, /* Error::InvalidTrustedSetup kzg.rs:21 */
-    KZG355_NO_DEVICE = 6              /* no usable HIP device / HIP runtime error (no reference counterpart) */
+    KZG355_NO_DEVICE = 6,             /* no usable HIP device / HIP runtime error (no reference counterpart) */
+    KZG355_NO_MEMORY = 7              /* a device or pinned-host allocation failed (no reference counterpart) */
 };
 
 typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings` (kzg.rs:28-40) */
@@ -116,8 +117,22 @@ int kzg355_verify_shard_records_device(uint8_t *d_records /* groups*n_local*160,
 /* Stage 2, replicated on every rank, over ALL gathered records (device): `groups` batches of n records each
  * (group-major).  r-powers (utils.rs:426-474), the three linear combinations and the pairing check (kzg.rs:579-627).
  * n == 1 reproduces the single-blob path (kzg.rs:658); n == 0 is an error like kzg.rs:588-592. */
+/* PRECONDITION: the records come from kzg355_verify_shard_records_device (here or on another rank) and every rank's stage-1
+ * status has been merged into the verdict by the caller (kzg_rust_amd/sharded.py does): this entry point decompresses C_i and
+ * proof_i WITHOUT the subgroup test and does not re-check that z_i, y_i are canonical -- stage 1 already did both.  A caller
+ * holding records of unknown origin must use kzg355_verify_records_checked_device instead. */
 int kzg355_verify_records_device(bool *ok /* groups */, int *status /* groups */, const uint8_t *d_records /* groups*n*160, device */,
                                  size_t n, size_t groups, const kzg355_settings *s);
+/* The same stage 2 with full input validation: validate_kzg_g1 (utils.rs:282-310, incl. subgroup) on every C_i / proof_i and
+ * bytes_to_bls_field (utils.rs:262-275) on every z_i / y_i; = verify_kzg_proof_batch (kzg.rs:579-627) on untrusted bytes. */
+int kzg355_verify_records_checked_device(bool *ok /* groups */, int *status /* groups */, const uint8_t *d_records, size_t n, size_t groups,
+                                         const kzg355_settings *s);
+/* Test / audit readback of the stage-2 intermediates of `groups` batches of n records: out[128 g ..] = r (32 bytes big-endian, the
+ * Fiat-Shamir batch challenge of utils.rs:426-474) | proof_lincomb (48, kzg.rs:601) | rhs (48, kzg.rs:618-622), the two points
+ * ZCash-compressed.  For n == 1 the r field reads 1 (r^0: the single-blob path takes no challenge).  Also returns the verdicts.
+ * Not on the hot path; tests/test_gpu_parity.py diffs these against the oracle and the committed n = 64 / 512 fixtures. */
+int kzg355_debug_batch_intermediates(uint8_t *out /* groups*128, host */, bool *ok /* groups */, int *status /* groups or NULL */,
+                                     const uint8_t *d_records /* device */, size_t n, size_t groups, const kzg355_settings *s);
 
 /* ---- introspection ---------------------------------------------------------------------------- */
 /* Device ordinal the handle lives on, and average duration in milliseconds of the most recent launch of a named

@@ -20,7 +20,7 @@ using namespace kzg;
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) {                                                                        \
             if (getenv("KZG355_DEBUG")) fprintf(stderr, "kzg355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            return KZG355_NO_DEVICE;                                                                   \
+            return _e == hipErrorOutOfMemory ? KZG355_NO_MEMORY : KZG355_NO_DEVICE;                      \
         }                                                                                              \
     } while (0)
 
@@ -33,7 +33,7 @@ struct DevBuf {
         if (bytes <= cap) return KZG355_OK;
         if (p) { hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return KZG355_NO_DEVICE; }
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return KZG355_NO_MEMORY; }
         cap = want;
         return KZG355_OK;
     }
@@ -47,7 +47,7 @@ struct PinBuf {
         if (bytes <= cap) return KZG355_OK;
         if (p) { hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return KZG355_NO_DEVICE; }
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return KZG355_NO_MEMORY; }
         cap = want;
         return KZG355_OK;
     }
@@ -144,6 +144,7 @@ struct Timed {
                 auto &k = s->last_ms[m.first]; k.last = ms; k.total += ms; k.count++;
             }
         }
+        marks.clear(); n = 0;             // the object is reused for the next chunk of a chunked call
     }
 };
 
@@ -580,7 +581,9 @@ int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const ui
     return first;
 }
 
-int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
+namespace {
+// stage 2 over gathered records; `dump` (host, groups*128 bytes or null) receives r | proof_lincomb | rhs per batch
+int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs) {
     if (!cs || !ok) return KZG355_BADARGS;
     if (groups == 0) return KZG355_OK;
     if (n == 0) return KZG355_BADARGS;                           // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
@@ -595,14 +598,26 @@ int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records
     if ((rc = w->ok.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->h_ok.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
+    if (dump && ((rc = w->out48.ensure(128 * groups)) || (rc = w->h_out.ensure(128 * groups)))) return rc;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
     Timed tm(s, w);
-    tm.begin("points_from_records"); launch_points_from_records(d_records, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
-    if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if (validate) {   // full validate_kzg_g1 on C_i / proof_i (decompression + subgroup test) straight from the records
+        tm.begin("validate_points");
+        launch_validate_points(d_records, d_records + 112, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream, RECORD_BYTES);
+        tm.end();
+    } else {
+        tm.begin("points_from_records"); launch_points_from_records(d_records, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
+    }
+    if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, validate, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if (dump) {
+        launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<G1Affine>(), (int)n, G, w->out48.as<uint8_t>(), w->stream);
+        HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 128 * groups, hipMemcpyDeviceToHost, w->stream));
+    }
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
     tm.collect();
+    if (dump) memcpy(dump, w->h_out.p, 128 * groups);
     int first = KZG355_OK;
     for (int i = 0; i < G; i++) {
         int st = status_from_err(w->h_err.as<int>()[i]);
@@ -611,6 +626,18 @@ int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records
         else if (first == KZG355_OK) first = st;
     }
     return first;
+}
+}  // namespace
+
+int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
+    return verify_records_impl(ok, status, nullptr, d_records, n, groups, 0, cs);
+}
+int kzg355_verify_records_checked_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
+    return verify_records_impl(ok, status, nullptr, d_records, n, groups, 1, cs);
+}
+int kzg355_debug_batch_intermediates(uint8_t *out, bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
+    if (!out) return KZG355_BADARGS;
+    return verify_records_impl(ok, status, out, d_records, n, groups, 1, cs);
 }
 
 // ---- host-buffer entry points (the drop-in surface) ------------------------------------------------------

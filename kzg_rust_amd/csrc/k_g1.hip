@@ -14,13 +14,13 @@ namespace kzg {
 // ------------------------------------------------------------------------------------------------ points
 // thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
 __global__ void __launch_bounds__(256) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
-                                                         G1Affine *pts, int *err) {
+                                                         G1Affine *pts, int *err, int stride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
     const bool is_proof = j >= n_total;
     if (is_proof && !proofs) return;
     const int i = is_proof ? j - n_total : j;
-    const uint8_t *src = (is_proof ? proofs : commitments) + 48 * (size_t)i;
+    const uint8_t *src = (is_proof ? proofs : commitments) + (size_t)stride * i;     // 48: packed arrays; 160: fields of records
     uint8_t b[48];
     for (int k = 0; k < 48; k++) b[k] = src[k];
     G1Affine p;
@@ -304,9 +304,29 @@ __global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1
 
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
-                            hipStream_t st) {
+                            hipStream_t st, int stride) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err);
+    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+}
+// Test / audit readback of stage 2 (tests/test_gpu_parity.py): per batch  r (32 bytes big-endian, utils.rs:472) | proof_lincomb (48) |
+// rhs (48), the latter two ZCash-compressed like bytes_from_g1 (utils.rs:221-227).  pair_pts holds -proof_lincomb (utils.rs:198-201).
+__global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_a, const G1Affine *pair_pts, int n, int groups, uint8_t *out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = id >> 1, which = id & 1;
+    if (g >= groups) return;
+    uint8_t *o = out + 128 * (size_t)g;
+    G1Affine p = pair_pts[2 * (size_t)g + which];
+    if (which == 0 && !g1a_is_inf(p)) fp_neg(p.y, p.y);
+    uint8_t b[48]; g1_compress_affine(b, p);
+    for (int k = 0; k < 48; k++) o[32 + 48 * which + k] = b[k];
+    if (which == 0) {
+        const uint32_t *r = scal_a + 8 * ((size_t)g * n + (n > 1 ? 1 : 0));      // a_1 = r (a_0 = 1)
+        for (int k = 0; k < 8; k++) { const uint32_t v = r[7 - k]; o[4 * k] = (uint8_t)(v >> 24); o[4 * k + 1] = (uint8_t)(v >> 16); o[4 * k + 2] = (uint8_t)(v >> 8); o[4 * k + 3] = (uint8_t)v; }
+    }
+}
+void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out, hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_dump_intermediates, dim3((2 * groups + 63) / 64), dim3(64), 0, st, d_scal_a, d_pair_pts, n_per_group, groups, d_out);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
     if (n_total <= 0) return;

@@ -47,7 +47,13 @@ __global__ void __launch_bounds__(256) k_digits_from_blobs(const uint8_t *blobs,
     uint32_t w[8], e[8];
     w[7] = bswap32m(a.x); w[6] = bswap32m(a.y); w[5] = bswap32m(a.z); w[4] = bswap32m(a.w);
     w[3] = bswap32m(b.x); w[2] = bswap32m(b.y); w[1] = bswap32m(b.z); w[0] = bswap32m(b.w);
-    if (!fr_words_canonical(w)) atomicOr(&err[blob], ERR_NONCANONICAL_FR);
+    if (!fr_words_canonical(w)) {
+        // the blob is rejected (its output is never returned); its digits must still stay inside the bucket range the MSM kernel
+        // indexes with (a top byte >= 0x81 would give bucket 129..255), so the offending scalar is recoded as 0
+        atomicOr(&err[blob], ERR_NONCANONICAL_FR);
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = 0;
+    }
     recode_words(e, w);
     store_digits(digits, blob, i, e);
 }

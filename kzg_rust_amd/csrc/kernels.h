@@ -58,7 +58,8 @@ void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTa
 // d_proofs may be null (commitments only, e.g. compute_blob_kzg_proof's challenge step, kzg.rs:321)
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group,
                             G1Affine *d_pts /* [group][2*npg]: commitments then proofs; may be null */, int *d_err /* per group */,
-                            hipStream_t st);
+                            hipStream_t st, int stride = 48 /* bytes between consecutive inputs: 48 packed, 160 inside records */);
+void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,

@@ -51,7 +51,12 @@ class NoDevice(Error):
     code = 6
 
 
-_ERRORS = {c.code: c for c in (BadArgs, InternalError, InvalidBytesLength, InvalidHexFormat, InvalidTrustedSetup, NoDevice)}
+class NoMemory(Error):
+    """A device or pinned-host allocation failed (no reference counterpart)."""
+    code = 7
+
+
+_ERRORS = {c.code: c for c in (BadArgs, InternalError, InvalidBytesLength, InvalidHexFormat, InvalidTrustedSetup, NoDevice, NoMemory)}
 
 
 def _check(rc, what):
@@ -252,7 +257,9 @@ class Kzg:
         n = len(bl)
         out = C.create_string_buffer(48 * max(n, 1))
         st = (C.c_int * max(n, 1))()
-        lib().kzg355_blob_to_kzg_commitment_many(out, st, b"".join(bl), n, s.handle)
+        rc = lib().kzg355_blob_to_kzg_commitment_many(out, st, b"".join(bl), n, s.handle)
+        if rc != 0 and not any(st[i] for i in range(n)):          # the call failed as a whole (no device, out of memory, n too large)
+            _check(rc, "blob_to_kzg_commitment_many")
         return [KzgCommitment(out.raw[48 * i:48 * i + 48]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("commit") for i in range(n)]
 
     @staticmethod
@@ -264,7 +271,9 @@ class Kzg:
         n = len(bl)
         out = C.create_string_buffer(48 * max(n, 1))
         st = (C.c_int * max(n, 1))()
-        lib().kzg355_compute_blob_kzg_proof_many(out, st, b"".join(bl), b"".join(cs), n, s.handle)
+        rc = lib().kzg355_compute_blob_kzg_proof_many(out, st, b"".join(bl), b"".join(cs), n, s.handle)
+        if rc != 0 and not any(st[i] for i in range(n)):
+            _check(rc, "compute_blob_kzg_proof_many")
         return [KzgProof(out.raw[48 * i:48 * i + 48]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("proof") for i in range(n)]
 
     @staticmethod
@@ -284,6 +293,6 @@ class Kzg:
         ok = (C.c_bool * G)()
         st = (C.c_int * G)()
         rc = lib().kzg355_verify_blob_kzg_proof_batch_many(ok, st, b"".join(flat_b), b"".join(flat_c), b"".join(flat_p), npg, G, s.handle)
-        if rc == NoDevice.code:
-            raise NoDevice("verify_blob_kzg_proof_batch_many")
+        if rc != 0 and not any(st[i] for i in range(G)):          # whole-call failure: no per-batch status was written
+            _check(rc, "verify_blob_kzg_proof_batch_many")
         return [bool(ok[i]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("verify") for i in range(G)]

@@ -621,3 +621,140 @@ def test_launch_shape_sweep(kz, settings):
             tmp = bad[j:j + 48].clone(); bad[j:j + 48] = bad[k:k + 48]; bad[k:k + 48] = tmp
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, tb.data_ptr(), tc.data_ptr(), bad.data_ptr(), npg, G, settings.handle)
             assert rc == 0 and [ok[i] for i in range(G)] == [True] * (G - 1) + [False], (npg, G)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stage 2 pinned value by value: the Fiat-Shamir batch challenge r (utils.rs:426-474), proof_lincomb
+# (kzg.rs:601) and rhs (kzg.rs:618-622) read back through kzg355_debug_batch_intermediates.  A consistently wrong
+# transcript (domain string, byte order, n encoding, a dropped field) keeps every boolean right; these tests do not.
+def _stage2_dump(kz, s, rec, n, groups=1):
+    import torch
+    dev = torch.device("cuda", s.device)
+    t_rec = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    out = C.create_string_buffer(128 * groups)
+    ok = (C.c_bool * groups)(); st = (C.c_int * groups)()
+    rc = kz.kzg.lib().kzg355_debug_batch_intermediates(out, ok, st, t_rec.data_ptr(), n, groups, s.handle)
+    assert rc == 0 and not any(st), (rc, list(st))
+    d = out.raw
+    return [{"r": d[128 * g:128 * g + 32], "proof_lincomb": d[128 * g + 32:128 * g + 80], "rhs": d[128 * g + 80:128 * g + 128], "ok": bool(ok[g])}
+            for g in range(groups)]
+
+
+@pytest.fixture(scope="module")
+def lincomb_handles(kz, setup_bytes):
+    """One handle per form of the batch linear combination (KZG355_LINCOMB pins it when the handle is created)."""
+    g1, g2 = setup_bytes
+    hs = {}
+    for form in ("window", "bucket"):
+        os.environ["KZG355_LINCOMB"] = form
+        try:
+            hs[form] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+        finally:
+            del os.environ["KZG355_LINCOMB"]
+    yield hs
+    for h in hs.values():
+        h.free()
+
+
+@pytest.mark.parametrize("n", [64, 512])
+def test_stage2_intermediates_match_fixtures(n, kz, settings, lincomb_handles):
+    """tests/golden/batch{n}.json carries r, proof_lincomb and rhs of the seeded n-blob batch (oracle-derived, cross-checked by
+    oracle/pyref.py when the fixture was made): the HIP path must reproduce all three byte for byte, in both lincomb forms."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"batch{n}.json")))
+    blobs = [random_blob(fx["first_index"] + i) for i in range(n)]
+    cs = [bytes.fromhex(c) for c in fx["commitments"]]; ps = [bytes.fromhex(p) for p in fx["proofs"]]
+    rec = _records_of(kz, settings, blobs, cs, ps)
+    for name, s in [("auto", settings)] + list(lincomb_handles.items()):
+        d = _stage2_dump(kz, s, rec, n)[0]
+        assert d["r"].hex() == fx["r"], name
+        assert d["proof_lincomb"].hex() == fx["proof_lincomb"], name
+        assert d["rhs"].hex() == fx["rhs"], name
+        assert d["ok"] is True
+    # the swapped twin: same r recipe, different transcript -> different r, and the verdict flips
+    a, b = fx["swapped_pair"]
+    sw = list(ps); sw[a], sw[b] = sw[b], sw[a]
+    d = _stage2_dump(kz, settings, _records_of(kz, settings, blobs, cs, sw), n)[0]
+    assert d["r"].hex() != fx["r"] and d["ok"] is False
+
+
+def test_stage2_intermediates_match_oracle(kz, settings, lincomb_handles, oracle, oracle_settings):
+    """r / proof_lincomb / rhs against oracle.verify_batch_intermediates for n in {2, 6, 9, 65} (windowed and bucket forms; 65 =
+    a second SHA chunk of the r-transcript and a partial second wave of powers), and for 520 batches in one launch (the
+    four-waves-per-workgroup shape of k_rpowers), one of them corrupted."""
+    blobs = [random_blob(9000 + i) for i in range(65)]
+    B, cs, ps = _product_commit_prove(kz, settings, blobs)
+    cs = [c.to_bytes() for c in cs]; ps = [p.to_bytes() for p in ps]
+    for n in (2, 6, 9, 65):
+        want = oracle.verify_batch_intermediates(blobs[:n], cs[:n], ps[:n], oracle_settings)
+        assert want["ok"] is True
+        rec = _records_of(kz, settings, blobs[:n], cs[:n], ps[:n])
+        for name, s in [("auto", settings)] + list(lincomb_handles.items()):
+            d = _stage2_dump(kz, s, rec, n)[0]
+            assert (d["r"], d["proof_lincomb"], d["rhs"], d["ok"]) == (want["r"], want["proof_lincomb"], want["rhs"], True), (n, name)
+        # a wrong-but-valid proof: every intermediate still has to be the oracle's (the boolean alone would also flip on garbage)
+        bad = list(ps[:n]); bad[n - 1] = ps[n - 2]
+        wantb = oracle.verify_batch_intermediates(blobs[:n], cs[:n], bad, oracle_settings)
+        d = _stage2_dump(kz, settings, _records_of(kz, settings, blobs[:n], cs[:n], bad), n)[0]
+        assert (d["r"], d["proof_lincomb"], d["rhs"], d["ok"]) == (wantb["r"], wantb["proof_lincomb"], wantb["rhs"], False), n
+    n, G = 6, 520
+    rec = _records_of(kz, settings, blobs[:n], cs[:n], ps[:n])
+    rec2 = _records_of(kz, settings, blobs[n:2 * n], cs[n:2 * n], ps[n:2 * n])
+    w1 = oracle.verify_batch_intermediates(blobs[:n], cs[:n], ps[:n], oracle_settings)
+    w2 = oracle.verify_batch_intermediates(blobs[n:2 * n], cs[n:2 * n], ps[n:2 * n], oracle_settings)
+    many = b"".join(rec2 if g % 7 == 3 else rec for g in range(G))
+    for s in (settings, lincomb_handles["bucket"]):
+        ds = _stage2_dump(kz, s, many, n, G)
+        for g in range(G):
+            w = w2 if g % 7 == 3 else w1
+            assert (ds[g]["r"], ds[g]["proof_lincomb"], ds[g]["rhs"], ds[g]["ok"]) == (w["r"], w["proof_lincomb"], w["rhs"], True), g
+
+
+def test_verify_records_checked_rejects_what_stage1_would(kz, settings, random_set):
+    """kzg355_verify_records_checked_device = verify_kzg_proof_batch on untrusted records: off-subgroup points and non-canonical
+    z / y are Err there, while the unchecked stage-2 entry point (precondition: stage-1 status merged by the caller) is not
+    required to notice.  Honest records verify through both."""
+    import torch
+    blobs, cs, ps = random_set
+    n = len(blobs)
+    rec = bytearray(_records_of(kz, settings, blobs, cs, ps))
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+
+    def run(fn, r):
+        t = torch.frombuffer(bytearray(r), dtype=torch.uint8).to(dev); torch.cuda.synchronize()
+        ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
+        rc = fn(ok, st, t.data_ptr(), n, 1, settings.handle)
+        return rc, bool(ok[0]), st[0]
+    assert run(L.kzg355_verify_records_checked_device, rec) == (0, True, 0)
+    assert run(L.kzg355_verify_records_device, rec) == (0, True, 0)
+    bad = bytearray(rec); bad[160 * 2 + 48:160 * 2 + 80] = b"\xff" * 32             # z_2 >= r
+    rc, _, st = run(L.kzg355_verify_records_checked_device, bad)
+    assert rc == 1 and st == 1
+    # x = 0x...cde0: on the curve, outside G1 (the reference's own not_in_G1 vector value)
+    off = bytes.fromhex("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcde0")
+    bad = bytearray(rec); bad[160 * 3:160 * 3 + 48] = off
+    rc, _, st = run(L.kzg355_verify_records_checked_device, bad)
+    assert rc == 1 and st == 1
+
+
+def test_invalid_blobs_on_the_bucket_msm_handle(kz, setup_bytes, golden_vectors, golden_blobs, backend):
+    """The reference's invalid-blob vectors (non-canonical field elements, top byte >= 0x81 among them) on a KZG355_MSM=bucket
+    handle: Err as on the table path, valid blobs after them still give the right commitments (no out-of-range bucket index)."""
+    g1, g2 = setup_bytes
+    os.environ["KZG355_MSM"] = "bucket"
+    try:
+        sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_MSM"]
+    try:
+        for fn in ("blob_to_kzg_commitment", "compute_blob_kzg_proof"):
+            n, failures = run_function(fn, golden_vectors, backend, sb, golden_blobs)
+            assert n == COUNTS[fn] and not failures, failures
+        hi = bytearray(random_blob(123)); hi[32 * 77:32 * 77 + 32] = bytes([0x90]) + bytes(31)      # digit 0x90 in the top window
+        good = random_blob(124)
+        res = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(bytes(hi)), kz.Blob(good), kz.Blob(b"\xff" * 131072)], sb)
+        assert isinstance(res[0], kz.BadArgs) and isinstance(res[2], kz.BadArgs)
+        assert res[1].to_bytes() == kz.Kzg.blob_to_kzg_commitment(kz.Blob(good), sb).to_bytes()
+    finally:
+        sb.free()
