@@ -10,15 +10,21 @@ Restates benches/kzg_benches.rs:93-126 (criterion group `verify_blob_kzg_proof_b
     64-blob batches (`--batches-per-step G`), submitted together through kzg355_verify_blob_kzg_proof_batch_many_device
     (or the two stage functions around the all-gather for N > 1).  One 64-blob batch is a chain of latency-bound integer
     kernels that occupies a handful of the chip's 1024 SIMDs, so whole-job throughput needs many batches in flight;
-    `config.latency_ms_single_batch` reports one batch alone.  K steps are executed and timed exactly;
-  * inputs are resident in HBM when the timed region starts.
+  * `value` is measured with the inputs resident in HBM when the timed region starts.  The same run also reports, in
+    `config.host_inputs`, what the reference's own bench shape gives (host slices through the drop-in C ABI, PCIe H2D
+    inside the call): one 64-blob call alone, and the streaming rate of a big call -- neither is ever `value`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM bound of the dominant kernel plus
+`roofline.alu`, the integer-issue bound that actually binds this path) and `cpu_baseline` objects.
+`--sweep` restates the criterion sweep n in {1,2,4,8,16,32,64} and the five single-op benches (kzg_benches.rs:46-126).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import re
+import statistics
 import sys
 import time
 
@@ -29,6 +35,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_PER_BATCH = 64
 BLOB = 131072
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 1024               # 256 CUs x 4 SIMD-32
+NOMINAL_CLOCK_HZ = 2.4e9
+# nominal VALU issue peak: one wave64 instruction per 2 cycles per SIMD-32 (MI355X_MICROARCH.md constants table, v_fma_f32)
+NOMINAL_WAVE_INSTS_PER_S = N_SIMD * NOMINAL_CLOCK_HZ / 2
 # Algorithmic bytes per blob, per kernel family (DESIGN.md "kernels" table); whole path per SURVEY.md 8(d): 262,240 B/blob.
 PATH_BYTES_PER_BLOB = 131072 + 131072 + 48 + 48
 KERNEL_BYTES_PER_BLOB = {
@@ -41,18 +51,28 @@ KERNEL_BYTES_PER_BLOB = {
     "lincomb_prep": 2 * 112 + 64, "lincomb_horner": 2 * 33 * 168 / N_PER_BATCH,
     "pairing": (2 * 68 * 3 * 2 * 56 + 2 * 112) / N_PER_BATCH,   # two 68-line tables + two points per batch
 }
+# algorithmic bytes are independent of expanded precompute tables -- the wide-table MSM is priced at the B_commit
+# figure (affine G1 sweep + scalars + output); the 11.7 MB of table rows it actually gathers per blob is `traffic`.
+B_COMMIT = 4096 * (96 + 32) + 48
+B_PROOF = 131072 + 131072 + 393216 + 48 + 48
 KERNEL_BYTES_PER_BLOB.update({
-    "msm_bucket": 4096 * (96 + 32) + 48,              # SURVEY 8(d) B_commit: affine G1 sweep + scalars + output
-    "msm_wide": 22 * 4096 * 128 + 131072,             # one 128-byte table row per (window, scalar) + the scalars
+    "msm_bucket": B_COMMIT,
+    "msm_wide": B_COMMIT,
     "msm_finalize": 32 * 168 + 48,
     "digits": 131072 + 131072,
     "quotient": 131072 + 131072 + 147456,
 })
 FAMILIES = list(KERNEL_BYTES_PER_BLOB)
-OP_BYTES_PER_BLOB = {"verify": PATH_BYTES_PER_BLOB, "commit": 4096 * (96 + 32) + 48, "proof": 131072 + 131072 + 393216 + 48 + 48}
+PER_BATCH_FAMILIES = ("rpowers", "lincomb", "lincomb_prep", "lincomb_horner", "pairing", "points_from_records")
+OP_BYTES_PER_BLOB = {"verify": PATH_BYTES_PER_BLOB, "commit": B_COMMIT, "proof": B_PROOF}
 OP_METRIC = {"verify": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, batch=64)",
              "commit": "blobs/sec on blob_to_kzg_commitment (mainnet 4096-point G1 MSM)",
              "proof": "blobs/sec on compute_blob_kzg_proof (mainnet 4096)"}
+KERNEL_NAMES = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets", "k_lc_carry"], "lincomb_prep": ["k_lc_prep"],
+                "lincomb_horner": ["k_lc_horner"], "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
+                "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"],
+                "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"], "msm_finalize": ["k_msm_finalize"]}
+ALTERNATIVE_FORMS = ("challenge", "msm_bucket", "msm_wide")     # lists of alternative forms of one kernel, not sequences
 
 
 def main():
@@ -67,8 +87,11 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="time the host-buffer drop-in entry point (H2D over PCIe inside the timed region); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the config.host_inputs measurements of the default run")
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (two-stage HipEngine driver of sharded.py) even at world size 1")
+    ap.add_argument("--sweep", action="store_true",
+                    help="criterion sweep: verify_blob_kzg_proof_batch for n in {1,..,64} and the five single-op benches, single calls on host inputs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +117,13 @@ def main():
     g2 = open(os.path.join(golden, "trusted_setup_g2.bin"), "rb").read()
     s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
     assert s.device == local_rank
+
+    if args.sweep:
+        line = run_sweep(args, kz, L, s, dev, random_blob)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        s.free()
+        return
 
     K, W = max(1, args.steps), max(0, args.warmup)
     if args.concurrent is None:
@@ -166,18 +196,21 @@ def main():
     # single-batch latency (reported, not the metric)
     run_steps(1)
     lat = []
-    for _ in range(3):
+    for _ in range(5):
         barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
-    latency_ms = sorted(lat)[len(lat) // 2]
+    latency_ms = statistics.median(lat)
 
     for _ in range(W):
         run_steps(Cc)
     L.kzg355_reset_kernel_stats(s.handle)
     s.set_kernel_timing(True)
+    step_ms = []
     barrier()
     t0 = time.perf_counter()
+    tp = t0
     for _ in range(K):
-        run_steps(Cc)
+        run_steps(Cc)                                  # synchronous: returns when this step's verdicts are on the host
+        tn = time.perf_counter(); step_ms.append((tn - tp) * 1e3); tp = tn
     barrier()
     dt = time.perf_counter() - t0
     s.set_kernel_timing(False)
@@ -201,9 +234,12 @@ def main():
         dom = max(stats, key=lambda f: stats[f][0])
         tot_ms, cnt = stats[dom]
         avg_s = tot_ms / cnt / 1e3
-        blobs_per_launch = blobs_total / world / cnt if dom not in ("rpowers", "lincomb", "lincomb_prep", "lincomb_horner", "pairing", "points_from_records") else blobs_total / cnt
-        if args.op != "verify":
-            blobs_per_launch = Cc * n_local
+
+        def blobs_per_launch_of(fam):
+            if args.op != "verify":
+                return Cc * n_local
+            return blobs_total / stats[fam][1] if fam in PER_BATCH_FAMILIES else blobs_total / world / stats[fam][1]
+        blobs_per_launch = blobs_per_launch_of(dom)
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
         traffic, traffic_src = pmc_traffic(dom, blobs_per_launch)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -213,8 +249,13 @@ def main():
                     "kernel_ms_share": {f: round(v[0], 3) for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0])},
                     "path_bytes_per_blob": OP_BYTES_PER_BLOB[args.op],
                     "path_frac_of_hbm_peak": value * OP_BYTES_PER_BLOB[args.op] / (world * HBM_PEAK_GBPS * 1e9),
-                    "note": "integer-ALU/latency-bound path: ~1e3 integer ops per byte, HBM fraction is small by construction"}
+                    "measured_stream_copy_gbps": stream_copy_peak(torch, dev) if rank == 0 else None,
+                    "alu": alu_roofline(stats, blobs_per_launch_of, value / world),
+                    "note": "integer-issue-bound path (~1e3 integer ops per byte): the HBM fraction is small by construction; roofline.alu is the bound that binds"}
 
+    host_inputs = None
+    if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
+        host_inputs = host_leg(L, s, t_blobs, commitments, proofs, n_local, min(Cc, 256))
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
@@ -229,7 +270,11 @@ def main():
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-gather of 160-B records"),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
-                       "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM", "latency_ms_single_batch": round(latency_ms, 3)},
+                       "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
+                       "msm_form": s.msm_form,
+                       "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
+                       "latency_ms_single_batch": round(latency_ms, 3), "latency_ms_single_batch_min": round(min(lat), 3),
+                       "host_inputs": host_inputs},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
@@ -238,30 +283,197 @@ def main():
         dist.destroy_process_group()
 
 
+def stream_copy_peak(torch, dev):
+    """Measured device-to-device stream copy on this box (read + write bytes per second), reported next to the 8 TB/s nominal."""
+    n = 1 << 30
+    try:
+        a = torch.empty(n, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+        a.random_(0, 255)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 10
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        del a, b
+        return round(2 * n * reps / (ms / 1e3) / 1e9, 1)
+    except Exception:
+        return None
+
+
+def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
+    """The reference-shaped measurements (benches/kzg_benches.rs:97-122 times the whole call on host slices): blobs in pageable
+    host memory, through the drop-in C ABI, H2D inside the call.  (a) one verify_blob_kzg_proof_batch(n = 64) call alone;
+    (b) `groups` batches streamed by one kzg355_verify_blob_kzg_proof_batch_many call (pinned staging ring inside the library)."""
+    nb = groups * n_local
+    h = t_blobs[:nb * BLOB].cpu().numpy()
+    hp = h.ctypes.data_as(C.c_char_p)
+    ok1 = C.c_bool()
+    lat = []
+    for i in range(7):
+        t0 = time.perf_counter()
+        rc = L.kzg355_verify_blob_kzg_proof_batch(C.byref(ok1), hp, n_local, commitments[:48 * n_local], n_local, proofs[:48 * n_local], n_local, s.handle)
+        lat.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0 and ok1.value
+    lat = lat[2:]
+    okg = (C.c_bool * groups)(); stg = (C.c_int * groups)()
+    rates = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many(okg, stg, hp, commitments[:48 * nb], proofs[:48 * nb], n_local, groups, s.handle)
+        dt = time.perf_counter() - t0
+        assert rc == 0 and all(okg[i] for i in range(groups))
+        if i:
+            rates.append(nb / dt)
+    best = max(rates)
+    return {"single_call_ms": round(statistics.median(lat), 3), "single_call_ms_min": round(min(lat), 3),
+            "single_call_blobs_per_s": round(n_local / (statistics.median(lat) / 1e3), 1),
+            "stream_blobs_per_s": round(statistics.median(rates), 1), "stream_blobs_per_s_best": round(best, 1),
+            "stream_h2d_gbps": round(statistics.median(rates) * (BLOB + 96) / 1e9, 2), "stream_blobs_per_call": nb,
+            "note": "pageable caller memory -> pinned staging ring -> HBM inside the call; never `value`"}
+
+
+def newest_profile(stem, key):
+    """newest committed profiles/rNN/<stem>[_tag]_vK.json that has one of `key` in its per_kernel map (numeric round / version order)."""
+    def version(f):
+        m = re.search(r"r(\d+)[/\\]" + stem + r"(_\w+?)?_v(\d+)\.json$", f)
+        return (int(m.group(1)), int(m.group(3)), 0 if m.group(2) else 1) if m else (0, 0, 0)     # untagged (verify) summary first
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", stem + "_*.json")), key=version, reverse=True):
+        try:
+            per = json.load(open(f))["per_kernel"]
+        except Exception:
+            continue
+        if any(k in per for k in key):
+            return f, per
+    return None, None
+
+
 def pmc_traffic(kernel_family, blobs_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE as is; separate passes, collected with this same bench command).  The counters are per
     blob there; scaled to this run's launch size.  None if no summary is committed for that kernel."""
-    import glob
-    names = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets"], "lincomb_prep": ["k_lc_prep"], "lincomb_horner": ["k_lc_horner"],
-             "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rpowers"],
-             "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"], "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"]}
-    import re
-    def version(f):                                               # .../rNN/pmc_traffic[_tag]_vK.json -> (NN, K)
-        m = re.search(r"r(\d+)[/\\]pmc_traffic(_\w+?)?_v(\d+)\.json$", f)
-        return (int(m.group(1)), int(m.group(3)), 0 if m.group(2) else 1) if m else (0, 0, 0)     # untagged (verify) summary first
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")), key=version, reverse=True)
-    if kernel_family not in names:
+    if kernel_family not in KERNEL_NAMES:
         return None, None
-    for f in files:                                               # newest summary that has this kernel
-        per = json.load(open(f))["per_kernel"]
-        ds = [per[k] for k in names[kernel_family] if k in per]
-        if kernel_family in ("challenge", "msm_bucket", "msm_wide"):
-            ds = ds[:1]                                          # alternative forms of one kernel, not a sequence
-        if ds:
-            per_blob = sum(d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"] for d in ds)
-            return per_blob * blobs_per_launch, os.path.relpath(f, ROOT)
-    return None, None
+    f, per = newest_profile("pmc_traffic", KERNEL_NAMES[kernel_family])
+    if not f:
+        return None, None
+    ds = [per[k] for k in KERNEL_NAMES[kernel_family] if k in per]
+    if kernel_family in ALTERNATIVE_FORMS:
+        ds = ds[:1]
+    per_blob = sum(d["fetch_bytes_per_blob_x2_corrected"] + d["write_bytes_per_blob"] for d in ds)
+    return per_blob * blobs_per_launch, os.path.relpath(f, ROOT)
+
+
+def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
+    """The bound that binds: VALU issue.  Wave-instructions per blob of every kernel family come from the committed SQ counter
+    pass (profiles/rNN/sq_*_vK.json, tools/sq_summary.py: SQ_INSTS_VALU at the bench's launch size); the durations are this
+    run's live HIP-event averages.  Fractions are quoted against the NOMINAL issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per
+    wave64 instruction) and against the MEASURED ceiling of this instruction mix (profiles/rNN/valu_ceiling.json, from
+    tools/ubench/valu_rates.hip: most integer VOP3 / 64-bit instructions issue at half rate)."""
+    out = {"nominal_peak_wave_insts_per_s": NOMINAL_WAVE_INSTS_PER_S, "per_kernel": {}, "source": None}
+    ceil_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_ceiling.json")))
+    ceiling = json.load(open(ceil_files[-1])) if ceil_files else None
+    total_insts = 0.0
+    for fam, (tot_ms, cnt) in stats.items():
+        names = KERNEL_NAMES.get(fam)
+        if not names:
+            continue
+        f, per = newest_profile("sq", names)
+        if not f:
+            continue
+        ds = [per[k] for k in names if k in per]
+        if fam in ALTERNATIVE_FORMS:
+            ds = ds[:1]
+        insts = sum(d["valu_wave_insts_per_blob"] for d in ds)
+        wait = ds[0].get("wait_inst_any_frac")
+        rate = insts * blobs_per_launch_of(fam) / (tot_ms / cnt / 1e3)
+        total_insts += insts
+        out["per_kernel"][fam] = {"valu_wave_insts_per_blob": round(insts, 1), "achieved_wave_insts_per_s": rate,
+                                  "frac_of_nominal": round(rate / NOMINAL_WAVE_INSTS_PER_S, 4), "wait_inst_any_frac": wait}
+        out["source"] = os.path.relpath(f, ROOT)
+    if total_insts:
+        out["path_valu_wave_insts_per_blob"] = round(total_insts, 1)
+        out["path_achieved_wave_insts_per_s"] = total_insts * blobs_per_s_per_gpu
+        out["path_frac_of_nominal"] = round(total_insts * blobs_per_s_per_gpu / NOMINAL_WAVE_INSTS_PER_S, 4)
+        out["nominal_ceiling_blobs_per_s"] = round(NOMINAL_WAVE_INSTS_PER_S / total_insts, 1)
+    if ceiling:
+        out["measured_ceiling"] = ceiling
+        if total_insts and ceiling.get("path_mix_wave_insts_per_s"):
+            out["path_frac_of_measured_ceiling"] = round(total_insts * blobs_per_s_per_gpu / ceiling["path_mix_wave_insts_per_s"], 4)
+    return out
+
+
+def run_sweep(args, kz, L, s, dev, random_blob):
+    """benches/kzg_benches.rs:46-126 restated: the five single-op benches and verify_blob_kzg_proof_batch/{1,...,64}, each a
+    single call on host buffers through the drop-in C ABI (criterion's iter_batched_ref shape: inputs built outside the timed
+    call), median and min over repeated calls, next to the CPU port (oracle, 1 thread) on the same inputs."""
+    from oracle.oracle import Oracle, build
+    n_max = 64
+    blobs = [random_blob(i) for i in range(n_max)]
+    B = [kz.Blob(b) for b in blobs]
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, s)
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, s)
+    cb, pb = [c.to_bytes() for c in cs], [p.to_bytes() for p in ps]
+    z = bytes(31) + b"\x05"
+    try:
+        build(native=True); o = Oracle(native=True)
+    except Exception:
+        o = Oracle(native=False)
+    golden = os.path.join(ROOT, "tests", "golden")
+    so = o.load_trusted_setup(open(os.path.join(golden, "trusted_setup_g1.bin"), "rb").read(), open(os.path.join(golden, "trusted_setup_g2.bin"), "rb").read())
+
+    def timeit(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+        return {"median_ms": round(statistics.median(ts), 4), "min_ms": round(min(ts), 4)}
+
+    proof0, y0 = kz.Kzg.compute_kzg_proof(B[0], kz.Bytes32(z), s)
+    gpu_ops = {
+        "blob_to_kzg_commitment": lambda: kz.Kzg.blob_to_kzg_commitment(B[0], s),
+        "compute_kzg_proof": lambda: kz.Kzg.compute_kzg_proof(B[0], kz.Bytes32(z), s),
+        "compute_blob_kzg_proof": lambda: kz.Kzg.compute_blob_kzg_proof(B[0], cs[0], s),
+        "verify_kzg_proof": lambda: kz.Kzg.verify_kzg_proof(cs[0], kz.Bytes32(z), y0, proof0, s),
+        "verify_blob_kzg_proof": lambda: kz.Kzg.verify_blob_kzg_proof(B[0], cs[0], ps[0], s),
+    }
+    cpu_ops = {
+        "blob_to_kzg_commitment": lambda: o.blob_to_kzg_commitment(blobs[0], so),
+        "compute_kzg_proof": lambda: o.compute_kzg_proof(blobs[0], z, so),
+        "compute_blob_kzg_proof": lambda: o.compute_blob_kzg_proof(blobs[0], cb[0], so),
+        "verify_kzg_proof": lambda: o.verify_kzg_proof(cb[0], z, y0.to_bytes(), proof0.to_bytes(), so),
+        "verify_blob_kzg_proof": lambda: o.verify_blob_kzg_proof(blobs[0], cb[0], pb[0], so),
+    }
+    single = {}
+    for name in gpu_ops:
+        assert gpu_ops[name]() is not False
+        single[name] = {"gpu": timeit(gpu_ops[name], 15), "cpu_port_1_thread": timeit(cpu_ops[name], 5, warm=1)}
+    sweep = {}
+    flat = b"".join(blobs)
+    ok1 = C.c_bool()
+    for n in (1, 2, 4, 8, 16, 32, 64):
+        cc, pp = b"".join(cb[:n]), b"".join(pb[:n])
+
+        def gpu_call():
+            rc = L.kzg355_verify_blob_kzg_proof_batch(C.byref(ok1), flat, n, cc, n, pp, n, s.handle)
+            assert rc == 0 and ok1.value
+        g = timeit(gpu_call, 15)
+        c = timeit(lambda: o.verify_blob_kzg_proof_batch(blobs[:n], cb[:n], pb[:n], so), 3 if n >= 16 else 5, warm=1)
+        sweep[str(n)] = {"gpu": dict(g, blobs_per_s=round(n / (g["median_ms"] / 1e3), 1)),
+                         "cpu_port_1_thread": dict(c, blobs_per_s=round(n / (c["median_ms"] / 1e3), 1))}
+    o.free_trusted_setup(so)
+    g64 = sweep["64"]["gpu"]
+    return {"metric": OP_METRIC["verify"] + " -- criterion sweep, single calls on host inputs", "value": g64["blobs_per_s"], "unit": "blobs/s",
+            "n_gpus": 1, "steps": 15, "warmup": 2, "ms_per_step": g64["median_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
+            "config": {"workload": "benches/kzg_benches.rs:46-126: five single-op benches + verify_blob_kzg_proof_batch/{1,2,4,8,16,32,64}, one call at a time, host buffers",
+                       "single_op": single, "verify_blob_kzg_proof_batch": sweep},
+            "roofline": None, "cpu_baseline": {"value": sweep["64"]["cpu_port_1_thread"]["blobs_per_s"], "unit": "blobs/s", "cores": 1, "kind": "port",
+                                               "sample": "per-n / per-op figures under config; oracle -O3 -march=native, restatement in portable C, not blst"}}
 
 
 def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
@@ -300,7 +512,7 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = max(1, min(cores, 256))
     done = [0] * cores
     t_end = time.perf_counter() + 6.0
     def worker(k):
@@ -324,7 +536,7 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
     return {"value": units / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; restatement in portable C, not blst "
                       f"(blst's asm is likely 1.5-3x faster per core)",
-            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "note": "same work, one call per thread, ~6 s"}}
+            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "note": "same work, one call per thread, every core this process may run on, ~6 s"}}
 
 
 if __name__ == "__main__":

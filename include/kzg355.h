@@ -139,6 +139,10 @@ int kzg355_debug_batch_intermediates(uint8_t *out /* groups*128, host */, bool *
  * kernel family on that handle ("verify_eval", "msm_bucket", ...), measured with HIP events on the launch stream;
  * returns a negative number if that kernel has not run.  Used by bench.py for the roofline line. */
 int kzg355_settings_device(const kzg355_settings *s);
+/* Which MSM form commitments / proofs take on this handle: 12, 13 or 14 = wide-window table of that digit width; 8 = the 8-bit
+ * bucket form because KZG355_MSM=bucket asked for it; -8 = the bucket form because the wide table could NOT be allocated (also
+ * reported once on stderr by the load function; KZG355_MSM=wide makes that a load error instead). */
+int kzg355_settings_msm_form(const kzg355_settings *s);
 double kzg355_last_kernel_ms(const kzg355_settings *s, const char *kernel_family);
 /* Accumulated HIP-event time and launch count of a kernel family since timing was enabled / last reset. 0 on success. */
 int kzg355_kernel_ms_stats(const kzg355_settings *s, const char *kernel_family, double *total_ms, long *launches);

@@ -53,6 +53,7 @@ def load():
         "kzg355_debug_batch_intermediates": [u8p, bp, ip, vp, sz, sz, vp],
         "kzg355_kernel_ms_stats": [vp, u8p, C.POINTER(C.c_double), C.POINTER(C.c_long)],
         "kzg355_settings_device": [vp],
+        "kzg355_settings_msm_form": [vp],
         "kzg355_set_kernel_timing": [vp, C.c_int],
     }
     for name, args in sigs.items():
@@ -79,5 +80,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_compute_blob_kzg_proof_many_device", "kzg355_verify_shard_records_device", "kzg355_verify_records_device",
     "kzg355_settings_device", "kzg355_last_kernel_ms", "kzg355_set_kernel_timing", "kzg355_version",
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
-    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates",
+    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form",
 ]

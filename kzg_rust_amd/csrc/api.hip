@@ -5,12 +5,15 @@
 #include "../../include/kzg355.h"
 #include "kernels.h"
 
+#include <sched.h>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace kzg;
@@ -63,11 +66,18 @@ struct Workspace {
     bool side_pending = false;      // work on the side stream that the main stream has not waited for yet
     DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials;
     PinBuf h_ok, h_err, h_out;
+    PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
     hipEvent_t ev[32];
     bool ev_ok = false;
+    bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
+    // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
+    void quiesce() {
+        if (in_flight || side_pending) { if (side) hipStreamSynchronize(side); if (stream) hipStreamSynchronize(stream); }
+        in_flight = false; side_pending = false;
+    }
     ~Workspace() {
         for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials}) b->release();
-        h_ok.release(); h_err.release(); h_out.release();
+        h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release();
         if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
@@ -77,6 +87,62 @@ struct Workspace {
 };
 
 }  // namespace
+
+// Host threads that copy caller memory into pinned staging buffers (one 64 KiB-granular slice each); the calling thread
+// takes a slice too.  A single memcpy stream moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s: the copy into pinned memory has to be
+// parallel for the link to be the limit.
+class CopyPool {
+public:
+    explicit CopyPool(int workers) {
+        for (int i = 0; i < workers; i++) th_.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int workers() const { return (int)th_.size(); }
+    void copy(void *dst, const void *src, size_t bytes) {
+        const size_t parts = th_.size() + 1;
+        if (th_.empty() || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
+        std::unique_lock<std::mutex> call(call_mu_);             // one parallel copy at a time
+        const size_t per = ((bytes / parts) + 65535) & ~(size_t)65535;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; bytes_ = bytes; per_ = per; pending_ = (int)th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        slice(th_.size());
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+private:
+    void slice(size_t k) {
+        const size_t lo = k * per_;
+        if (lo >= bytes_) return;
+        const size_t n = bytes_ - lo < per_ ? bytes_ - lo : per_;
+        memcpy(dst_ + lo, src_ + lo, n);
+    }
+    void run(int i) {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            slice((size_t)i);
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_;
+    uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr;
+    size_t bytes_ = 0, per_ = 0;
+    int pending_ = 0; unsigned long gen_ = 0; bool stop_ = false;
+};
 
 struct kzg355_settings {
     int device = 0;
@@ -88,6 +154,10 @@ struct kzg355_settings {
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
     std::mutex mu;
     std::vector<Workspace *> pool;
+    CopyPool *copy_pool = nullptr;  // created with the handle (KZG355_COPY_THREADS, default min(8, cores / 2) - 1 workers)
+    size_t chunk_bytes = (size_t)512 << 20;   // blobs per chunk of a host-buffer call (KZG355_CHUNK_MB)
+    int chunks_in_flight = 3;                 // workspaces (pinned slot + device buffers + stream) a host-buffer call rotates over
+    bool wide_table_failed = false;           // the wide-window MSM table was wanted but could not be allocated / built
     bool timing = false;
     struct KStat { double last = -1, total = 0; long count = 0; };
     std::map<std::string, KStat> last_ms;
@@ -119,7 +189,7 @@ struct WsGuard {
     WsGuard(const kzg355_settings *cs) : s(const_cast<kzg355_settings *>(cs)), w(nullptr) {
         if (s && hipSetDevice(s->device) == hipSuccess) w = ws_acquire(s);
     }
-    ~WsGuard() { if (w) ws_release(s, w); }
+    ~WsGuard() { if (w) { w->quiesce(); ws_release(s, w); } }
 };
 
 // Optional per-kernel-family timing with HIP events on the launch stream (kzg355_set_kernel_timing).
@@ -221,6 +291,7 @@ int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
     if ((rc = w->ok.ensure(sizeof(int) * (size_t)G))) return rc;
     if ((rc = w->h_ok.ensure(sizeof(int) * (size_t)G))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * (size_t)G))) return rc;
+    w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
     if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
     if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
@@ -231,6 +302,7 @@ int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
 // ... and wait for it: verdicts / statuses of its G batches.  Returns the first non-OK status.
 int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G) {
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     int first = KZG355_OK;
     for (int i = 0; i < G; i++) {
@@ -272,7 +344,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
     int rc = verify_enqueue(a.s, a.w, ta, d_blobs, d_c, d_p, (int)npg, (int)ga);
     if (rc) return rc;
     rc = verify_enqueue(b.s, b.w, tb, d_blobs + (size_t)BLOB_BYTES * npg * ga, d_c + 48 * npg * ga, d_p + 48 * npg * ga, (int)npg, (int)gb);
-    if (rc) { hipStreamSynchronize(a.w->stream); return rc; }
+    if (rc) return rc;                            // (the guards wait for whatever is in flight)
     const int ra = verify_collect(a.w, ta, ok, status, (int)ga);
     const int rb = verify_collect(b.w, tb, ok + ga, status ? status + ga : nullptr, (int)gb);
     return ra != KZG355_OK ? ra : rb;
@@ -282,6 +354,16 @@ int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes)
     int rc = dst.ensure(bytes);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, w->stream));
+    return KZG355_OK;
+}
+// Caller memory -> this workspace's pinned slot (parallel host copy) -> device (asynchronous DMA on w->stream).
+// The workspace must be idle (its previous launch set collected): the pinned slot is reused.
+int stage_via_pinned(kzg355_settings *s, Workspace *w, PinBuf &pin, size_t pin_off, DevBuf &dst, const uint8_t *src, size_t bytes) {
+    int rc;
+    if ((rc = dst.ensure(bytes))) return rc;
+    if (s->copy_pool) s->copy_pool->copy(pin.as<uint8_t>() + pin_off, src, bytes);
+    else memcpy(pin.as<uint8_t>() + pin_off, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst.p, pin.as<uint8_t>() + pin_off, bytes, hipMemcpyHostToDevice, w->stream));
     return KZG355_OK;
 }
 
@@ -308,21 +390,38 @@ int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_
     return KZG355_OK;
 }
 
-int commit_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, size_t n, const kzg355_settings *cs) {
-    if (!cs || !out) return KZG355_BADARGS;
-    if (n == 0) return KZG355_OK;
-    if (n > (size_t)1 << 20) return KZG355_BADARGS;
-    WsGuard g(cs);
-    if (!g.w) return KZG355_NO_DEVICE;
-    kzg355_settings *s = g.s; Workspace *w = g.w;
+// proofs for n blobs at challenge points already in w->z (Montgomery); err accumulates per blob
+int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, int n) {
+    int rc;
+    if ((rc = w->y.ensure(sizeof(Fr) * (size_t)n))) return rc;
+    if ((rc = w->q.ensure(sizeof(Fr) * (size_t)n * N_FE))) return rc;
+    tm.begin("quotient"); launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<Fr>(), w->err.as<int>(), w->stream); tm.end();
+    return msm_to_host(s, w, tm, n, nullptr, w->q.as<Fr>());
+}
+
+// n commitments (d_c == null) or n blob proofs against the commitments d_c: enqueue on w->stream ...
+int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n) {
     int rc;
     if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
+    if (d_c && (rc = w->z.ensure(sizeof(Fr) * n))) return rc;
+    w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
-    Timed tm(s, w);
-    if ((rc = msm_to_host(s, w, tm, (int)n, d_blobs, nullptr))) return rc;
+    if (!d_c) {
+        if ((rc = msm_to_host(s, w, tm, (int)n, d_blobs, nullptr))) return rc;
+    } else {
+        // compute_challenge validates the commitment (kzg.rs:321-323); one "group" per blob so errors stay per blob
+        tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end();
+        tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form); tm.end();
+        if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
+    }
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
+    return KZG355_OK;
+}
+// ... and wait for it: 48-byte outputs / statuses of its n blobs.  Returns the first non-OK status.
+int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n) {
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     int first = KZG355_OK;
     for (size_t i = 0; i < n; i++) {
@@ -334,41 +433,80 @@ int commit_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, s
     return first;
 }
 
-// proofs for n blobs at challenge points already in w->z (Montgomery); err accumulates per blob
-int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, int n) {
-    int rc;
-    if ((rc = w->y.ensure(sizeof(Fr) * (size_t)n))) return rc;
-    if ((rc = w->q.ensure(sizeof(Fr) * (size_t)n * N_FE))) return rc;
-    tm.begin("quotient"); launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<Fr>(), w->err.as<int>(), w->stream); tm.end();
-    return msm_to_host(s, w, tm, n, nullptr, w->q.as<Fr>());
-}
-
-int blob_proof_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs) {
+int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs) {
     if (!cs || !out) return KZG355_BADARGS;
     if (n == 0) return KZG355_OK;
     if (n > (size_t)1 << 20) return KZG355_BADARGS;
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
-    kzg355_settings *s = g.s; Workspace *w = g.w;
-    int rc;
-    if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
-    if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
-    if ((rc = w->z.ensure(sizeof(Fr) * n))) return rc;
-    HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
-    Timed tm(s, w);
-    // compute_challenge validates the commitment (kzg.rs:321-323); one "group" per blob so errors stay per blob
-    tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end();
-    tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form); tm.end();
-    if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
-    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
-    HIPCHK(hipStreamSynchronize(w->stream));
-    tm.collect();
+    Timed tm(g.s, g.w);
+    int rc = msm_op_enqueue(g.s, g.w, tm, d_blobs, d_c, n);
+    if (rc) return rc;
+    return msm_op_collect(g.w, tm, out, status, n);
+}
+
+// The host-buffer pipeline shared by the three *_many entry points.  `units` independent units of work (batches of npg blobs
+// for verify, single blobs for commit / proof) are cut into chunks of <= chunk_bytes of blobs; chunk k goes through workspace
+// k mod W (W = chunks_in_flight): parallel host copy caller memory -> that workspace's PINNED slot, asynchronous H2D on its
+// stream, kernels, results.  While the host copies chunk k+1 the DMA engine moves chunk k and the kernels of chunk k-1 run, so
+// the call runs at the rate of its slowest leg (PCIe on this path) instead of the sum of the three.  Results are collected
+// in chunk order; a failure waits for everything in flight before the workspaces go back to the pool (WsGuard).
+struct HostCall {
+    int kind;                        // 0 verify, 1 commit, 2 blob proof
+    const uint8_t *blobs, *commitments, *proofs;
+    size_t npg;                      // blobs per unit
+    bool *ok; uint8_t *out48; int *status;
+};
+int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
+    kzg355_settings *s = const_cast<kzg355_settings *>(cs);
+    size_t upc = s->chunk_bytes / ((size_t)BLOB_BYTES * hc.npg);                   // units per chunk
+    if (upc < 1) upc = 1;
+    if (upc > units) upc = units;
+    const size_t nchunks = (units + upc - 1) / upc;
+    const int W = (int)(nchunks < (size_t)s->chunks_in_flight ? nchunks : (size_t)s->chunks_in_flight);
+    std::vector<WsGuard *> guards;
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{guards};
+    std::vector<Timed> tms;
+    for (int i = 0; i < W; i++) {
+        guards.push_back(new WsGuard(cs));
+        if (!guards.back()->w) return KZG355_NO_DEVICE;
+        tms.emplace_back(s, guards.back()->w);
+    }
+    struct Pending { size_t u0, cnt; };
+    std::vector<Pending> pend(W, Pending{0, 0});
     int first = KZG355_OK;
-    for (size_t i = 0; i < n; i++) {
-        int st = status_from_err(w->h_err.as<int>()[i]);
-        if (status) status[i] = st;
-        if (st == KZG355_OK) memcpy(out + 48 * i, w->h_out.as<uint8_t>() + 48 * i, 48);
-        else if (first == KZG355_OK) first = st;
+    auto collect = [&](int slot) -> int {
+        if (!pend[slot].cnt) return KZG355_OK;
+        Workspace *w = guards[slot]->w;
+        const size_t u0 = pend[slot].u0, cnt = pend[slot].cnt;
+        pend[slot].cnt = 0;
+        int rc = hc.kind == 0 ? verify_collect(w, tms[slot], hc.ok + u0, hc.status ? hc.status + u0 : nullptr, (int)cnt)
+                              : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt);
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return rc;
+        if (rc != KZG355_OK && first == KZG355_OK) first = rc;
+        return KZG355_OK;
+    };
+    size_t k = 0;
+    for (size_t u0 = 0; u0 < units; u0 += upc, k++) {
+        const size_t cnt = units - u0 < upc ? units - u0 : upc;
+        const int slot = (int)(k % W);
+        Workspace *w = guards[slot]->w;
+        int rc;
+        if ((rc = collect(slot))) return rc;                                       // frees this slot's pinned and device buffers
+        const size_t nb = cnt * hc.npg, off = u0 * hc.npg;
+        if ((rc = w->h_stage.ensure((size_t)BLOB_BYTES * nb))) return rc;
+        if ((rc = w->h_stage_cp.ensure(96 * nb))) return rc;
+        if ((rc = stage_via_pinned(s, w, w->h_stage, 0, w->blobs, hc.blobs + (size_t)BLOB_BYTES * off, (size_t)BLOB_BYTES * nb))) return rc;
+        if (hc.commitments && (rc = stage_via_pinned(s, w, w->h_stage_cp, 0, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
+        if (hc.proofs && (rc = stage_via_pinned(s, w, w->h_stage_cp, 48 * nb, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
+        if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt);
+        else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt);
+        if (rc) return rc;
+        pend[slot] = Pending{u0, cnt};
+    }
+    for (size_t j = 0; j < (size_t)W; j++) {                                       // remaining chunks, oldest first
+        int rc = collect((int)((k + j) % W));
+        if (rc) return rc;
     }
     return first;
 }
@@ -435,6 +573,16 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
         if (hipMemcpy(s->scheds.p, sc, sizeof sc, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
         s->t.coop_scheds = s->scheds.as<CoopSched>();
     }
+    {
+        cpu_set_t cpus; CPU_ZERO(&cpus);
+        int workers = sched_getaffinity(0, sizeof cpus, &cpus) == 0 ? CPU_COUNT(&cpus) / 2 : 1;     // cores this process may run on
+        if (workers > 8) workers = 8;
+        if (const char *e = getenv("KZG355_COPY_THREADS")) workers = atoi(e);
+        if (workers > 64) workers = 64;
+        if (workers > 1) s->copy_pool = new CopyPool(workers - 1);           // the calling thread is one of the copiers
+        if (const char *e = getenv("KZG355_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 16384) s->chunk_bytes = (size_t)v << 20; }
+        if (const char *e = getenv("KZG355_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->chunks_in_flight = v; }
+    }
     if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
     if (const char *e = getenv("KZG355_SPLIT")) s->split_big_calls = atoi(e) != 0;
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
@@ -457,8 +605,9 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
             s->t.wide = wide_shape(bits);
             if (s->wide.ensure(wide_table_bytes(s->t.wide)) == KZG355_OK) {
                 s->t.wide_table = s->wide.as<WideRow>();
-                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; } }
-            } else if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; }
+                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; } }
+            } else { s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_MEMORY; } }
+            if (s->wide_table_failed) fprintf(stderr, "kzg355: the %.1f GB wide-window MSM table could not be allocated; commitments / proofs take the 8-bit bucket form (about 3x slower, same results)\n", wide_table_bytes(s->t.wide) / 1e9);
             (void)hipGetLastError();
         }
     }
@@ -511,12 +660,18 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     hipSetDevice(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
+    delete s->copy_pool; s->copy_pool = nullptr;
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
 }
 
 int kzg355_settings_device(const kzg355_settings *s) { return s ? s->device : -1; }
+int kzg355_settings_msm_form(const kzg355_settings *s) {
+    if (!s) return 0;
+    if (s->t.wide_table) return s->t.wide.bits;
+    return s->wide_table_failed ? -8 : 8;
+}
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
 double kzg355_last_kernel_ms(const kzg355_settings *cs, const char *family) {
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
@@ -546,11 +701,12 @@ int kzg355_verify_blob_kzg_proof_batch_many_device(bool *ok, int *status, const 
     return verify_many_device_impl(ok, status, d_blobs, d_commitments, d_proofs, n_per_group, groups, s);
 }
 int kzg355_blob_to_kzg_commitment_many_device(uint8_t *out, int *status, const uint8_t *d_blobs, size_t n, const kzg355_settings *s) {
-    return commit_many_device_impl(out, status, d_blobs, n, s);
+    return msm_op_many_device_impl(out, status, d_blobs, nullptr, n, s);
 }
 int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments, size_t n,
                                               const kzg355_settings *s) {
-    return blob_proof_many_device_impl(out, status, d_blobs, d_commitments, n, s);
+    if (!d_commitments) return KZG355_BADARGS;
+    return msm_op_many_device_impl(out, status, d_blobs, d_commitments, n, s);
 }
 
 int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
@@ -648,40 +804,8 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t
     if (n == 0) return verify_many_device_impl(ok, status, nullptr, nullptr, nullptr, n_per_group, groups, cs);
     if (!blobs || !commitments || !proofs) return KZG355_BADARGS;
     if (n > (size_t)1 << 24) return KZG355_BADARGS;
-    // Host buffers: the batches are cut into chunks of <= 256 MiB of blobs and double-buffered over two workspaces, so
-    // the H2D copy of chunk k+1 (on its own stream) runs while the kernels of chunk k execute.
-    size_t gpc = ((size_t)256 << 20) / ((size_t)BLOB_BYTES * n_per_group);      // batches per chunk
-    if (gpc < 1) gpc = 1;
-    if (gpc > groups) gpc = groups;
-    WsGuard g0(cs), g1(cs);
-    if (!g0.w || !g1.w) return KZG355_NO_DEVICE;
-    kzg355_settings *s = g0.s;
-    Workspace *ws[2] = {g0.w, g1.w};
-    Timed tm0(s, ws[0]), tm1(s, ws[1]);
-    Timed *tms[2] = {&tm0, &tm1};
-    int first = KZG355_OK;
-    size_t prev_g0 = 0, prev_cnt = 0;
-    int k = 0;
-    for (size_t gstart = 0; gstart < groups; gstart += gpc, k++) {
-        const size_t cnt = groups - gstart < gpc ? groups - gstart : gpc;
-        Workspace *w = ws[k & 1];
-        const size_t nb = cnt * n_per_group, off = gstart * n_per_group;
-        int rc;
-        if ((rc = stage_to_device(w, w->blobs, blobs + (size_t)BLOB_BYTES * off, (size_t)BLOB_BYTES * nb))) return rc;
-        if ((rc = stage_to_device(w, w->commitments, commitments + 48 * off, 48 * nb))) return rc;
-        if ((rc = stage_to_device(w, w->proofs, proofs + 48 * off, 48 * nb))) return rc;
-        if ((rc = verify_enqueue(s, w, *tms[k & 1], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)n_per_group, (int)cnt))) return rc;
-        if (k > 0) {   // collect the previous chunk while this one runs
-            rc = verify_collect(ws[(k - 1) & 1], *tms[(k - 1) & 1], ok + prev_g0, status ? status + prev_g0 : nullptr, (int)prev_cnt);
-            if (rc == KZG355_NO_DEVICE) return rc;
-            if (rc != KZG355_OK && first == KZG355_OK) first = rc;
-        }
-        prev_g0 = gstart; prev_cnt = cnt;
-    }
-    int rc = verify_collect(ws[(k - 1) & 1], *tms[(k - 1) & 1], ok + prev_g0, status ? status + prev_g0 : nullptr, (int)prev_cnt);
-    if (rc == KZG355_NO_DEVICE) return rc;
-    if (rc != KZG355_OK && first == KZG355_OK) first = rc;
-    return first;
+    HostCall hc{0, blobs, commitments, proofs, n_per_group, ok, nullptr, status};
+    return host_pipeline(hc, groups, cs);
 }
 
 int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,
@@ -736,13 +860,9 @@ int kzg355_blob_to_kzg_commitment_many(uint8_t *out, int *status, const uint8_t 
     if (!cs || !out) return KZG355_BADARGS;
     if (n == 0) return KZG355_OK;
     if (!blobs) return KZG355_BADARGS;
-    WsGuard g(cs);
-    if (!g.w) return KZG355_NO_DEVICE;
-    Workspace *w = g.w;
-    int rc;
-    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
-    HIPCHK(hipStreamSynchronize(w->stream));
-    return commit_many_device_impl(out, status, w->blobs.as<uint8_t>(), n, cs);
+    if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    HostCall hc{1, blobs, nullptr, nullptr, 1, nullptr, out, status};
+    return host_pipeline(hc, n, cs);
 }
 int kzg355_blob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const kzg355_settings *s) {
     int st = KZG355_OK;
@@ -756,14 +876,9 @@ int kzg355_compute_blob_kzg_proof_many(uint8_t *out, int *status, const uint8_t 
     if (!cs || !out) return KZG355_BADARGS;
     if (n == 0) return KZG355_OK;
     if (!blobs || !commitments) return KZG355_BADARGS;
-    WsGuard g(cs);
-    if (!g.w) return KZG355_NO_DEVICE;
-    Workspace *w = g.w;
-    int rc;
-    if ((rc = stage_to_device(w, w->blobs, blobs, (size_t)BLOB_BYTES * n))) return rc;
-    if ((rc = stage_to_device(w, w->commitments, commitments, 48 * n))) return rc;
-    HIPCHK(hipStreamSynchronize(w->stream));
-    return blob_proof_many_device_impl(out, status, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), n, cs);
+    if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    HostCall hc{2, blobs, commitments, nullptr, 1, nullptr, out, status};
+    return host_pipeline(hc, n, cs);
 }
 int kzg355_compute_blob_kzg_proof(uint8_t proof_out[48], const uint8_t *blob, const uint8_t commitment[48], const kzg355_settings *s) {
     int st = KZG355_OK;

@@ -175,6 +175,12 @@ class KzgSettings:
     def device(self):
         return lib().kzg355_settings_device(self.handle)
 
+    @property
+    def msm_form(self):
+        """12 / 13 / 14: wide-window table of that digit width; 8: bucket form by request; -8: bucket form because the table
+        could not be allocated."""
+        return lib().kzg355_settings_msm_form(self.handle)
+
     def set_kernel_timing(self, enabled=True):
         lib().kzg355_set_kernel_timing(self.handle, 1 if enabled else 0)
 
