@@ -13,7 +13,7 @@ namespace kzg {
 constexpr int PAIRING_WAVES = 4;
 __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Affine *pair_pts, int groups,
                                                                       const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
-                                                                      const CoopInsn *prog, int n_insn, const CoopSched *scheds, int *ok) {
+                                                                      const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
     __shared__ CoopMem mems[PAIRING_WAVES];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g_raw = blockIdx.x * PAIRING_WAVES + wid;

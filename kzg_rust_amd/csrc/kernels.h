@@ -47,7 +47,7 @@ struct DeviceTables {
     FrobTables *frob;        // w-basis Frobenius tables
     CoopInsn *pairing_prog;  // the pairing check as an instruction list (pairing_coop.h)
     int pairing_prog_len;
-    CoopSched *coop_scheds;  // [2]: product and square work schedules
+    CoopScheds *coop_scheds; // product, square, line-product and cyclotomic-square work schedules
 };
 
 // ---- k_setup.hip

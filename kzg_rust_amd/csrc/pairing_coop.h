@@ -7,19 +7,23 @@
 //
 //   representation   Fp12 = Fp[w]/(w^12 - 2 w^6 + 2)  (w^2 = v, w^6 = 1 + u): a = sum_{k<12} a_k w^k, a_k in Fp.
 //                    Tower coefficient (x0 + x1 u) v^j w^i sits at m = 2j + i:  a_m += x0 - x1,  a_{m+6} += x1.
-//   product          phase 1: lane s (0..22) computes the convolution term d_s = sum_{i+j=s} a_i b_j.  The <= 12 limb
-//                    products are accumulated UNREDUCED in 64-bit columns (29-bit limbs leave room for 4 products
-//                    between carry sweeps) and Montgomery-reduced once.
-//                    phase 2: lane k (0..11) folds w^12 = 2 w^6 - 2:
-//                        k<=4: d_k - 2 d_{k+12} - 4 d_{k+18}   k=5: d_5 - 2 d_17
-//                        6<=k<=10: d_k + 2 d_{k+6} + 2 d_{k+12}  k=11: d_11 + 2 d_17
-//   square           same with d_s = 2 sum_{i<j} a_i a_j + a_{s/2}^2          (<= 6 limb products per lane)
-//   line product     a Miller-loop line  c0 + c1' v + c4' v w  has only w^{0,2,3,6,8,9} -> <= 6 limb products per lane
+//   product          phase 1: a lane takes <= 3 limb products a_i b_j of ONE convolution index s = i + j, accumulates them
+//                    UNREDUCED in 64-bit columns (29-bit limbs leave room for 4 products between carry sweeps) and
+//                    Montgomery-reduces its own partial sum once (the reduction is linear, so the sum of reduced partials is
+//                    the reduced sum) -> 14 limbs per lane in LDS.
+//                    phase 2: lane k (0..11) forms coefficient k directly as a small-integer combination of those partials:
+//                    the partials of d_k and the fold w^12 = 2 w^6 - 2 in one sweep
+//                        k<=5: d_k - 2 d_{k+12} - 4 d_{k+18}       k>=6: d_k + 2 d_{k+6} + 2 d_{k+12}
+//   square           same with d_s = 2 sum_{i<j} a_i a_j + a_{s/2}^2          (<= 2 limb products per lane)
+//   line product     a Miller-loop line  c0 + c1' v + c4' v w  has only w^{0,2,3,6,8,9} -> 72 limb products, <= 2 per lane
+//   cyclotomic sq.   Granger-Scott squaring for the final exponentiation's hard part (elements of the cyclotomic subgroup):
+//                    36 lanes, ONE limb product each, then the same combination phase
 //   Frobenius        a_k -> a_k gamma^k folded back, two constant products per lane; conjugation flips odd k.
 //
 // Operands live in a CoopMem block (LDS on the device); lanes only communicate through it, with a barrier between
 // phases.  The same source runs on the host for unit tests: COOP_LANES loops over the 64 lanes sequentially there.
 #pragma once
+#include <initializer_list>
 #include "pairing.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -42,33 +46,73 @@ constexpr uint32_t LINE_MASK = (1u << 0) | (1u << 2) | (1u << 3) | (1u << 6) | (
 constexpr uint32_t EVEN_MASK = 0x555u;
 constexpr uint32_t FULL_MASK = 0xfffu;
 
-// Work schedule of one product type: which limb products lane l accumulates (all for the same convolution index s),
-// and which lanes' partial sums convolution index s collects.
+constexpr int COOP_MAX_TERMS = 10;
+// Work schedule of one product type.  Phase 1: which limb products lane l accumulates (all for the same convolution index
+// s).  Phase 2: coefficient k = sum_j tc[k][j] * partial[tl[k][j]] + kp[k] * p  (the multiple of p keeps the value positive;
+// partials are < 1.04 p, so every coefficient stays below 32 p: the lazy bound of an Fp12W between operations).
 struct CoopSched {
     uint8_t s[64];            // convolution index this lane works for (255: idle)
     uint8_t np[64];           // number of (i, j) pairs, <= 3
     uint8_t pi[64][3], pj[64][3];
     uint8_t dbl[64];          // 1: the partial enters doubled (cross terms a_i a_j, i < j, of a square)
-    uint8_t first[23], cnt[23];   // lanes [first, first+cnt) hold the partials of index s
+    uint8_t nt[12], kp[12];
+    uint8_t tl[12][COOP_MAX_TERMS];
+    int8_t tc[12][COOP_MAX_TERMS];
 };
+// Granger-Scott squaring: lane l multiplies  (U[a0] + fa U[a1]) * (U[b0] + fb U[b1])  with fa, fb in {0, 1, 2} and
+// U = (a_0 .. a_11, 2, 0); phase 2 as above.
+struct CoopCycSched {
+    uint8_t act[64], a0[64], a1[64], fa[64], b0[64], b1[64], fb[64];
+    uint8_t nt[12], kp[12];
+    uint8_t tl[12][COOP_MAX_TERMS];
+    int8_t tc[12][COOP_MAX_TERMS];
+};
+struct CoopScheds { CoopSched mul, sqr, line; CoopCycSched cyc; };
+static_assert(sizeof(CoopScheds) % 4 == 0, "copied to LDS word by word");
 struct CoopMem {
     Fp12W f, t0, t1, t2, t3, t4;
     Fp12W line[2];
-    Fp d[23];
+    Fp cyc_consts[2];         // 2 (Montgomery form) and 0: entries 12, 13 of the cyclotomic squaring's operand table; must follow line[]
+    Fp red[64];               // the reduced partial of every lane (phase 1 -> phase 2)
     Fp px[2], py[2];
-    uint32_t part[64][2 * NFP];   // carried (normalised) partial column sums, one row per lane
-    CoopSched sched_mul, sched_sqr;
+    CoopScheds sc;
     int flag;
 };
 
+// Phase-2 tables of a product schedule from its lane -> convolution index map, with the bound check.
+inline bool coop_finish_sched(CoopSched &sc) {
+    bool ok = true;
+    for (int k = 0; k < 12; k++) {
+        int n = 0, neg = 0, pos = 0;
+        for (int l = 0; l < 64; l++) {
+            const int s = sc.s[l];
+            if (s == 255) continue;
+            int coef = 0;
+            if (s == k) coef = 1;
+            else if (k <= 5) coef = s == k + 12 ? -2 : s == k + 18 ? -4 : 0;
+            else coef = (s == k + 12 || s == k + 6) ? 2 : 0;
+            if (!coef) continue;
+            if (n == COOP_MAX_TERMS) { ok = false; break; }
+            sc.tl[k][n] = (uint8_t)l; sc.tc[k][n] = (int8_t)coef; n++;
+            if (coef < 0) neg -= coef; else pos += coef;
+        }
+        sc.nt[k] = (uint8_t)n;
+        const int K = (neg * 105 + 99) / 100;                    // partials are < 1.04 p
+        sc.kp[k] = (uint8_t)K;
+        if (pos * 105 + K * 100 >= 3100) ok = false;             // coefficient < 31 p
+    }
+    return ok;
+}
 // Schedules: convolution index s of a full product has c_s = min(s, 22 - s) + 1 limb products; it gets ceil(c_s / 3)
 // lanes (56 lanes in all).  A square has floor(c_s / 2) cross products (2 per lane, doubled) plus a_{s/2}^2 on a lane of
-// its own for even s.
-inline void build_coop_schedules(CoopSched &mul, CoopSched &sqr) {
-    for (int l = 0; l < 64; l++) { mul.s[l] = sqr.s[l] = 255; mul.np[l] = sqr.np[l] = 0; mul.dbl[l] = sqr.dbl[l] = 0; }
+// its own for even s.  A line product only has the 72 products with j in {0, 2, 3, 6, 8, 9}: 2 per lane.
+inline bool build_coop_schedules(CoopScheds &out) {
+    CoopSched &mul = out.mul, &sqr = out.sqr, &lin = out.line;
+    for (CoopSched *sc : {&mul, &sqr, &lin})
+        for (int l = 0; l < 64; l++) { sc->s[l] = 255; sc->np[l] = 0; sc->dbl[l] = 0; for (int k = 0; k < 3; k++) sc->pi[l][k] = sc->pj[l][k] = 0; }
+    bool ok = true;
     int lane = 0;
     for (int s = 0; s < 23; s++) {
-        mul.first[s] = (uint8_t)lane;
         int k = 0;
         for (int i = 0; i < 12; i++) {
             const int j = s - i;
@@ -77,12 +121,10 @@ inline void build_coop_schedules(CoopSched &mul, CoopSched &sqr) {
             mul.s[lane] = (uint8_t)s; mul.pi[lane][k] = (uint8_t)i; mul.pj[lane][k] = (uint8_t)j; mul.np[lane] = (uint8_t)(++k);
         }
         lane++;
-        mul.cnt[s] = (uint8_t)(lane - mul.first[s]);
     }
-    // (56 lanes used)
+    ok = ok && lane <= 64;
     lane = 0;
     for (int s = 0; s < 23; s++) {
-        sqr.first[s] = (uint8_t)lane;
         int k = 0; bool any = false;
         for (int i = 0; i < 12; i++) {
             const int j = s - i;
@@ -96,8 +138,73 @@ inline void build_coop_schedules(CoopSched &mul, CoopSched &sqr) {
             sqr.s[lane] = (uint8_t)s; sqr.pi[lane][0] = sqr.pj[lane][0] = (uint8_t)(s >> 1); sqr.np[lane] = 1; sqr.dbl[lane] = 0;
             lane++;
         }
-        sqr.cnt[s] = (uint8_t)(lane - sqr.first[s]);
     }
+    ok = ok && lane <= 64;
+    lane = 0;
+    for (int s = 0; s < 23; s++) {
+        int k = 0; bool any = false;
+        for (int i = 0; i < 12; i++) {
+            const int j = s - i;
+            if (j < 0 || j > 11 || !((LINE_MASK >> j) & 1u)) continue;
+            if (k == 2) { lane++; k = 0; }
+            lin.s[lane] = (uint8_t)s; lin.pi[lane][k] = (uint8_t)i; lin.pj[lane][k] = (uint8_t)j; lin.np[lane] = (uint8_t)(++k);
+            any = true;
+        }
+        if (any) lane++;
+    }
+    ok = ok && lane <= 64;
+    ok = coop_finish_sched(mul) && ok;
+    ok = coop_finish_sched(sqr) && ok;
+    ok = coop_finish_sched(lin) && ok;
+    // Granger-Scott squaring of g = sum g_i w^i, g_i = x0 + x1 u in Fp2 with x0 = a_i + a_{i+6}, x1 = a_{i+6}.  For the three
+    // Fp4 elements (g_t, g_{t+3}), t = 0, 1, 2, with (x, y) = (g_t, g_{t+3}) and a = a_t, b = a_{t+6}, c = a_{t+3}, d = a_{t+9}:
+    //   P1 = (a + 2b) a   [x0^2 - x1^2]   P2 = (a + b) b  [x0 x1]   P3 = (c + 2d) c  [y0^2 - y1^2]   P4 = (c + d) d  [y0 y1]
+    //   P5 = (a + b)(c + d) [x0 y0]       P6 = b d [x1 y1]          P7 = (a + b) d [x0 y1]           P8 = b (c + d) [x1 y0]
+    // and E_k = 2 a_k.  g^2 = (3 A^2 - 2 conj A) + (3 s C^2 + 2 conj B) w + (3 B^2 - 2 conj C) w^2 over Fp4 = Fp2[s], s = w^3, gives
+    //   t = 0:  a_0' = 3P1 - 6P2 - 12P4 - E0,  a_6' = 6P2 + 3P3 + 6P4 - E6,  a_3' = 6P5 - 6P6 - 6P7 - 6P8 + E3,  a_9' = 6P7 + 6P8 + E9
+    //   t = 1:  the same four rows for (a_2', a_8', a_5', a_11')
+    //   t = 2:  a_4', a_10' as the first two rows;  a_1' = -12P7 - 12P8 + E1,  a_7' = 6P5 - 6P6 + 6P7 + 6P8 + E7
+    // (checked against the generic square by tests/test_device_math_host.py).
+    CoopCycSched &cy = out.cyc;
+    for (int l = 0; l < 64; l++) { cy.act[l] = 0; cy.a0[l] = cy.a1[l] = cy.b0[l] = cy.b1[l] = 13; cy.fa[l] = cy.fb[l] = 0; }
+    auto prod = [&](int l, int a0, int a1, int fa, int b0, int b1, int fb) {
+        cy.act[l] = 1; cy.a0[l] = (uint8_t)a0; cy.a1[l] = (uint8_t)a1; cy.fa[l] = (uint8_t)fa; cy.b0[l] = (uint8_t)b0; cy.b1[l] = (uint8_t)b1; cy.fb[l] = (uint8_t)fb;
+    };
+    for (int t = 0; t < 3; t++) {
+        const int a = t, b = t + 6, c = t + 3, d = t + 9, l = 8 * t;
+        prod(l + 0, a, b, 2, a, 13, 0);     // P1
+        prod(l + 1, a, b, 1, b, 13, 0);     // P2
+        prod(l + 2, c, d, 2, c, 13, 0);     // P3
+        prod(l + 3, c, d, 1, d, 13, 0);     // P4
+        prod(l + 4, a, b, 1, c, d, 1);      // P5
+        prod(l + 5, b, 13, 0, d, 13, 0);    // P6
+        prod(l + 6, a, b, 1, d, 13, 0);     // P7
+        prod(l + 7, b, 13, 0, c, d, 1);     // P8
+    }
+    for (int k = 0; k < 12; k++) prod(24 + k, k, 13, 0, 12, 13, 0);       // E_k = 2 a_k
+    for (int k = 0; k < 12; k++) cy.nt[k] = 0;
+    auto term = [&](int k, int l, int coef) { const int n = cy.nt[k]; if (n < COOP_MAX_TERMS) { cy.tl[k][n] = (uint8_t)l; cy.tc[k][n] = (int8_t)coef; } else ok = false; cy.nt[k] = (uint8_t)(n + 1); };
+    const int lo_of[3] = {0, 2, 4}, hi_of[3] = {6, 8, 10};
+    for (int t = 0; t < 3; t++) {
+        const int l = 8 * t, lo = lo_of[t], hi = hi_of[t];
+        term(lo, l + 0, 3); term(lo, l + 1, -6); term(lo, l + 3, -12); term(lo, 24 + lo, -1);
+        term(hi, l + 1, 6); term(hi, l + 2, 3); term(hi, l + 3, 6); term(hi, 24 + hi, -1);
+    }
+    for (int t = 0; t < 2; t++) {
+        const int l = 8 * t, k3 = t == 0 ? 3 : 5, k9 = t == 0 ? 9 : 11;
+        term(k3, l + 4, 6); term(k3, l + 5, -6); term(k3, l + 6, -6); term(k3, l + 7, -6); term(k3, 24 + k3, 1);
+        term(k9, l + 6, 6); term(k9, l + 7, 6); term(k9, 24 + k9, 1);
+    }
+    term(1, 16 + 6, -12); term(1, 16 + 7, -12); term(1, 24 + 1, 1);
+    term(7, 16 + 4, 6); term(7, 16 + 5, -6); term(7, 16 + 6, 6); term(7, 16 + 7, 6); term(7, 24 + 7, 1);
+    for (int k = 0; k < 12; k++) {
+        int neg = 0, pos = 0;
+        for (int j = 0; j < cy.nt[k] && j < COOP_MAX_TERMS; j++) { if (cy.tc[k][j] < 0) neg -= cy.tc[k][j]; else pos += cy.tc[k][j]; }
+        const int K = (neg * 105 + 99) / 100;
+        cy.kp[k] = (uint8_t)K;
+        if (pos * 105 + K * 100 >= 3100) ok = false;
+    }
+    return ok;
 }
 
 // Tower line triple (pairing.h LineCoeff) -> w basis
@@ -145,30 +252,31 @@ KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
 }
 
 // ---------------------------------------------------------------------------------- cooperative Fp12 operations
-// phase 3 of every product: fold the 23 convolution terms with w^12 = 2 w^6 - 2:
-//     k <= 5:  c_k = d_k - 2 (d_{k+12} + 2 d_{k+18})        (d_23 = 0)
-//     k >= 6:  c_k = d_k + 2 (d_{k+12} + d_{k+6})           (d_23 = 0)
-// written without lane-dependent branches (a wave would execute every branch body one after the other).
-KZG_HD void coop_fold(Fp12W &dst, const Fp *d, int k) {
-    // lazy: d_s < 2p in, c_k < 18p out (k <= 5: d_k + 16p - 2 (v + 2x) with v, x < 2p; k >= 6: d_k + 2 (v + x) < 10p)
-    const uint32_t m16[NFP] = FP_MOD16_INIT;
-    const bool low = k <= 5;
-    const Fp zero = fp_zero();
-    Fp v, x, y, s2, lo, hi;
-    fp_select(v, k <= 10, zero, d[k + 12 <= 22 ? k + 12 : 22]);            // d_{k+12} or 0
-    fp_select(x, low, d[low ? 0 : k + 6], d[k <= 4 ? k + 18 : 0]);          // low: d_{k+18} (k <= 4), else d_{k+6}
-    if (k == 5) x = zero;
-    fp_add_lz(y, x, x); fp_select(x, low, x, y);                            // low: 2 d_{k+18}
-    fp_add_lz(v, v, x); fp_add_lz(s2, v, v);                                // 2 ( ... )            < 12p
-    fp_sub_lz(lo, d[k], s2, m16);                                           // d_k + 16p - 2 (...)  in (4p, 18p)
-    fp_add_lz(hi, d[k], s2);                                                //                      < 14p
-    fp_select(dst.c[k], low, hi, lo);
+// phase 2 of every product: out = sum_j coef_j * red[lane_j] + K p, limb-wise in signed 64-bit columns, one carry sweep.
+// The value is in [0, 31 p) by construction of the schedules, so the top limb keeps a small non-negative excess.
+KZG_HD void coop_combine(Fp &out, const Fp *red, const uint8_t *lanes, const int8_t *coefs, int n, int K) {
+    const uint32_t m[NFP] = FP_MOD_INIT;
+    int64_t acc[NFP];
+#pragma unroll
+    for (int i = 0; i < NFP; i++) acc[i] = (int64_t)K * (int64_t)m[i];
+    for (int j = 0; j < n; j++) {
+        const Fp &v = red[lanes[j]];
+        const int64_t c = coefs[j];
+#pragma unroll
+        for (int i = 0; i < NFP; i++) acc[i] += c * (int64_t)v.l[i];
+    }
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) {
+        const int64_t t = acc[i] + cy;
+        if (i < NFP - 1) { out.l[i] = (uint32_t)t & LMASK; cy = t >> LB; }
+        else out.l[i] = (uint32_t)t;
+    }
 }
 
-// Phases 1 and 2 of every product.  Phase 1: every lane accumulates its <= 3 limb products (unreduced 64-bit columns),
-// carries them and parks the 28 columns in m.part.  Phase 2: lane s < 23 adds up the partials of convolution index s
-// (doubling cross terms of a square), and Montgomery-reduces once -> m.d[s].
-KZG_HD void coop_convolve(CoopMem &m, const CoopSched &sc, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
+// dst = a * b (sc = mul / line schedule; for the line schedule b has non-zero coefficients only at w^{0,2,3,6,8,9}) or, with
+// sc = the square schedule and b = a, dst = a^2.  bmask: coefficients of b known to be zero are skipped.  dst may alias a or b.
+KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
     COOP_LANES(lane) {
         if (sc.s[lane] != 255) {
             uint64_t acc[2 * NFP];
@@ -179,38 +287,46 @@ KZG_HD void coop_convolve(CoopMem &m, const CoopSched &sc, const Fp12W &a, const
                 if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, b.c[j].l);
             }
             wide_carry(acc);
-#pragma unroll
-            for (int c = 0; c < 2 * NFP; c++) m.part[lane][c] = (uint32_t)acc[c];
+            if (sc.dbl[lane]) wide_double(acc);                  // columns < 2^29 after the carry sweep
+            Fp r; wide_reduce(r, acc);
+            m.red[lane] = r;
         }
     }
     COOP_SYNC();
+    COOP_LANES(lane) { if (lane < 12) coop_combine(dst.c[lane], m.red, sc.tl[lane], sc.tc[lane], sc.nt[lane], sc.kp[lane]); }
+    COOP_SYNC();
+}
+KZG_HD void coop_mul(CoopMem &m, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) { coop_product(m, m.sc.mul, dst, a, b, bmask); }
+KZG_HD void coop_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) { coop_product(m, m.sc.sqr, dst, a, a, FULL_MASK); }
+
+// dst = a^2 for a in the cyclotomic subgroup (a^(p^6+1) = 1 and a^(p^4-p^2+1) = 1): Granger-Scott.  dst may alias a.
+KZG_HD void coop_cyc_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
+    const CoopCycSched &sc = m.sc.cyc;
     COOP_LANES(lane) {
-        if (lane < 23) {
+        if (sc.act[lane]) {
+            const Fp *U = a.c;                                   // entries 12, 13 come from m.cyc_consts
+            auto get = [&](int idx) -> const Fp & { return idx < 12 ? U[idx] : m.cyc_consts[idx - 12]; };
+            auto operand = [&](Fp &o, int i0, int i1, int f) {
+                Fp t = get(i1), t2;
+                fp_add_lz(t2, t, t);
+                fp_select(t, f == 2, t, t2);
+                const Fp z = fp_zero();
+                fp_select(t, f == 0, t, z);
+                fp_add_lz(o, get(i0), t);
+            };
+            Fp x, y;
+            operand(x, sc.a0[lane], sc.a1[lane], sc.fa[lane]);
+            operand(y, sc.b0[lane], sc.b1[lane], sc.fb[lane]);
             uint64_t acc[2 * NFP];
             wide_zero(acc);
-            const int f = sc.first[lane], n = sc.cnt[lane];
-            for (int q = f; q < f + n; q++) {
-                const uint32_t sh = sc.dbl[q];
-#pragma unroll
-                for (int c = 0; c < 2 * NFP; c++) acc[c] += (uint64_t)m.part[q][c] << sh;
-            }
+            wide_mac(acc, x.l, y.l);
             wide_carry(acc);
-            wide_reduce(m.d[lane], acc);
+            Fp r; wide_reduce(r, acc);
+            m.red[lane] = r;
         }
     }
     COOP_SYNC();
-}
-
-// dst = a * b, b having non-zero coefficients only where bmask has a bit set.  dst may alias a or b.
-KZG_HD void coop_mul(CoopMem &m, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
-    coop_convolve(m, m.sched_mul, a, b, bmask);
-    COOP_LANES(lane) { if (lane < 12) coop_fold(dst, m.d, lane); }
-    COOP_SYNC();
-}
-// dst = a^2.  dst may alias a.
-KZG_HD void coop_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
-    coop_convolve(m, m.sched_sqr, a, a, FULL_MASK);
-    COOP_LANES(lane) { if (lane < 12) coop_fold(dst, m.d, lane); }
+    COOP_LANES(lane) { if (lane < 12) coop_combine(dst.c[lane], m.red, sc.tl[lane], sc.tc[lane], sc.nt[lane], sc.kp[lane]); }
     COOP_SYNC();
 }
 
@@ -304,7 +420,7 @@ KZG_HD void coop_frob2(Fp12W &dst, const Fp12W &a, const Fp *tab) {
 // them; spelled out as straight-line code the kernel was >0.5 MB of instructions (far beyond the 64 KB instruction
 // cache).  Instead the check is a flat list of instructions over 8 Fp12 slots, built once by build_pairing_program()
 // on the host, and the kernel is a small interpreter with ONE body per opcode.
-enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_EVEN, OP_LINE_EVAL, OP_CONJ, OP_FROB1, OP_FROB2, OP_FP6INV, OP_COPY };
+enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_EVEN, OP_LINE_EVAL, OP_CONJ, OP_FROB1, OP_FROB2, OP_FP6INV, OP_COPY, OP_CYC_SQR };
 struct CoopInsn { uint8_t op, dst, a, b; };
 enum : uint8_t { S_F = 0, S_T0 = 1, S_T1 = 2, S_T2 = 3, S_T3 = 4, S_T4 = 5, S_L0 = 6, S_L1 = 7 };
 constexpr int COOP_PROGRAM_MAX = 1024;
@@ -312,9 +428,9 @@ constexpr int COOP_PROGRAM_MAX = 1024;
 inline int build_pairing_program(CoopInsn *p) {
     int n = 0;
     auto emit = [&](uint8_t op, uint8_t d, uint8_t a, uint8_t b) { p[n].op = op; p[n].dst = d; p[n].a = a; p[n].b = b; n++; };
-    auto cyc_exp_x = [&](uint8_t d, uint8_t a) {           // d = a^x (x < 0): square-and-multiply over |x|, then conjugate
+    auto cyc_exp_x = [&](uint8_t d, uint8_t a) {           // d = a^x (x < 0), a in the cyclotomic subgroup: square-and-multiply over |x|, then conjugate
         emit(OP_COPY, d, a, 0);
-        for (int i = 62; i >= 0; i--) { emit(OP_SQR, d, d, 0); if ((BLS_X_ABS >> i) & 1) emit(OP_MUL, d, d, a); }
+        for (int i = 62; i >= 0; i--) { emit(OP_CYC_SQR, d, d, 0); if ((BLS_X_ABS >> i) & 1) emit(OP_MUL, d, d, a); }
         emit(OP_CONJ, d, d, 0);
     };
     // Miller loops of both pairs, sharing the squarings (utils.rs:206-209)
@@ -341,7 +457,7 @@ inline int build_pairing_program(CoopInsn *p) {
     cyc_exp_x(S_T1, S_T2); cyc_exp_x(S_T0, S_T1);                                             // b^(x^2)
     emit(OP_FROB2, S_T1, S_T2, 0); emit(OP_MUL, S_T0, S_T0, S_T1);                            // * b^(p^2)
     emit(OP_CONJ, S_T1, S_T2, 0); emit(OP_MUL, S_T0, S_T0, S_T1);                             // * b^-1
-    emit(OP_SQR, S_T1, S_F, 0); emit(OP_MUL, S_T1, S_T1, S_F);                                // f^3
+    emit(OP_CYC_SQR, S_T1, S_F, 0); emit(OP_MUL, S_T1, S_T1, S_F);                            // f^3
     emit(OP_MUL, S_T0, S_T0, S_T1);                                                           // verdict: slot T0 == 1 ?
     return n;
 }
@@ -352,16 +468,20 @@ KZG_HD Fp12W &coop_slot(CoopMem &m, int s) {
 }
 
 // Interpreter.  p1 / p2 = (0,0) (infinity) makes that pair contribute 1 (its line products are skipped).
-KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopSched *scheds, const LineW *lines1, const G1Affine &p1,
+KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,
                                const LineW *lines2, const G1Affine &p2, const FrobTables &ft) {
     const bool use1 = !g1a_is_inf(p1), use2 = !g1a_is_inf(p2);
     COOP_LANES(lane) {
-        {   // bring the two schedules next to the data (byte-wise copy, 64 lanes)
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(scheds);
-            uint8_t *dm = reinterpret_cast<uint8_t *>(&m.sched_mul), *ds = reinterpret_cast<uint8_t *>(&m.sched_sqr);
-            for (int o = lane; o < (int)sizeof(CoopSched); o += 64) { dm[o] = src[o]; ds[o] = src[sizeof(CoopSched) + o]; }
+        {   // bring the schedules next to the data (word-wise copy, 64 lanes)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(scheds);
+            uint32_t *dstw = reinterpret_cast<uint32_t *>(&m.sc);
+            for (int o = lane; o < (int)(sizeof(CoopScheds) / 4); o += 64) dstw[o] = src[o];
         }
-        if (lane == 0) { m.px[0] = p1.x; m.py[0] = p1.y; m.px[1] = p2.x; m.py[1] = p2.y; }
+        if (lane == 0) {
+            m.px[0] = p1.x; m.py[0] = p1.y; m.px[1] = p2.x; m.py[1] = p2.y;
+            Fp two = fp_one(); fp_add(two, two, two);
+            m.cyc_consts[0] = two; m.cyc_consts[1] = fp_zero();
+        }
         if (lane < 24) { m.line[lane / 12].c[lane % 12] = fp_zero(); }
     }
     COOP_SYNC();
@@ -372,12 +492,13 @@ KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, con
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
             const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2);
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
-            if (!skip) coop_mul(m, dst, a, coop_slot(m, in.b), mask);
+            if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask);
             continue;
         }
         switch (in.op) {
             case OP_SET_ONE: coop_set_one(dst); break;
             case OP_SQR: coop_sqr(m, dst, a); break;
+            case OP_CYC_SQR: coop_cyc_sqr(m, dst, a); break;
             case OP_LINE_EVAL: {
                 const int n = in.a;
                 COOP_LANES(lane) {                          // evaluate both lines at their points: 8 products on 8 lanes

@@ -194,9 +194,9 @@ int hd_pairings_verify_coop(int *ok, const uint8_t *p1, const uint8_t *q1, const
     static CoopInsn prog[COOP_PROGRAM_MAX];
     const int n_insn = build_pairing_program(prog);
     if (n_insn > COOP_PROGRAM_MAX) return 2;
-    static CoopSched sc[2];
-    build_coop_schedules(sc[0], sc[1]);
-    *ok = coop_pairing_check(*mem, prog, n_insn, sc, w1.data(), an, w2.data(), b, ft) ? 1 : 0;
+    static CoopScheds sc;
+    if (!build_coop_schedules(sc)) return 3;
+    *ok = coop_pairing_check(*mem, prog, n_insn, &sc, w1.data(), an, w2.data(), b, ft) ? 1 : 0;
     delete mem;
     return 0;
 }
