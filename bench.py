@@ -255,7 +255,7 @@ def main():
 
     host_inputs = None
     if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
-        host_inputs = host_leg(L, s, t_blobs, commitments, proofs, n_local, min(Cc, 256))
+        host_inputs = host_leg(L, s, t_blobs, commitments, proofs, n_local, min(Cc, 1024))
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
@@ -307,7 +307,7 @@ def stream_copy_peak(torch, dev):
 def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
     """The reference-shaped measurements (benches/kzg_benches.rs:97-122 times the whole call on host slices): blobs in pageable
     host memory, through the drop-in C ABI, H2D inside the call.  (a) one verify_blob_kzg_proof_batch(n = 64) call alone;
-    (b) `groups` batches streamed by one kzg355_verify_blob_kzg_proof_batch_many call (pinned staging ring inside the library)."""
+    (b) `groups` batches streamed by one kzg355_verify_blob_kzg_proof_batch_many call (chunked H2D / kernel pipeline inside the library)."""
     nb = groups * n_local
     h = t_blobs[:nb * BLOB].cpu().numpy()
     hp = h.ctypes.data_as(C.c_char_p)
@@ -333,7 +333,7 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
             "single_call_blobs_per_s": round(n_local / (statistics.median(lat) / 1e3), 1),
             "stream_blobs_per_s": round(statistics.median(rates), 1), "stream_blobs_per_s_best": round(best, 1),
             "stream_h2d_gbps": round(statistics.median(rates) * (BLOB + 96) / 1e9, 2), "stream_blobs_per_call": nb,
-            "note": "pageable caller memory -> pinned staging ring -> HBM inside the call; never `value`"}
+            "note": "pageable caller memory -> HBM inside the call (the runtime locks the caller's pages and DMAs from them, 512 MiB chunks over 3 streams); never `value`"}
 
 
 def newest_profile(stem, key):
@@ -512,31 +512,38 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 256))
-    done = [0] * cores
-    t_end = time.perf_counter() + 6.0
-    def worker(k):
-        j = k
-        while time.perf_counter() < t_end:
-            if op == "verify":
-                o.verify_blob_kzg_proof_batch(blobs, cs, ps, so); done[k] += n
-            elif op == "commit":
-                o.blob_to_kzg_commitment(blobs[j % n], so); done[k] += 1
-            else:
-                o.compute_blob_kzg_proof(blobs[j % n], cs[j % n], so); done[k] += 1
-            j += cores
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
-    for t in th: t.start()
-    for t in th: t.join()
-    all_cores = sum(done) / (time.perf_counter() - t0)
+    avail = max(1, cores)
+
+    def run_threads(cores):
+        done = [0] * cores
+        t_end = time.perf_counter() + 5.0
+        def worker(k):
+            j = k
+            while time.perf_counter() < t_end:
+                if op == "verify":
+                    o.verify_blob_kzg_proof_batch(blobs, cs, ps, so); done[k] += n
+                elif op == "commit":
+                    o.blob_to_kzg_commitment(blobs[j % n], so); done[k] += 1
+                else:
+                    o.compute_blob_kzg_proof(blobs[j % n], cs[j % n], so); done[k] += 1
+                j += cores
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+        for t in th: t.start()
+        for t in th: t.join()
+        return sum(done) / (time.perf_counter() - t0)
+    # the box's CPUs are shared with the other GPUs' jobs: try its per-GPU share and every CPU this process may run on, keep the better
+    trials = {c: run_threads(c) for c in sorted({min(avail, 64), avail})}
+    cores = max(trials, key=trials.get)
+    all_cores = trials[cores]
     o.free_trusted_setup(so)
     what = {"verify": "verify_blob_kzg_proof_batch(n=64) on the bench's first batch", "commit": "blob_to_kzg_commitment on blobs of the first batch",
             "proof": "compute_blob_kzg_proof on blobs of the first batch"}[op]
     return {"value": units / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; restatement in portable C, not blst "
                       f"(blst's asm is likely 1.5-3x faster per core)",
-            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "note": "same work, one call per thread, every core this process may run on, ~6 s"}}
+            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
+                          "note": "same work, one call per thread, ~5 s per trial; best of the trials"}}
 
 
 if __name__ == "__main__":

@@ -55,7 +55,7 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
 
 /* ---- trusted setup ---------------------------------------------------------------------------- */
 /* Kzg::load_trusted_setup (kzg.rs:1005 -> 45-78 -> 833-899).  g1: n1*48 bytes, g2: n2*96 bytes, compressed,
- * Lagrange form, file order.  n1 != 4096 or n2 != 65 -> INVALID_TRUSTED_SETUP; bad point / monomial form -> BADARGS.
+ * Lagrange form, file order.  n1 not in {4096} + {4, 8, .., 64} or n2 != 65 -> INVALID_TRUSTED_SETUP; bad point / monomial form -> BADARGS.
  * Builds the device-resident tables (roots of unity, bit-reversed G1 table and its per-window multiples,
  * Miller-loop line tables of the two G2 points the verify path uses) -- including the 23.6 GB wide-window MSM table
  * (every multiple 1..2048 of 2^(12w) * g1[i]); if that allocation fails, or with KZG355_MSM=bucket in the environment,
@@ -63,6 +63,11 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
 /* Kzg::load_trusted_setup_file (kzg.rs:995 -> 906-979): "4096\n65\n" + hex lines. */
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out);
+/* Minimal preset helper: n compressed MONOMIAL points [tau^k]G1 (n a power of two in [4, 64], e.g. the first four `setup_G1`
+ * entries of a ceremony JSON) -> the n compressed points of the size-n LAGRANGE setup, L_j = (1/n) sum_k w^(-jk) [tau^k]G1, in
+ * file (natural) order, ready for kzg355_load_trusted_setup.  (src/trusted_setup.rs:144-151 truncates the 4096-point Lagrange
+ * setup instead; that loads but is not a basis of the smaller domain.)  Bad point -> BADARGS. */
+int kzg355_lagrange_setup_from_monomial(uint8_t *out /* n*48 */, const uint8_t *monomial_g1 /* n*48 */, size_t n);
 /* Drop for KzgSettings. */
 void kzg355_free_trusted_setup(kzg355_settings *s);
 
@@ -139,6 +144,11 @@ int kzg355_debug_batch_intermediates(uint8_t *out /* groups*128, host */, bool *
  * kernel family on that handle ("verify_eval", "msm_bucket", ...), measured with HIP events on the launch stream;
  * returns a negative number if that kernel has not run.  Used by bench.py for the roofline line. */
 int kzg355_settings_device(const kzg355_settings *s);
+/* FIELD_ELEMENTS_PER_BLOB of the handle (consts.rs:13 is a compile-time 4096; the reference's README also names a minimal preset
+ * with 4).  It is fixed by the number of G1 points given to the load function: 4096 -> the mainnet kernels; a power of two in
+ * [4, 64] -> the small-domain path (one lane per blob, naive lincomb as utils.rs:369-371 takes below 8 points).  Every `blob`
+ * argument of this header is 32 * FIELD_ELEMENTS_PER_BLOB bytes for the handle it is passed with. */
+int kzg355_settings_field_elements_per_blob(const kzg355_settings *s);
 /* Which MSM form commitments / proofs take on this handle: 12, 13 or 14 = wide-window table of that digit width; 8 = the 8-bit
  * bucket form because KZG355_MSM=bucket asked for it; -8 = the bucket form because the wide table could NOT be allocated (also
  * reported once on stderr by the load function; KZG355_MSM=wide makes that a load error instead). */

@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <sched.h>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,8 @@ struct kzg355_settings {
     CopyPool *copy_pool = nullptr;  // created with the handle (KZG355_COPY_THREADS, default min(8, cores / 2) - 1 workers)
     size_t chunk_bytes = (size_t)512 << 20;   // blobs per chunk of a host-buffer call (KZG355_CHUNK_MB)
     int chunks_in_flight = 3;                 // workspaces (pinned slot + device buffers + stream) a host-buffer call rotates over
+    bool pinned_ring = false;                 // KZG355_STAGING=ring: stage caller memory through the workspaces' pinned slots; default: let the
+                                              // runtime lock the caller's pages and DMA from them (measured on MI355X hosts: 56 GB/s, no CPU copy)
     bool wide_table_failed = false;           // the wide-window MSM table was wanted but could not be allocated / built
     bool timing = false;
     struct KStat { double last = -1, total = 0; long count = 0; };
@@ -172,7 +175,8 @@ Workspace *ws_acquire(kzg355_settings *s) {
     }
     Workspace *w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
-    if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    // (the side stream is created on first use: HIP multiplexes its streams onto a handful of hardware queues, and every extra
+    // stream makes it likelier that the main streams of two workspaces share one and serialise)
     if (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { delete w; return nullptr; }
     bool ok = true;
     for (auto &e : w->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -218,6 +222,9 @@ struct Timed {
     }
 };
 
+inline bool is_small(const kzg355_settings *s) { return s->t.n_fe != N_FE; }
+inline size_t blob_bytes_of(const kzg355_settings *s) { return (size_t)32 * s->t.n_fe; }
+
 int status_from_err(int err) {
     if (err == 0) return KZG355_OK;
     return KZG355_BADARGS;   // validate_kzg_g1 / bytes_to_bls_field failures are Error::BadArgs (utils.rs:268, 292, 304)
@@ -228,12 +235,18 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
                int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err) {
     int rc;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
+    if (is_small(s)) {   // minimal preset: one lane per blob does conversion, challenge and evaluation (k_small.hip)
+        tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
+        tm.begin("small_records"); launch_small_records(d_blobs, d_c, d_p, n_total, npg, s->t, w->z.as<Fr>(), d_records, d_err, w->stream); tm.end();
+        return KZG355_OK;
+    }
     // Point validation depends on nothing but the inputs.  While the card is far from full (few batches) it runs on the side
     // stream next to the challenge -> evaluation (-> r powers) chain and the main stream waits for it only where the points
     // are first needed (join_side()).  With many batches in flight both kernels fill the card on their own and sharing the
     // SIMDs only slows the challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together:
     // one-wave workgroups of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
-    if (n_total <= 16384) {
+    if (n_total <= 16384 && !w->side && hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) { w->side = nullptr; (void)hipGetLastError(); }
+    if (n_total <= 16384 && w->side) {
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
         tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
@@ -259,7 +272,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
     if ((rc = w->lc_partials.ensure(lincomb_partials_bytes(npg, groups)))) return rc;
-    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream); tm.end();
+    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe); tm.end();
     // windowed per-term form (shortest chain) for few batches, bucket method (least issue work) when many are in flight
     const bool buckets = npg >= 8 && npg <= 4096 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
     if (buckets && (rc = w->lc_partials.ensure(lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
@@ -343,7 +356,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
     Timed ta(a.s, a.w), tb(b.s, b.w);
     int rc = verify_enqueue(a.s, a.w, ta, d_blobs, d_c, d_p, (int)npg, (int)ga);
     if (rc) return rc;
-    rc = verify_enqueue(b.s, b.w, tb, d_blobs + (size_t)BLOB_BYTES * npg * ga, d_c + 48 * npg * ga, d_p + 48 * npg * ga, (int)npg, (int)gb);
+    rc = verify_enqueue(b.s, b.w, tb, d_blobs + blob_bytes_of(cs) * npg * ga, d_c + 48 * npg * ga, d_p + 48 * npg * ga, (int)npg, (int)gb);
     if (rc) return rc;                            // (the guards wait for whatever is in flight)
     const int ra = verify_collect(a.w, ta, ok, status, (int)ga);
     const int rb = verify_collect(b.w, tb, ok + ga, status ? status + ga : nullptr, (int)gb);
@@ -407,7 +420,16 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
     if (d_c && (rc = w->z.ensure(sizeof(Fr) * n))) return rc;
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
-    if (!d_c) {
+    if (is_small(s)) {
+        if ((rc = w->out48.ensure(48 * n))) return rc;
+        if ((rc = w->h_out.ensure(48 * n))) return rc;
+        if (!d_c) { tm.begin("small_commit"); launch_small_commit(d_blobs, (int)n, s->t, w->out48.as<uint8_t>(), w->err.as<int>(), w->stream); tm.end(); }
+        else {
+            tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end();
+            tm.begin("small_proof"); launch_small_proof(d_blobs, d_c, nullptr, (int)n, s->t, w->out48.as<uint8_t>(), nullptr, w->err.as<int>(), w->stream); tm.end();
+        }
+        HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 48 * n, hipMemcpyDeviceToHost, w->stream));
+    } else if (!d_c) {
         if ((rc = msm_to_host(s, w, tm, (int)n, d_blobs, nullptr))) return rc;
     } else {
         // compute_challenge validates the commitment (kzg.rs:321-323); one "group" per blob so errors stay per blob
@@ -447,10 +469,15 @@ int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, c
 
 // The host-buffer pipeline shared by the three *_many entry points.  `units` independent units of work (batches of npg blobs
 // for verify, single blobs for commit / proof) are cut into chunks of <= chunk_bytes of blobs; chunk k goes through workspace
-// k mod W (W = chunks_in_flight): parallel host copy caller memory -> that workspace's PINNED slot, asynchronous H2D on its
-// stream, kernels, results.  While the host copies chunk k+1 the DMA engine moves chunk k and the kernels of chunk k-1 run, so
-// the call runs at the rate of its slowest leg (PCIe on this path) instead of the sum of the three.  Results are collected
-// in chunk order; a failure waits for everything in flight before the workspaces go back to the pool (WsGuard).
+// k mod W (W = chunks_in_flight): H2D on its stream, kernels, results.  Two ways to move the bytes:
+//   direct (default)  hipMemcpyAsync straight from the caller's pageable memory: the runtime locks the pages and DMAs from them
+//                     (no CPU copy; 56.5 GB/s = the PCIe 5 x16 link on the MI355X hosts measured).  The call blocks the host
+//                     thread for the duration of the copy, which is exactly the pacing wanted: the next chunk's copy is issued the
+//                     moment the link is free, while the kernels of the previous chunks run on their own streams.
+//   ring (KZG355_STAGING=ring)  parallel host copy into the workspace's pinned slot, then an asynchronous H2D from there.
+//                     Measured slower here (300 k against 395 k blobs/s on an 8 GiB call): the CPU copy and the DMA compete
+//                     for host memory bandwidth; kept for hosts where page locking is expensive.
+// Results are collected in chunk order; a failure waits for everything in flight before the workspaces go back to the pool.
 struct HostCall {
     int kind;                        // 0 verify, 1 commit, 2 blob proof
     const uint8_t *blobs, *commitments, *proofs;
@@ -459,28 +486,28 @@ struct HostCall {
 };
 int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
-    const size_t unit_bytes = (size_t)BLOB_BYTES * hc.npg;
+    const size_t BB = blob_bytes_of(cs);
+    const size_t unit_bytes = BB * hc.npg;
     size_t upc = s->chunk_bytes / unit_bytes;                                       // units per full-size chunk
     if (upc < 1) upc = 1;
     if (upc > units) upc = units;
-    // The first chunks are small (64 MiB, doubling up to the full size): the card starts working after a ~2 ms copy instead of
-    // waiting for a full chunk, and the DMA engine is busy from then on.
+    // One launch set is a ~10 ms chain of latency-bound kernels whatever its size (up to ~1000 batches), and the chains of
+    // successive chunks mostly serialise on the card: a chunk must carry more than 10 ms of PCIe traffic (~600 MiB) for the link,
+    // not the chain, to set the pace.  So: full-size chunks (1 GiB by default), except a small first one (64 MiB) that gets the
+    // card started after a ~2 ms copy; its chain runs under the H2D of the second chunk.
     std::vector<size_t> sizes;
     {
-        size_t ramp = ((size_t)64 << 20) / unit_bytes;
-        if (ramp < 1) ramp = 1;
-        for (size_t left = units; left;) {
-            size_t c = ramp < upc ? ramp : upc;
-            if (c > left) c = left;
-            sizes.push_back(c); left -= c;
-            if (ramp < upc) ramp *= 2;
-        }
+        size_t head = ((size_t)64 << 20) / unit_bytes;
+        if (head < 1) head = 1;
+        size_t left = units;
+        if (left > upc) { const size_t c = head < left ? head : left; sizes.push_back(c); left -= c; }
+        while (left) { const size_t c = upc < left ? upc : left; sizes.push_back(c); left -= c; }
     }
     const size_t nchunks = sizes.size();
     const int W = (int)(nchunks < (size_t)s->chunks_in_flight ? nchunks : (size_t)s->chunks_in_flight);
     // a call that fits one small chunk (a single 64-blob batch is 8 MiB) goes straight from caller memory: the runtime's own
     // staged copy moves it at link speed (measured 52 GB/s for 8 MiB), one pass over the bytes instead of two
-    const bool direct = nchunks == 1 && unit_bytes * units <= ((size_t)32 << 20);
+    const bool direct = !s->pinned_ring || (nchunks == 1 && unit_bytes * units <= ((size_t)32 << 20));
     std::vector<WsGuard *> guards;
     struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{guards};
     std::vector<Timed> tms;
@@ -503,34 +530,62 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         if (rc != KZG355_OK && first == KZG355_OK) first = rc;
         return KZG355_OK;
     };
+    const bool dbg = getenv("KZG355_DEBUG_PIPE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0, t_stage = 0, t_enq = 0, t_alloc = 0;
+    std::vector<hipEvent_t> dev_ev;                                  // debug only: H2D start / H2D end / kernels end per chunk
+    if (dbg) { dev_ev.resize(3 * nchunks); for (auto &e : dev_ev) hipEventCreate(&e); }
+    const double t_begin = now();
     size_t u0 = 0;
     for (size_t k = 0; k < nchunks; u0 += sizes[k], k++) {
         const size_t cnt = sizes[k];
         const int slot = (int)(k % W);
         Workspace *w = guards[slot]->w;
         int rc;
+        double t0 = now();
         if ((rc = collect(slot))) return rc;                                       // frees this slot's pinned and device buffers
+        t_wait += now() - t0; t0 = now();
         const size_t nb = cnt * hc.npg, off = u0 * hc.npg;
         if (direct) {
-            if ((rc = stage_to_device(w, w->blobs, hc.blobs + (size_t)BLOB_BYTES * off, (size_t)BLOB_BYTES * nb))) return rc;
+            if ((rc = stage_to_device(w, w->blobs, hc.blobs + BB * off, BB * nb))) return rc;
             if (hc.commitments && (rc = stage_to_device(w, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
             if (hc.proofs && (rc = stage_to_device(w, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
         } else {
-            if ((rc = w->h_stage.ensure((size_t)BLOB_BYTES * nb))) return rc;
+            if ((rc = w->h_stage.ensure(BB * nb))) return rc;
             if ((rc = w->h_stage_cp.ensure(96 * nb))) return rc;
-            if ((rc = stage_via_pinned(s, w, w->h_stage, 0, w->blobs, hc.blobs + (size_t)BLOB_BYTES * off, (size_t)BLOB_BYTES * nb))) return rc;
+            if ((rc = w->blobs.ensure(BB * nb))) return rc;
+            t_alloc += now() - t0; t0 = now();
+            if (dbg) hipEventRecord(dev_ev[3 * k], w->stream);
+            if ((rc = stage_via_pinned(s, w, w->h_stage, 0, w->blobs, hc.blobs + BB * off, BB * nb))) return rc;
+            if (dbg) hipEventRecord(dev_ev[3 * k + 1], w->stream);
             if (hc.commitments && (rc = stage_via_pinned(s, w, w->h_stage_cp, 0, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
             if (hc.proofs && (rc = stage_via_pinned(s, w, w->h_stage_cp, 48 * nb, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
         }
+        t_stage += now() - t0; t0 = now();
         if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt);
         else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt);
         if (rc) return rc;
+        if (dbg && !direct) hipEventRecord(dev_ev[3 * k + 2], w->stream);
+        t_enq += now() - t0;
         pend[slot] = Pending{u0, cnt};
     }
+    const double t_loop = now();
     for (size_t j = 0; j < (size_t)W; j++) {                                       // remaining chunks, oldest first
         int rc = collect((int)((nchunks + j) % W));
         if (rc) return rc;
     }
+    if (dbg && !direct) {
+        for (size_t k = 0; k < nchunks; k++) {
+            float h2d = 0, ker = 0, since = 0;
+            hipEventElapsedTime(&h2d, dev_ev[3 * k], dev_ev[3 * k + 1]); hipEventElapsedTime(&ker, dev_ev[3 * k + 1], dev_ev[3 * k + 2]);
+            hipEventElapsedTime(&since, dev_ev[0], dev_ev[3 * k]);
+            fprintf(stderr, "  chunk %zu (%zu units): H2D starts at %.1f ms, takes %.1f ms (%.1f GB/s), kernels %.1f ms\n", k, sizes[k], since, h2d,
+                    sizes[k] * unit_bytes / (h2d * 1e6), ker);
+        }
+        for (auto &e : dev_ev) hipEventDestroy(e);
+    }
+    if (dbg) fprintf(stderr, "kzg355 pipe: %zu chunks, W %d: alloc %.1f ms, host copy + H2D enqueue %.1f ms, kernel enqueue %.1f ms, waits in loop %.1f ms, drain %.1f ms, total %.1f ms\n",
+                     nchunks, W, t_alloc, t_stage, t_enq, t_wait, now() - t_loop, now() - t_begin);
     return first;
 }
 
@@ -546,7 +601,10 @@ const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montg
 
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out) {
     if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
-    if (n1 != (size_t)N_FE || n2 != (size_t)N_G2) return KZG355_INVALID_TRUSTED_SETUP;   // kzg.rs:49-62 (843: BadArgs)
+    // FIELD_ELEMENTS_PER_BLOB is a compile-time constant of the reference (consts.rs:13: 4096; its README's minimal preset: 4); here
+    // it is a property of the handle, taken from the number of G1 points: 4096, or a power of two in [4, 64] for the small path
+    const bool small = n1 >= (size_t)SMALL_N_MIN && n1 <= (size_t)SMALL_N_MAX && (n1 & (n1 - 1)) == 0;
+    if ((n1 != (size_t)N_FE && !small) || n2 != (size_t)N_G2) return KZG355_INVALID_TRUSTED_SETUP;   // kzg.rs:49-62 (843: BadArgs)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
     int dev = 0;
@@ -558,9 +616,10 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     DevBuf g1b, g2b, err;
     int rc = KZG355_OK;
     auto fail = [&](int code) { g1b.release(); g2b.release(); err.release(); kzg355_free_trusted_setup(s); return code; };
-    if ((rc = s->roots.ensure(sizeof(Fr) * N_FE))) return fail(rc);
-    if ((rc = s->eval_tab.ensure(sizeof(EvalGroupTab) * (N_FE / 4)))) return fail(rc);
-    if ((rc = s->msm_table.ensure(sizeof(G1Affine) * (size_t)N_FE * MSM_WINDOWS))) return fail(rc);
+    s->t.n_fe = (int)n1;
+    if ((rc = s->roots.ensure(sizeof(Fr) * n1))) return fail(rc);
+    if (!small && (rc = s->eval_tab.ensure(sizeof(EvalGroupTab) * (N_FE / 4)))) return fail(rc);
+    if ((rc = s->msm_table.ensure(sizeof(G1Affine) * n1 * (small ? 1 : MSM_WINDOWS)))) return fail(rc);
     if ((rc = s->lines.ensure(sizeof(LineCoeff) * 3 * N_LINES))) return fail(rc);
     if ((rc = s->lines_inf.ensure(sizeof(int) * 3))) return fail(rc);
     if ((rc = s->g1_first2.ensure(sizeof(G1Affine) * 2))) return fail(rc);
@@ -604,6 +663,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
         if (workers > 64) workers = 64;
         if (workers > 1) s->copy_pool = new CopyPool(workers - 1);           // the calling thread is one of the copiers
         if (const char *e = getenv("KZG355_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 16384) s->chunk_bytes = (size_t)v << 20; }
+        if (const char *e = getenv("KZG355_STAGING")) s->pinned_ring = strcmp(e, "ring") == 0;
         if (const char *e = getenv("KZG355_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->chunks_in_flight = v; }
     }
     if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
@@ -613,6 +673,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (small) launch_setup_small(g1b.as<uint8_t>(), (int)n1, s->t, err.as<int>(), nullptr);
     launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr);
     launch_lines_to_w(s->t, nullptr);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_NO_DEVICE);
@@ -622,7 +683,7 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     g1b.release(); g2b.release(); err.release();
     {   // the 23.6 GB wide-window MSM table (KZG355_MSM=bucket keeps the 15 MB 8-bit form only; so does a failed allocation)
         const char *e = getenv("KZG355_MSM");
-        if (!(e && strcmp(e, "bucket") == 0)) {
+        if (!small && !(e && strcmp(e, "bucket") == 0)) {
             int bits = 12;
             if (const char *b = getenv("KZG355_MSM_BITS")) { const int v = atoi(b); if (v >= 10 && v <= 14) bits = v; }
             s->t.wide = wide_shape(bits);
@@ -654,7 +715,7 @@ int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out) {
         return true;
     };
     size_t n1 = 0, n2 = 0;
-    if (!read_count(&n1) || n1 != (size_t)N_FE) { fclose(f); return KZG355_INVALID_TRUSTED_SETUP; }   // kzg.rs:916-932
+    if (!read_count(&n1) || (n1 != (size_t)N_FE && !(n1 >= (size_t)SMALL_N_MIN && n1 <= (size_t)SMALL_N_MAX && (n1 & (n1 - 1)) == 0))) { fclose(f); return KZG355_INVALID_TRUSTED_SETUP; }   // kzg.rs:916-932
     if (!read_count(&n2) || n2 != (size_t)N_G2) { fclose(f); return KZG355_INVALID_TRUSTED_SETUP; }   // kzg.rs:934-950
     std::vector<uint8_t> g1(48 * n1), g2(96 * n2);
     int rc = KZG355_OK;
@@ -678,6 +739,25 @@ int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out) {
     return kzg355_load_trusted_setup(g1.data(), n1, g2.data(), n2, out);
 }
 
+int kzg355_lagrange_setup_from_monomial(uint8_t *out, const uint8_t *monomial_g1, size_t n) {
+    if (!out || !monomial_g1) return KZG355_BADARGS;
+    if (n < (size_t)SMALL_N_MIN || n > (size_t)SMALL_N_MAX || (n & (n - 1))) return KZG355_BADARGS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
+    if (const char *e = getenv("KZG355_DEVICE")) HIPCHK(hipSetDevice(atoi(e)));
+    DevBuf in, res, err;
+    int rc = KZG355_OK;
+    auto done = [&](int code) { in.release(); res.release(); err.release(); return code; };
+    if ((rc = in.ensure(48 * n)) || (rc = res.ensure(48 * n)) || (rc = err.ensure(sizeof(int)))) return done(rc);
+    if (hipMemcpy(in.p, monomial_g1, 48 * n, hipMemcpyHostToDevice) != hipSuccess || hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return done(KZG355_NO_DEVICE);
+    launch_lagrange_from_monomial(in.as<uint8_t>(), (int)n, res.as<uint8_t>(), err.as<int>(), nullptr);
+    int herr = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_NO_DEVICE);
+    if (herr) return done(KZG355_BADARGS);
+    if (hipMemcpy(out, res.p, 48 * n, hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_NO_DEVICE);
+    return done(KZG355_OK);
+}
+
 void kzg355_free_trusted_setup(kzg355_settings *s) {
     if (!s) return;
     hipSetDevice(s->device);
@@ -690,6 +770,7 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
 }
 
 int kzg355_settings_device(const kzg355_settings *s) { return s ? s->device : -1; }
+int kzg355_settings_field_elements_per_blob(const kzg355_settings *s) { return s ? s->t.n_fe : 0; }
 int kzg355_settings_msm_form(const kzg355_settings *s) {
     if (!s) return 0;
     if (s->t.wide_table) return s->t.wide.bits;
@@ -917,7 +998,7 @@ int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uin
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
     int rc;
-    if ((rc = stage_to_device(w, w->blobs, blob, BLOB_BYTES))) return rc;
+    if ((rc = stage_to_device(w, w->blobs, blob, blob_bytes_of(cs)))) return rc;
     if ((rc = stage_to_device(w, w->small, z_bytes, 32))) return rc;
     if ((rc = w->err.ensure(sizeof(int)))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int)))) return rc;
@@ -927,8 +1008,15 @@ int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uin
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
     Timed tm(s, w);
     launch_fr_from_bytes(w->small.as<uint8_t>(), 1, w->z.as<Fr>(), w->err.as<int>(), w->stream);       // kzg.rs:452
-    if ((rc = prove_common(s, w, tm, w->blobs.as<uint8_t>(), 1))) return rc;
-    launch_fr_to_bytes(w->y.as<Fr>(), 1, w->records.as<uint8_t>(), w->stream);                         // kzg.rs:455
+    if (is_small(s)) {
+        if ((rc = w->out48.ensure(48))) return rc;
+        if ((rc = w->h_out.ensure(48))) return rc;
+        launch_small_proof(w->blobs.as<uint8_t>(), nullptr, w->z.as<Fr>(), 1, s->t, w->out48.as<uint8_t>(), w->records.as<uint8_t>(), w->err.as<int>(), w->stream);
+        HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 48, hipMemcpyDeviceToHost, w->stream));
+    } else {
+        if ((rc = prove_common(s, w, tm, w->blobs.as<uint8_t>(), 1))) return rc;
+        launch_fr_to_bytes(w->y.as<Fr>(), 1, w->records.as<uint8_t>(), w->stream);                     // kzg.rs:455
+    }
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->records.p, 32, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));

@@ -323,7 +323,7 @@ __constant__ uint32_t SHA_K[64] = {
 #define RP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
-                                                  uint32_t *scal_c, int *err) {
+                                                  uint32_t *scal_c, int *err, int n_fe) {
     __shared__ uint32_t wk_all[4][64][64];           // per wave: [t][block of the chunk]
     __shared__ uint32_t digest_all[4][8];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, 
                     const uint32_t idx = 16u * b + (uint32_t)t;
                     uint32_t v;
                     if (idx < 8u) {
-                        const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)N_FE, 0u, (uint32_t)n};
+                        const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)n_fe, 0u, (uint32_t)n};
                         v = hdr[idx];                                   // "RCKZGBATCH___V1_" | 4096 | n
                     } else if (idx < total_words) v = bswap32(reinterpret_cast<const uint32_t *>(rec)[idx - 8u]);   // records are 4-byte aligned
                     else if (idx == total_words) v = 0x80000000u;
@@ -455,12 +455,12 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
     hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, t.eval_tab, n_per_group, d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
-                    uint32_t *d_scal_c, int *d_err, hipStream_t st) {
+                    uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe) {
     if (groups <= 0) return;
     // four waves per workgroup once there are more batches than CUs can take one each (even placement); below that one wave per
     // workgroup: four of these LDS-latency-bound single-lane chains on one CU slow each other down (512-blob batches: 3x)
     const int wpw = groups > 512 ? 4 : 1;
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err);
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe);
 }
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;

@@ -35,6 +35,7 @@ constexpr int ERR_SETUP_MONOMIAL = 8;      // is_trusted_setup_in_lagrange_form 
 struct alignas(128) WideRow { Fp x, y; uint32_t pad[4]; };       // one affine point per 128-byte line
 
 struct DeviceTables {
+    int n_fe;                // FIELD_ELEMENTS_PER_BLOB of this handle: 4096 (mainnet) or a small power of two (minimal preset: 4)
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
     EvalGroupTab *eval_tab;  // [1024] per group of four domain points: w^-1, w^4 (eval_core.h)
     WideShape wide;          // shape of wide_table
@@ -67,7 +68,7 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
 // stage 2 (per group of n records): points from records, r-powers, lincomb, pairing
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st);
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
-                    uint32_t *d_scal_c, int *d_err, hipStream_t st);
+                    uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe = N_FE /* the u64be(FIELD_ELEMENTS_PER_BLOB) field of the transcript */);
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                     int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, G1Affine *d_pair_pts /* [group][2] */,
                     hipStream_t st);
@@ -95,6 +96,16 @@ void launch_digits_from_blobs(const uint8_t *d_blobs, int n, uint8_t *d_digits /
 void launch_digits_from_fr(const Fr *d_scalars /* [n][4096] Montgomery */, int n, uint8_t *d_digits, hipStream_t st);
 void launch_msm_bucket(const uint8_t *d_digits, DeviceTables t, int n, G1Jac *d_partials /* [n][32] */, hipStream_t st);
 void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48 /* [n][48] */, hipStream_t st, int ppb = 0 /* partials per blob; 0: bucket form */);
+
+// ---- k_small.hip: handles with 4 <= FIELD_ELEMENTS_PER_BLOB <= 64 (minimal preset); t.msm_table holds the n bit-reversed points
+constexpr int SMALL_N_MIN = 4, SMALL_N_MAX = 64;
+void launch_lagrange_from_monomial(const uint8_t *d_mono, int n, uint8_t *d_out /* n*48 */, int *d_err, hipStream_t st);
+void launch_setup_small(const uint8_t *d_g1_bytes, int n, DeviceTables t, int *d_err, hipStream_t st);
+void launch_small_records(const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p /* may be null */, int n_total, int npg, DeviceTables t, Fr *d_z /* may be null */,
+                          uint8_t *d_records /* may be null */, int *d_err /* per group */, hipStream_t st);
+void launch_small_commit(const uint8_t *d_blobs, int n_blobs, DeviceTables t, uint8_t *d_out48, int *d_err /* per blob */, hipStream_t st);
+// proofs at d_z (Montgomery, one per blob) or, if d_c != null, at each blob's own Fiat-Shamir challenge; d_y32 (32-byte y per blob) may be null
+void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_z, int n_blobs, DeviceTables t, uint8_t *d_out48, uint8_t *d_y32, int *d_err, hipStream_t st);
 
 // ---- k_prove.hip
 // quotient polynomial q(X) = (p(X) - y)/(X - z) in evaluation form (kzg.rs:461-523) for n blobs; also y.

@@ -119,7 +119,7 @@ class Bytes48(_Fixed):
 
 
 class Blob(_Fixed):
-    """kzg.rs:154-178."""
+    """kzg.rs:154-178 (mainnet preset: 4096 field elements; kzg_rust_amd.kzg_minimal.Blob is the 4-element one)."""
     SIZE = BYTES_PER_BLOB
 
 
@@ -176,6 +176,11 @@ class KzgSettings:
         return lib().kzg355_settings_device(self.handle)
 
     @property
+    def field_elements_per_blob(self):
+        """4096 (mainnet) or 4 (minimal preset): fixed by the number of G1 points the handle was loaded from."""
+        return lib().kzg355_settings_field_elements_per_blob(self.handle)
+
+    @property
     def msm_form(self):
         """12 / 13 / 14: wide-window table of that digit width; 8: bucket form by request; -8: bucket form because the table
         could not be allocated."""
@@ -203,6 +208,15 @@ def _b(x, cls):
     return x.bytes if isinstance(x, _Fixed) else cls(x).bytes
 
 
+def _blob(x, s):
+    """Blob bytes for the handle's preset: the newtype's length rule (kzg.rs:160-173) with BYTES_PER_BLOB = 32 * FIELD_ELEMENTS_PER_BLOB."""
+    b = x.bytes if isinstance(x, _Fixed) else bytes(x)
+    want = 32 * s.field_elements_per_blob
+    if len(b) != want:
+        raise InvalidBytesLength(f"Invalid byte length. Expected {want} got {len(b)}")
+    return b
+
+
 class Kzg:
     """pub struct Kzg (kzg.rs:983-1079): the seven associated functions, forwarded to the HIP engine."""
 
@@ -217,19 +231,19 @@ class Kzg:
     @staticmethod
     def blob_to_kzg_commitment(blob, s):  # kzg.rs:1013
         out = C.create_string_buffer(48)
-        _check(lib().kzg355_blob_to_kzg_commitment(out, _b(blob, Blob), s.handle), "blob_to_kzg_commitment")
+        _check(lib().kzg355_blob_to_kzg_commitment(out, _blob(blob, s), s.handle), "blob_to_kzg_commitment")
         return KzgCommitment(out.raw)
 
     @staticmethod
     def compute_kzg_proof(blob, z_bytes, s):  # kzg.rs:1021
         pr, y = C.create_string_buffer(48), C.create_string_buffer(32)
-        _check(lib().kzg355_compute_kzg_proof(pr, y, _b(blob, Blob), _b(z_bytes, Bytes32), s.handle), "compute_kzg_proof")
+        _check(lib().kzg355_compute_kzg_proof(pr, y, _blob(blob, s), _b(z_bytes, Bytes32), s.handle), "compute_kzg_proof")
         return KzgProof(pr.raw), Bytes32(y.raw)
 
     @staticmethod
     def compute_blob_kzg_proof(blob, commitment, s):  # kzg.rs:1030
         pr = C.create_string_buffer(48)
-        _check(lib().kzg355_compute_blob_kzg_proof(pr, _b(blob, Blob), _b(commitment, KzgCommitment), s.handle), "compute_blob_kzg_proof")
+        _check(lib().kzg355_compute_blob_kzg_proof(pr, _blob(blob, s), _b(commitment, KzgCommitment), s.handle), "compute_blob_kzg_proof")
         return KzgProof(pr.raw)
 
     @staticmethod
@@ -242,13 +256,13 @@ class Kzg:
     @staticmethod
     def verify_blob_kzg_proof(blob, commitment, proof, s):  # kzg.rs:1050
         ok = C.c_bool()
-        _check(lib().kzg355_verify_blob_kzg_proof(C.byref(ok), _b(blob, Blob), _b(commitment, KzgCommitment), _b(proof, KzgProof), s.handle),
+        _check(lib().kzg355_verify_blob_kzg_proof(C.byref(ok), _blob(blob, s), _b(commitment, KzgCommitment), _b(proof, KzgProof), s.handle),
                "verify_blob_kzg_proof")
         return bool(ok.value)
 
     @staticmethod
     def verify_blob_kzg_proof_batch(blobs, commitments, proofs, s):  # kzg.rs:1066
-        bl = [_b(x, Blob) for x in blobs]
+        bl = [_blob(x, s) for x in blobs]
         cs = [_b(x, KzgCommitment) for x in commitments]
         ps = [_b(x, KzgProof) for x in proofs]
         ok = C.c_bool()
@@ -259,7 +273,7 @@ class Kzg:
     # ---- throughput extensions (no reference counterpart; same semantics per unit) ----
     @staticmethod
     def blob_to_kzg_commitment_many(blobs, s):
-        bl = [_b(x, Blob) for x in blobs]
+        bl = [_blob(x, s) for x in blobs]
         n = len(bl)
         out = C.create_string_buffer(48 * max(n, 1))
         st = (C.c_int * max(n, 1))()
@@ -270,7 +284,7 @@ class Kzg:
 
     @staticmethod
     def compute_blob_kzg_proof_many(blobs, commitments, s):
-        bl = [_b(x, Blob) for x in blobs]
+        bl = [_blob(x, s) for x in blobs]
         cs = [_b(x, KzgCommitment) for x in commitments]
         if len(bl) != len(cs):
             raise BadArgs("length mismatch")
@@ -292,7 +306,7 @@ class Kzg:
         for bl, cs, ps in groups:
             if not (len(bl) == len(cs) == len(ps) == npg):
                 raise BadArgs("all groups must have the same size")
-            flat_b += [_b(x, Blob) for x in bl]
+            flat_b += [_blob(x, s) for x in bl]
             flat_c += [_b(x, KzgCommitment) for x in cs]
             flat_p += [_b(x, KzgProof) for x in ps]
         G = len(groups)

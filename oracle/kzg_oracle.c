@@ -20,7 +20,11 @@
 #include <string.h>
 #include <ctype.h>
 
+/* FIELD_ELEMENTS_PER_BLOB is a compile-time constant in the reference (src/consts.rs:13); its README advertises a mainnet
+ * (4096) and a minimal (4) preset.  The same source builds both oracles: -DN_FE=4 gives liboracle_minimal.so. */
+#ifndef N_FE
 #define N_FE 4096
+#endif
 #define BYTES_PER_BLOB (N_FE * 32)
 #define N_G2 65
 #define OK 0
@@ -308,10 +312,11 @@ EXPORT int okzg_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uin
     }
     if (rc == OK) {                                             /* kzg.rs:764-799: root = 7^((r-1)/2^12) */
         fr_t seven, root, cur = FR_ONE; fr_from_u64(&seven, 7);
-        /* (r-1)/4096 as 64-bit chunks: exponentiate via repeated fr_pow on limbs */
+        /* (r-1)/2^max_scale as 64-bit chunks (= SCALE2_ROOT_OF_UNITY[max_scale], consts.rs:163-168): exponentiate via square-and-multiply */
         uint64_t e[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
         e[0] -= 1;
-        for (int i = 0; i < 4; i++) e[i] = (e[i] >> 12) | (i < 3 ? e[i + 1] << 52 : 0);
+        if (max_scale < 1 || max_scale > 32) rc = BADARGS;
+        else for (int i = 0; i < 4; i++) e[i] = (e[i] >> max_scale) | (i < 3 ? e[i + 1] << (64 - max_scale) : 0);
         root = FR_ONE;
         for (int i = 255; i >= 0; i--) { fr_sqr(&root, &root); if ((e[i / 64] >> (i % 64)) & 1) fr_mul(&root, &root, &seven); }
         fr_t *expanded = malloc(n1 * sizeof(fr_t));
@@ -464,6 +469,7 @@ EXPORT void okzg_get_g1_values(uint8_t *out, const okzg_settings *s) { for (int 
 
 /* ---------------------------------------------------------------- primitive probes (canonical big-endian bytes in/out) */
 EXPORT void okzg_init(void) { bls_init(); }
+EXPORT int okzg_field_elements_per_blob(void) { return N_FE; }
 EXPORT void okzg_sha256(uint8_t out[32], const uint8_t *msg, size_t len) { sha256(out, msg, len); }
 EXPORT int okzg_fp_op(int op, uint8_t out[48], const uint8_t a[48], const uint8_t b[48]) {
     bls_init(); fp_t x, y, r;

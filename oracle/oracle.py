@@ -23,20 +23,23 @@ def build(native=False):
     subprocess.run(["make", "-C", _HERE, target], check=True, stdout=subprocess.DEVNULL)
 
 
-def _load(native=False):
-    name = "liboracle_native.so" if native else "liboracle.so"
+def _load(native=False, preset="mainnet"):
+    name = "liboracle_minimal.so" if preset == "minimal" else "liboracle_native.so" if native else "liboracle.so"
     path = os.path.join(_HERE, name)
     if not os.path.exists(path):
-        build(native)
+        build(native and preset != "minimal")
     lib = C.CDLL(path)
     lib.okzg_init()
     return lib
 
 
 class Oracle:
-    def __init__(self, native=False):
-        self.lib = _load(native)
+    def __init__(self, native=False, preset="mainnet"):
+        """preset "mainnet": FIELD_ELEMENTS_PER_BLOB = 4096; "minimal": 4 (the same source built with -DN_FE=4)."""
+        self.lib = _load(native, preset)
         L = self.lib
+        self.field_elements_per_blob = L.okzg_field_elements_per_blob()
+        self.bytes_per_blob = 32 * self.field_elements_per_blob
         vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_char_p
         L.okzg_load_trusted_setup.argtypes = [u8p, sz, u8p, sz, C.POINTER(vp)]
         L.okzg_load_trusted_setup_file.argtypes = [u8p, C.POINTER(vp)]
@@ -87,7 +90,7 @@ class Oracle:
 
     # ---- the seven entry points
     def blob_to_kzg_commitment(self, blob, s):
-        assert len(blob) == BYTES_PER_BLOB
+        assert len(blob) == self.bytes_per_blob
         out = C.create_string_buffer(48)
         rc = self.lib.okzg_blob_to_kzg_commitment(out, bytes(blob), s)
         if rc:
@@ -95,7 +98,7 @@ class Oracle:
         return out.raw
 
     def compute_kzg_proof(self, blob, z, s):
-        assert len(blob) == BYTES_PER_BLOB and len(z) == 32
+        assert len(blob) == self.bytes_per_blob and len(z) == 32
         pr, y = C.create_string_buffer(48), C.create_string_buffer(32)
         rc = self.lib.okzg_compute_kzg_proof(pr, y, bytes(blob), bytes(z), s)
         if rc:
@@ -103,7 +106,7 @@ class Oracle:
         return pr.raw, y.raw
 
     def compute_blob_kzg_proof(self, blob, c, s):
-        assert len(blob) == BYTES_PER_BLOB and len(c) == 48
+        assert len(blob) == self.bytes_per_blob and len(c) == 48
         pr = C.create_string_buffer(48)
         rc = self.lib.okzg_compute_blob_kzg_proof(pr, bytes(blob), bytes(c), s)
         if rc:
@@ -119,7 +122,7 @@ class Oracle:
         return bool(ok.value)
 
     def verify_blob_kzg_proof(self, blob, c, proof, s):
-        assert len(blob) == BYTES_PER_BLOB and len(c) == 48 and len(proof) == 48
+        assert len(blob) == self.bytes_per_blob and len(c) == 48 and len(proof) == 48
         ok = C.c_bool()
         rc = self.lib.okzg_verify_blob_kzg_proof(C.byref(ok), bytes(blob), bytes(c), bytes(proof), s)
         if rc:
@@ -127,7 +130,7 @@ class Oracle:
         return bool(ok.value)
 
     def verify_blob_kzg_proof_batch(self, blobs, cs, proofs, s):
-        assert all(len(b) == BYTES_PER_BLOB for b in blobs)
+        assert all(len(b) == self.bytes_per_blob for b in blobs)
         assert all(len(c) == 48 for c in cs) and all(len(p) == 48 for p in proofs)
         ok = C.c_bool()
         rc = self.lib.okzg_verify_blob_kzg_proof_batch(C.byref(ok), b"".join(blobs), len(blobs), b"".join(cs), len(cs),
@@ -163,12 +166,12 @@ class Oracle:
                 "z": [zy.raw[64 * i:64 * i + 32] for i in range(n)], "y": [zy.raw[64 * i + 32:64 * i + 64] for i in range(n)]}
 
     def roots_of_unity(self, s):
-        out = C.create_string_buffer(4096 * 32)
+        out = C.create_string_buffer(self.field_elements_per_blob * 32)
         self.lib.okzg_get_roots_of_unity(out, s)
         return out.raw
 
     def g1_values(self, s):
-        out = C.create_string_buffer(4096 * 48)
+        out = C.create_string_buffer(self.field_elements_per_blob * 48)
         self.lib.okzg_get_g1_values(out, s)
         return out.raw
 

@@ -35,6 +35,13 @@ G2_GEN = (
 
 FIELD_ELEMENTS_PER_BLOB = 4096
 BYTES_PER_BLOB = 4096 * 32
+
+
+def set_preset(field_elements_per_blob):
+    """The reference's FIELD_ELEMENTS_PER_BLOB is a compile-time constant (src/consts.rs:13): 4096 (mainnet) or 4 (minimal)."""
+    global FIELD_ELEMENTS_PER_BLOB, BYTES_PER_BLOB
+    FIELD_ELEMENTS_PER_BLOB = field_elements_per_blob
+    BYTES_PER_BLOB = 32 * field_elements_per_blob
 FIAT_SHAMIR_PROTOCOL_DOMAIN = b"FSBLOBVERIFY_V1_"
 RANDOM_CHALLENGE_KZG_BATCH_DOMAIN = b"RCKZGBATCH___V1_"
 
@@ -377,7 +384,7 @@ class Settings:
         g2 = [g2_uncompress(b) for b in g2_bytes]
         if check_lagrange and pairings_verify(g1[1], g2[0], g1[0], g2[1]):  # kzg.rs:802-830
             raise KzgError("monomial form")
-        self.roots = compute_roots_of_unity()
+        self.roots = compute_roots_of_unity(FIELD_ELEMENTS_PER_BLOB)
         self.g1 = bit_reversal_permutation(g1)
         self.g2 = g2
 

@@ -41,3 +41,8 @@ def random_field_element(index):
     b = bytearray(words.astype("<u8").tobytes())
     b[0] = 0
     return bytes(b)
+
+
+def splitmix64_bytes(seed, n_bytes):
+    """n_bytes of the same little-endian splitmix64 stream (minimal-preset fixtures, tests/golden/make_minimal_fixtures.py)."""
+    return _splitmix64_vec(seed, (n_bytes + 7) // 8).astype("<u8").tobytes()[:n_bytes]

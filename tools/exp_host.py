@@ -27,11 +27,15 @@ del tb
 s0.free()
 ok = (C.c_bool * G)(); sg = (C.c_int * G)()
 print(f"{n} blobs ({n * 131072 / 2**30:.1f} GiB) per call, cpus {len(os.sched_getaffinity(0))}", flush=True)
-for chunk, inflight, threads in [(512, 3, None), (256, 3, None), (1024, 3, None), (128, 4, None), (512, 2, None), (512, 4, None), (512, 3, 1), (512, 3, 4), (512, 3, 16), (2048, 2, None)]:
+CONFIGS = [(512, 3, None), (256, 4, None), (1024, 3, None), (512, 3, 1)]
+if len(sys.argv) > 2:
+    CONFIGS = [tuple(int(v) if v != "auto" else None for v in c.split(",")) for c in sys.argv[2:]]
+for chunk, inflight, threads in CONFIGS:
     os.environ["KZG355_CHUNK_MB"] = str(chunk); os.environ["KZG355_CHUNKS_IN_FLIGHT"] = str(inflight)
     if threads: os.environ["KZG355_COPY_THREADS"] = str(threads)
     else: os.environ.pop("KZG355_COPY_THREADS", None)
     os.environ["KZG355_MSM"] = "bucket"       # no 24 GB table per experiment handle
+    if os.environ.get("STAGING"): os.environ["KZG355_STAGING"] = os.environ["STAGING"]
     s = kz.Kzg.load_trusted_setup(g1l, g2l)
     ts = []
     for i in range(4):
