@@ -61,6 +61,16 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
  * (every multiple 1..2048 of 2^(12w) * g1[i]); if that allocation fails, or with KZG355_MSM=bucket in the environment,
  * only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results). */
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
+/* The same over several GPUs of one node: a full replica of the tables per device, and the host-buffer entry points below spread
+ * their work over the devices INSIDE the call, invisibly to the caller (the reference has no notion of devices): independent
+ * batches / blobs go to the devices in contiguous ranges with no exchange; a call with fewer batches than devices (one 512-blob
+ * batch on 8 GPUs) cuts every batch into per-device blocks of blobs, runs stage 1 per block, exchanges the 160-byte records with
+ * ONE all-gather (RCCL ncclAllGather over xGMI on a communicator set kept in the handle; peer copies if RCCL is not available,
+ * the device list has duplicates, the blocks are ragged, or KZG355_EXCHANGE=peer) and runs stage 2 of each batch on one device.
+ * kzg355_load_trusted_setup does the same when KZG355_DEVICES=0,1,... is set.  The *_device entry points (device pointers) and
+ * kzg355_settings_device refer to the first device of the list. */
+int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
+                                      kzg355_settings **out);
 /* Kzg::load_trusted_setup_file (kzg.rs:995 -> 906-979): "4096\n65\n" + hex lines. */
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out);
 /* Minimal preset helper: n compressed MONOMIAL points [tau^k]G1 (n a power of two in [4, 64], e.g. the first four `setup_G1`
@@ -144,6 +154,11 @@ int kzg355_debug_batch_intermediates(uint8_t *out /* groups*128, host */, bool *
  * kernel family on that handle ("verify_eval", "msm_bucket", ...), measured with HIP events on the launch stream;
  * returns a negative number if that kernel has not run.  Used by bench.py for the roofline line. */
 int kzg355_settings_device(const kzg355_settings *s);
+/* Number of devices the handle spans (1 for a plain handle). */
+int kzg355_settings_device_count(const kzg355_settings *s);
+/* Multi-device handles: how many record exchanges ran as an RCCL all-gather / as peer copies so far.  Returns the exchange the
+ * handle is set up for (1 RCCL, 0 peer copies; -1 for a plain handle). */
+int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, long *peer_exchanges);
 /* FIELD_ELEMENTS_PER_BLOB of the handle (consts.rs:13 is a compile-time 4096; the reference's README also names a minimal preset
  * with 4).  It is fixed by the number of G1 points given to the load function: 4096 -> the mainnet kernels; a power of two in
  * [4, 64] -> the small-domain path (one lane per blob, naive lincomb as utils.rs:369-371 takes below 8 points).  Every `blob`

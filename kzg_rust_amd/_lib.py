@@ -54,6 +54,9 @@ def load():
         "kzg355_kernel_ms_stats": [vp, u8p, C.POINTER(C.c_double), C.POINTER(C.c_long)],
         "kzg355_settings_device": [vp],
         "kzg355_settings_msm_form": [vp],
+        "kzg355_load_trusted_setup_devices": [u8p, sz, u8p, sz, C.POINTER(C.c_int), sz, C.POINTER(vp)],
+        "kzg355_settings_device_count": [vp],
+        "kzg355_settings_exchange_stats": [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)],
         "kzg355_lagrange_setup_from_monomial": [u8p, u8p, sz],
         "kzg355_settings_field_elements_per_blob": [vp],
         "kzg355_set_kernel_timing": [vp, C.c_int],
@@ -82,5 +85,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_compute_blob_kzg_proof_many_device", "kzg355_verify_shard_records_device", "kzg355_verify_records_device",
     "kzg355_settings_device", "kzg355_last_kernel_ms", "kzg355_set_kernel_timing", "kzg355_version",
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
-    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
+    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
 ]

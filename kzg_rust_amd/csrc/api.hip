@@ -8,6 +8,9 @@
 #include <sched.h>
 #include <chrono>
 #include <condition_variable>
+#include <dlfcn.h>
+#include <functional>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -145,8 +148,10 @@ private:
     int pending_ = 0; unsigned long gen_ = 0; bool stop_ = false;
 };
 
+struct MultiDev;
 struct kzg355_settings {
     int device = 0;
+    MultiDev *multi = nullptr;      // handles created over several devices: the replicas and the exchange (owner handle only)
     DeviceTables t{};
     DevBuf roots, eval_tab, wide, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
@@ -599,7 +604,7 @@ extern "C" {
 
 const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montgomery, fixed-base Pippenger, precomputed-line pairing)"; }
 
-int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out) {
+static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, kzg355_settings **out) {
     if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
     // FIELD_ELEMENTS_PER_BLOB is a compile-time constant of the reference (consts.rs:13: 4096; its README's minimal preset: 4); here
     // it is a property of the handle, taken from the number of G1 points: 4096, or a power of two in [4, 64] for the small path
@@ -608,8 +613,10 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
     int dev = 0;
-    if (const char *e = getenv("KZG355_DEVICE")) dev = atoi(e);
+    if (dev_or_minus1 >= 0) dev = dev_or_minus1;
+    else if (const char *e = getenv("KZG355_DEVICE")) dev = atoi(e);
     else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= ndev) return KZG355_NO_DEVICE;
     HIPCHK(hipSetDevice(dev));
     kzg355_settings *s = new kzg355_settings();
     s->device = dev;
@@ -699,6 +706,105 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     return KZG355_OK;
 }
 
+// ---- handles over several devices --------------------------------------------------------------------------------------
+// "handle owns 1..8 devices; multi-GPU calls are collective inside the library, invisible to the caller".  The owner
+// handle keeps one full replica of the settings per device (the tables are per-GPU constants) and the host-buffer entry points
+// spread their work over them:
+//   * many independent units (batches for verify, blobs for commit / proof): contiguous ranges of units per device, no
+//     exchange at all -- every device runs the single-device pipeline on its range from its own host thread;
+//   * fewer batches than devices (the 512-blob batch over 8 GPUs of BASELINE.json): every batch is cut into contiguous blocks
+//     of blobs, one per device: stage 1 per block -> ONE all-gather of the 160-byte records (RCCL ncclAllGather
+//     over xGMI on a persistent communicator set, or peer copies when RCCL is unavailable / the blocks are ragged) -> stage 2
+//     for each batch on one device.
+// RCCL is bound at run time (dlopen of the librccl the process already has, or /opt/rocm's), so the library carries no link
+// dependency on it and single-device users never load it.
+typedef void *ncclComm_p;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_p *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_p) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_p, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool load() {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+    }
+};
+struct MultiDev {
+    std::vector<kzg355_settings *> rep;        // rep[0] is the owner handle itself
+    RcclApi rccl;
+    std::vector<ncclComm_p> comms;             // one per replica when the RCCL exchange is usable (distinct devices)
+    int exchange = 0;                          // 0 peer copies, 1 RCCL all-gather (KZG355_EXCHANGE=peer|rccl; default rccl when available)
+    long n_allgathers = 0, n_peer_exchanges = 0;   // introspection for tests
+};
+
+static void free_single(kzg355_settings *s);
+
+int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
+                                      kzg355_settings **out) {
+    if (!out || !devices || n_devices == 0 || n_devices > 64) return KZG355_BADARGS;
+    std::vector<kzg355_settings *> rep;
+    auto fail = [&](int code) { for (auto *r : rep) free_single(r); return code; };
+    for (size_t i = 0; i < n_devices; i++) {
+        kzg355_settings *r = nullptr;
+        int rc = load_on_device(g1_bytes, n1, g2_bytes, n2, devices[i], &r);
+        if (rc) return fail(rc);
+        rep.push_back(r);
+    }
+    if (n_devices == 1 && !getenv("KZG355_FORCE_MULTI")) { *out = rep[0]; return KZG355_OK; }     // (test hook: a one-device "multi" handle)
+    MultiDev *m = new MultiDev();
+    m->rep = rep;
+    bool distinct = true;
+    for (size_t i = 0; i < n_devices; i++) for (size_t j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
+    for (size_t i = 0; i < n_devices; i++)                       // peer access speeds up the record copies; not required
+        for (size_t j = 0; j < n_devices; j++)
+            if (devices[i] != devices[j] && hipSetDevice(devices[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
+    const char *ex = getenv("KZG355_EXCHANGE");
+    const bool want_rccl = !(ex && strcmp(ex, "peer") == 0);
+    if (want_rccl && distinct && m->rccl.load()) {
+        m->comms.assign(n_devices, nullptr);
+        if (m->rccl.CommInitAll(m->comms.data(), (int)n_devices, devices) == 0) m->exchange = 1;
+        else m->comms.clear();
+    }
+    if (ex && strcmp(ex, "rccl") == 0 && m->exchange != 1) { delete m; return fail(KZG355_NO_DEVICE); }
+    rep[0]->multi = m;
+    *out = rep[0];
+    return KZG355_OK;
+}
+
+int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out) {
+    // KZG355_DEVICES=0,1,...: the handle spans those devices; otherwise KZG355_DEVICE / the current device
+    if (const char *e = getenv("KZG355_DEVICES")) {
+        std::vector<int> devs;
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            devs.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (!devs.empty()) return kzg355_load_trusted_setup_devices(g1_bytes, n1, g2_bytes, n2, devs.data(), devs.size(), out);
+    }
+    return load_on_device(g1_bytes, n1, g2_bytes, n2, -1, out);
+}
+int kzg355_settings_device_count(const kzg355_settings *s) { return !s ? 0 : s->multi ? (int)s->multi->rep.size() : 1; }
+int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, long *peer_exchanges) {
+    if (!s || !allgathers || !peer_exchanges) return KZG355_BADARGS;
+    *allgathers = s->multi ? s->multi->n_allgathers : 0;
+    *peer_exchanges = s->multi ? s->multi->n_peer_exchanges : 0;
+    return s->multi ? s->multi->exchange : -1;
+}
+
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out) {
     if (!path || !out) return KZG355_BADARGS;
     FILE *f = fopen(path, "r");
@@ -758,7 +864,7 @@ int kzg355_lagrange_setup_from_monomial(uint8_t *out, const uint8_t *monomial_g1
     return done(KZG355_OK);
 }
 
-void kzg355_free_trusted_setup(kzg355_settings *s) {
+static void free_single(kzg355_settings *s) {
     if (!s) return;
     hipSetDevice(s->device);
     for (Workspace *w : s->pool) delete w;
@@ -767,6 +873,16 @@ void kzg355_free_trusted_setup(kzg355_settings *s) {
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
+}
+void kzg355_free_trusted_setup(kzg355_settings *s) {
+    if (!s) return;
+    if (MultiDev *m = s->multi) {
+        s->multi = nullptr;
+        for (size_t i = 0; i < m->comms.size(); i++) if (m->comms[i]) m->rccl.CommDestroy(m->comms[i]);
+        for (size_t i = 1; i < m->rep.size(); i++) free_single(m->rep[i]);
+        delete m;
+    }
+    free_single(s);
 }
 
 int kzg355_settings_device(const kzg355_settings *s) { return s ? s->device : -1; }
@@ -900,6 +1016,177 @@ int kzg355_debug_batch_intermediates(uint8_t *out, bool *ok, int *status, const 
     return verify_records_impl(ok, status, out, d_records, n, groups, 1, cs);
 }
 
+// ---- multi-device execution of the host-buffer entry points ------------------------------------------------------------
+namespace {
+
+int single_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+                       const kzg355_settings *cs) {
+    HostCall hc{0, blobs, commitments, proofs, npg, ok, nullptr, status};
+    return host_pipeline(hc, groups, cs);
+}
+
+// contiguous ranges of `units` over D devices; the work of device d is fn(d, first unit, count) on its own host thread
+int fan_out(size_t D, size_t units, const std::function<int(size_t, size_t, size_t)> &fn) {
+    std::vector<std::future<int>> fut;
+    for (size_t d = 0; d < D; d++) {
+        const size_t lo = units * d / D, hi = units * (d + 1) / D;
+        if (hi > lo) fut.push_back(std::async(std::launch::async, fn, d, lo, hi - lo));
+    }
+    int first = KZG355_OK;
+    for (auto &f : fut) { const int rc = f.get(); if (rc != KZG355_OK && first == KZG355_OK) first = rc; }
+    return first;
+}
+
+// Fewer batches than devices: every batch is sharded over the devices in contiguous blocks of blobs.
+int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+                         const kzg355_settings *cs) {
+    MultiDev *m = cs->multi;
+    const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
+    std::vector<size_t> cnt(D), off(D);
+    for (size_t d = 0; d < D; d++) { off[d] = npg * d / D; cnt[d] = npg * (d + 1) / D - off[d]; }
+    std::vector<WsGuard *> gs(D, nullptr);
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{gs};
+    std::vector<std::vector<int>> st1(D, std::vector<int>(groups, KZG355_OK));
+    // stage 1: device d takes blobs [off_d, off_d + cnt_d) of every batch (records in transcript order within the block)
+    {
+        std::vector<std::future<int>> fut;
+        for (size_t d = 0; d < D; d++) {
+            gs[d] = new WsGuard(m->rep[d]);
+            if (!gs[d]->w) return KZG355_NO_DEVICE;
+            fut.push_back(std::async(std::launch::async, [&, d]() -> int {
+                kzg355_settings *rs = gs[d]->s; Workspace *w = gs[d]->w;
+                if (hipSetDevice(rs->device) != hipSuccess) return KZG355_NO_DEVICE;
+                const size_t n_loc = cnt[d], n_tot = n_loc * groups;
+                int rc;
+                if ((rc = w->records.ensure((size_t)RECORD_BYTES * (n_tot ? n_tot : 1)))) return rc;
+                if (n_loc == 0) return KZG355_OK;
+                if ((rc = w->blobs.ensure(BB * n_tot)) || (rc = w->commitments.ensure(48 * n_tot)) || (rc = w->proofs.ensure(48 * n_tot))) return rc;
+                if ((rc = w->err.ensure(sizeof(int) * groups)) || (rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
+                for (size_t g = 0; g < groups; g++) {
+                    const size_t src = g * npg + off[d], dst = g * n_loc;
+                    HIPCHK(hipMemcpyAsync(w->blobs.as<uint8_t>() + BB * dst, blobs + BB * src, BB * n_loc, hipMemcpyHostToDevice, w->stream));
+                    HIPCHK(hipMemcpyAsync(w->commitments.as<uint8_t>() + 48 * dst, commitments + 48 * src, 48 * n_loc, hipMemcpyHostToDevice, w->stream));
+                    HIPCHK(hipMemcpyAsync(w->proofs.as<uint8_t>() + 48 * dst, proofs + 48 * src, 48 * n_loc, hipMemcpyHostToDevice, w->stream));
+                }
+                w->in_flight = true;
+                HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
+                Timed tm(rs, w);
+                if ((rc = run_stage1(rs, w, tm, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)n_tot, (int)n_loc,
+                                     w->records.as<uint8_t>(), nullptr, w->err.as<int>()))) return rc;
+                if ((rc = join_side(w))) return rc;
+                HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
+                HIPCHK(hipStreamSynchronize(w->stream));
+                w->in_flight = false;
+                tm.collect();
+                for (size_t g = 0; g < groups; g++) st1[d][g] = status_from_err(w->h_err.as<int>()[g]);
+                return KZG355_OK;
+            }));
+        }
+        int first = KZG355_OK;
+        for (auto &f : fut) { const int rc = f.get(); if (rc != KZG355_OK && first == KZG355_OK) first = rc; }
+        if (first != KZG355_OK) return first;
+    }
+    // the exchange: ONE all-gather of the records (equal blocks: RCCL over xGMI) or peer copies into the batch's stage-2 device
+    const bool equal_blocks = npg % D == 0;
+    const bool use_rccl = m->exchange == 1 && equal_blocks;
+    const size_t shard_bytes = (size_t)RECORD_BYTES * cnt[0] * groups;
+    if (use_rccl) {
+        for (size_t d = 0; d < D; d++) {
+            if (hipSetDevice(gs[d]->s->device) != hipSuccess) return KZG355_NO_DEVICE;
+            int rc = gs[d]->w->small.ensure(shard_bytes * D);                   // [rank][batch][block] as the collective delivers it
+            if (rc) return rc;
+        }
+        m->rccl.GroupStart();
+        for (size_t d = 0; d < D; d++) {
+            hipSetDevice(gs[d]->s->device);
+            m->rccl.AllGather(gs[d]->w->records.p, gs[d]->w->small.p, shard_bytes, /* ncclUint8 */ 1, m->comms[d], gs[d]->w->stream);
+        }
+        if (m->rccl.GroupEnd() != 0) return KZG355_NO_DEVICE;
+        m->n_allgathers++;
+    } else m->n_peer_exchanges++;
+    // stage 2: batch g on device g mod D, over the records of all blocks in transcript order
+    std::vector<int> rc_dev(D, KZG355_OK);
+    {
+        std::vector<std::future<int>> fut;
+        for (size_t t = 0; t < D && t < groups; t++) {
+            fut.push_back(std::async(std::launch::async, [&, t]() -> int {
+                kzg355_settings *rs = gs[t]->s; Workspace *w = gs[t]->w;
+                if (hipSetDevice(rs->device) != hipSuccess) return KZG355_NO_DEVICE;
+                std::vector<size_t> mine;
+                for (size_t g = t; g < groups; g += D) mine.push_back(g);
+                const size_t G = mine.size();
+                int rc;
+                DevBuf &gath = w->q;                                               // the gathered records of this device's batches
+                if ((rc = gath.ensure((size_t)RECORD_BYTES * npg * G))) return rc;
+                for (size_t k = 0; k < G; k++) {
+                    const size_t g = mine[k];
+                    for (size_t d = 0; d < D; d++) {
+                        if (!cnt[d]) continue;
+                        uint8_t *dst = gath.as<uint8_t>() + (size_t)RECORD_BYTES * (k * npg + off[d]);
+                        const size_t bytes = (size_t)RECORD_BYTES * cnt[d];
+                        if (use_rccl) {           // local permute out of the all-gathered [rank][batch][block] layout
+                            const uint8_t *src = w->small.as<uint8_t>() + shard_bytes * d + (size_t)RECORD_BYTES * cnt[d] * g;
+                            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, w->stream));
+                        } else {
+                            const uint8_t *src = gs[d]->w->records.as<uint8_t>() + (size_t)RECORD_BYTES * cnt[d] * g;
+                            if (gs[d]->s->device == rs->device) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, w->stream));
+                            else HIPCHK(hipMemcpyPeerAsync(dst, rs->device, src, gs[d]->s->device, bytes, w->stream));
+                        }
+                    }
+                }
+                if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * npg * G))) return rc;
+                if ((rc = w->err.ensure(sizeof(int) * G)) || (rc = w->ok.ensure(sizeof(int) * G))) return rc;
+                if ((rc = w->h_ok.ensure(sizeof(int) * G)) || (rc = w->h_err.ensure(sizeof(int) * G))) return rc;
+                w->in_flight = true;
+                HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * G, w->stream));
+                Timed tm(rs, w);
+                tm.begin("points_from_records"); launch_points_from_records(gath.as<uint8_t>(), (int)(npg * G), (int)npg, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
+                if ((rc = run_stage2(rs, w, tm, gath.as<uint8_t>(), (int)npg, (int)G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+                HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
+                HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
+                HIPCHK(hipStreamSynchronize(w->stream));
+                w->in_flight = false;
+                tm.collect();
+                for (size_t k = 0; k < G; k++) {
+                    const size_t g = mine[k];
+                    int st = status_from_err(w->h_err.as<int>()[k]);
+                    for (size_t d = 0; d < D; d++) if (st == KZG355_OK) st = st1[d][g];    // an Err on any block is an Err of the batch (the `?`s of kzg.rs:673-682)
+                    if (status) status[g] = st;
+                    if (st == KZG355_OK) ok[g] = w->h_ok.as<int>()[k] != 0;
+                    else if (rc_dev[t] == KZG355_OK) rc_dev[t] = st;
+                }
+                return KZG355_OK;
+            }));
+        }
+        int first = KZG355_OK;
+        for (auto &f : fut) { const int rc = f.get(); if (rc != KZG355_OK && first == KZG355_OK) first = rc; }
+        if (first != KZG355_OK) return first;
+    }
+    for (size_t g = 0; g < groups; g++) {            // first failing batch in batch order
+        int st = KZG355_OK;
+        if (status) st = status[g];
+        else for (size_t t = 0; t < D; t++) if (rc_dev[t] != KZG355_OK) st = rc_dev[t];
+        if (st != KZG355_OK) return st;
+    }
+    return KZG355_OK;
+}
+
+int multi_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+                      const kzg355_settings *cs) {
+    MultiDev *m = cs->multi;
+    const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
+    const bool force_sharded = getenv("KZG355_FORCE_SHARDED") != nullptr && npg >= D;         // (test hook)
+    if (!force_sharded && (groups >= D || npg < 2 * D)) {               // enough independent batches (or batches too small to cut): ranges of batches, no exchange
+        return fan_out(D, groups, [&](size_t d, size_t g0, size_t n) -> int {
+            if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
+            return single_verify_many(ok + g0, status ? status + g0 : nullptr, blobs + BB * npg * g0, commitments + 48 * npg * g0, proofs + 48 * npg * g0, npg, n, m->rep[d]);
+        });
+    }
+    return multi_verify_sharded(ok, status, blobs, commitments, proofs, npg, groups, cs);
+}
+
+}  // namespace
+
 // ---- host-buffer entry points (the drop-in surface) ------------------------------------------------------
 int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
                                             size_t n_per_group, size_t groups, const kzg355_settings *cs) {
@@ -908,8 +1195,8 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t
     if (n == 0) return verify_many_device_impl(ok, status, nullptr, nullptr, nullptr, n_per_group, groups, cs);
     if (!blobs || !commitments || !proofs) return KZG355_BADARGS;
     if (n > (size_t)1 << 24) return KZG355_BADARGS;
-    HostCall hc{0, blobs, commitments, proofs, n_per_group, ok, nullptr, status};
-    return host_pipeline(hc, groups, cs);
+    if (cs->multi) return multi_verify_many(ok, status, blobs, commitments, proofs, n_per_group, groups, cs);
+    return single_verify_many(ok, status, blobs, commitments, proofs, n_per_group, groups, cs);
 }
 
 int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,
@@ -965,6 +1252,15 @@ int kzg355_blob_to_kzg_commitment_many(uint8_t *out, int *status, const uint8_t 
     if (n == 0) return KZG355_OK;
     if (!blobs) return KZG355_BADARGS;
     if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    if (cs->multi && cs->multi->rep.size() > 1 && n >= cs->multi->rep.size()) {      // independent blobs: contiguous ranges per device
+        MultiDev *m = cs->multi;
+        const size_t BB = blob_bytes_of(cs);
+        return fan_out(m->rep.size(), n, [&](size_t d, size_t i0, size_t cnt) -> int {
+            if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
+            HostCall hc{1, blobs + BB * i0, nullptr, nullptr, 1, nullptr, out + 48 * i0, status ? status + i0 : nullptr};
+            return host_pipeline(hc, cnt, m->rep[d]);
+        });
+    }
     HostCall hc{1, blobs, nullptr, nullptr, 1, nullptr, out, status};
     return host_pipeline(hc, n, cs);
 }
@@ -981,6 +1277,15 @@ int kzg355_compute_blob_kzg_proof_many(uint8_t *out, int *status, const uint8_t 
     if (n == 0) return KZG355_OK;
     if (!blobs || !commitments) return KZG355_BADARGS;
     if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    if (cs->multi && cs->multi->rep.size() > 1 && n >= cs->multi->rep.size()) {
+        MultiDev *m = cs->multi;
+        const size_t BB = blob_bytes_of(cs);
+        return fan_out(m->rep.size(), n, [&](size_t d, size_t i0, size_t cnt) -> int {
+            if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
+            HostCall hc{2, blobs + BB * i0, commitments + 48 * i0, nullptr, 1, nullptr, out + 48 * i0, status ? status + i0 : nullptr};
+            return host_pipeline(hc, cnt, m->rep[d]);
+        });
+    }
     HostCall hc{2, blobs, commitments, nullptr, 1, nullptr, out, status};
     return host_pipeline(hc, n, cs);
 }

@@ -154,13 +154,18 @@ class KzgSettings:
         return self._h
 
     @staticmethod
-    def load_trusted_setup(g1_bytes, g2_bytes):
-        """kzg.rs:45-78: lists of 48-byte / 96-byte strings."""
+    def load_trusted_setup(g1_bytes, g2_bytes, devices=None):
+        """kzg.rs:45-78: lists of 48-byte / 96-byte strings.  devices (extension): list of GPU ordinals the handle spans; the
+        host-buffer calls then spread their work over them inside the library."""
         g1_bytes, g2_bytes = list(g1_bytes), list(g2_bytes)
         if any(len(x) != BYTES_PER_G1 for x in g1_bytes) or any(len(x) != BYTES_PER_G2 for x in g2_bytes):
             raise InvalidBytesLength("trusted setup point length")
         h = C.c_void_p()
-        rc = lib().kzg355_load_trusted_setup(b"".join(g1_bytes), len(g1_bytes), b"".join(g2_bytes), len(g2_bytes), C.byref(h))
+        if devices is None:
+            rc = lib().kzg355_load_trusted_setup(b"".join(g1_bytes), len(g1_bytes), b"".join(g2_bytes), len(g2_bytes), C.byref(h))
+        else:
+            devs = (C.c_int * len(devices))(*devices)
+            rc = lib().kzg355_load_trusted_setup_devices(b"".join(g1_bytes), len(g1_bytes), b"".join(g2_bytes), len(g2_bytes), devs, len(devices), C.byref(h))
         _check(rc, "load_trusted_setup")
         return KzgSettings(h)
 
@@ -174,6 +179,16 @@ class KzgSettings:
     @property
     def device(self):
         return lib().kzg355_settings_device(self.handle)
+
+    @property
+    def device_count(self):
+        return lib().kzg355_settings_device_count(self.handle)
+
+    def exchange_stats(self):
+        """(exchange kind: 1 RCCL all-gather, 0 peer copies, -1 plain handle; all-gathers so far; peer exchanges so far)."""
+        a, p = C.c_long(), C.c_long()
+        kind = lib().kzg355_settings_exchange_stats(self.handle, C.byref(a), C.byref(p))
+        return kind, a.value, p.value
 
     @property
     def field_elements_per_blob(self):
@@ -225,8 +240,8 @@ class Kzg:
         return KzgSettings.load_trusted_setup_file(path)
 
     @staticmethod
-    def load_trusted_setup(g1_bytes, g2_bytes):  # kzg.rs:1005
-        return KzgSettings.load_trusted_setup(g1_bytes, g2_bytes)
+    def load_trusted_setup(g1_bytes, g2_bytes, devices=None):  # kzg.rs:1005
+        return KzgSettings.load_trusted_setup(g1_bytes, g2_bytes, devices)
 
     @staticmethod
     def blob_to_kzg_commitment(blob, s):  # kzg.rs:1013

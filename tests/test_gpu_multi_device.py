@@ -1,0 +1,117 @@
+"""-m gpu: handles that span several devices (include/kzg355.h: kzg355_load_trusted_setup_devices).  A GPU box
+has ONE card, so the orchestration is exercised with two replicas on the same device (block partition, ragged blocks, status
+merging, peer-copy exchange, fan-out of independent units) and the RCCL all-gather with a one-device communicator; the driver's
+multi-GPU run covers real xGMI traffic through bench.py --gpus N."""
+import ctypes as C
+import os
+
+import pytest
+
+from synth import random_blob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kz():
+    import kzg_rust_amd
+    return kzg_rust_amd
+
+
+def _load(kz, setup_bytes, devices, **env):
+    g1, g2 = setup_bytes
+    env = dict(env, KZG355_MSM="bucket")              # no 24 GB table per replica
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], devices=devices)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def data(kz, setup_bytes):
+    s = _load(kz, setup_bytes, None)
+    blobs = [random_blob(5200 + i) for i in range(24)]
+    B = [kz.Blob(b) for b in blobs]
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, s)
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, s)
+    yield s, B, cs, ps
+    s.free()
+
+
+def test_two_replicas_shard_one_batch(kz, setup_bytes, data):
+    s1, B, cs, ps = data
+    s = _load(kz, setup_bytes, [0, 0], KZG355_EXCHANGE="peer")
+    try:
+        assert s.device_count == 2 and s.exchange_stats()[0] == 0
+        for n in (8, 7, 5, 24):                       # 7, 5: ragged blocks (3 + 4, 2 + 3)
+            before = s.exchange_stats()[2]
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], ps[:n], s) is True
+            assert s.exchange_stats()[2] == before + 1, "the sharded path (one exchange per call) was not taken"
+            sw = list(ps[:n]); sw[0], sw[n - 1] = sw[n - 1], sw[0]          # across the two blocks
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], cs[:n], sw, s) is False
+        # an Err in either block is an Err of the call: invalid commitment in the second block, non-canonical blob in the first
+        bad_c = list(cs[:8]); bad_c[6] = kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch(B[:8], bad_c, ps[:8], s)
+        bb = bytearray(B[1].to_bytes()); bb[64:96] = b"\xff" * 32
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch([B[0], kz.Blob(bytes(bb))] + B[2:8], cs[:8], ps[:8], s)
+        # small calls fall back to one device; n = 0 and length mismatch as ever
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:1], cs[:1], ps[:1], s) is True
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:3], cs[:3], ps[:3], s) is True
+        assert kz.Kzg.verify_blob_kzg_proof_batch([], [], [], s) is True
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch(B[:4], cs[:3], ps[:4], s)
+    finally:
+        s.free()
+
+
+def test_two_replicas_fan_out_independent_units(kz, setup_bytes, data):
+    s1, B, cs, ps = data
+    s = _load(kz, setup_bytes, [0, 0])
+    try:
+        groups = [(B[6 * g:6 * g + 6], cs[6 * g:6 * g + 6], ps[6 * g:6 * g + 6]) for g in range(4)]
+        groups[2] = (groups[2][0], groups[2][1], list(reversed(groups[2][2])))
+        bad_c = list(groups[3][1]); bad_c[0] = kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)
+        groups.append((groups[3][0], bad_c, groups[3][2]))
+        res = kz.Kzg.verify_blob_kzg_proof_batch_many(groups, s)
+        assert res[0] is True and res[1] is True and res[2] is False and res[3] is True and isinstance(res[4], kz.BadArgs)
+        assert s.exchange_stats()[1:] == (0, 0)        # ranges of batches: no exchange
+        got_c = kz.Kzg.blob_to_kzg_commitment_many(B[:9], s)
+        assert [c.to_bytes() for c in got_c] == [c.to_bytes() for c in cs[:9]]
+        got_p = kz.Kzg.compute_blob_kzg_proof_many(B[:9], cs[:9], s)
+        assert [p.to_bytes() for p in got_p] == [p.to_bytes() for p in ps[:9]]
+        bb = bytearray(B[7].to_bytes()); bb[0:32] = b"\xff" * 32
+        res = kz.Kzg.blob_to_kzg_commitment_many(B[:7] + [kz.Blob(bytes(bb))] + B[8:9], s)
+        assert isinstance(res[7], kz.BadArgs) and res[8].to_bytes() == cs[8].to_bytes() and res[0].to_bytes() == cs[0].to_bytes()
+    finally:
+        s.free()
+
+
+def test_rccl_all_gather_on_a_one_device_communicator(kz, setup_bytes, data):
+    """The RCCL leg of the exchange: librccl bound at run time, ncclCommInitAll / ncclAllGather inside the handle.  With one
+    device the collective is a local copy, but every call of the production path is made."""
+    s1, B, cs, ps = data
+    try:
+        s = _load(kz, setup_bytes, [0], KZG355_FORCE_MULTI="1", KZG355_EXCHANGE="rccl")
+    except kz.NoDevice:
+        pytest.skip("librccl could not be loaded / initialised on this box")
+    os.environ["KZG355_FORCE_SHARDED"] = "1"
+    try:
+        kind, ag0, _ = s.exchange_stats()
+        assert kind == 1 and s.device_count == 1
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:8], cs[:8], ps[:8], s) is True
+        sw = list(ps[:8]); sw[2], sw[5] = sw[5], sw[2]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:8], cs[:8], sw, s) is False
+        assert s.exchange_stats()[1] == ag0 + 2
+        groups = [(B[4 * g:4 * g + 4], cs[4 * g:4 * g + 4], ps[4 * g:4 * g + 4]) for g in range(3)]
+        assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, s) == [True, True, True]
+    finally:
+        del os.environ["KZG355_FORCE_SHARDED"]
+        s.free()
