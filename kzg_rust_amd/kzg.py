@@ -4,7 +4,7 @@ parity tests read like the reference's own (src/lib.rs:30-203).  All arithmetic 
 this module only checks lengths / hex (as the Rust newtypes do before any FFI) and forwards.
 
 The reference's host language is Rust; no Rust toolchain exists in this image, so the shim a maintainer
-would compile is shown in INTEGRATION.md and rust/ -- this Python mirror is what the test-suite drives.
+would compile is in rust/ (source only, see rust/README.md) -- this Python mirror is what the test-suite drives.
 """
 import ctypes as C
 import os

@@ -1,0 +1,260 @@
+//! The public surface of the reference crate (src/kzg.rs:10-22, 28-79, 101-204, 983-1079) with every body forwarded through
+//! `ffi` to libkzg355.so.  The byte newtypes raise their length / hex errors on this side, before any FFI call, exactly as the
+//! reference's do; the engine decides everything else (Ok vs Err, the returned bytes, the verdicts).
+use crate::consts::*;
+use crate::ffi;
+use std::ffi::CString;
+use std::ops::Deref;
+use std::path::Path;
+
+#[derive(Debug)]
+pub enum Error {
+    /// The supplied data is invalid in some way.
+    BadArgs(String),
+    /// Internal error - this should never occur (also: no usable HIP device, allocation failure; there is no CPU fallback).
+    InternalError,
+    /// The provided bytes are of incorrect length.
+    InvalidBytesLength(String),
+    /// Error when converting from hex to bytes.
+    InvalidHexFormat(String),
+    /// The provided trusted setup params are invalid.
+    InvalidTrustedSetup(String),
+}
+
+fn check(rc: i32, what: &str) -> Result<(), Error> {
+    match rc {
+        ffi::KZG355_OK => Ok(()),
+        ffi::KZG355_BADARGS => Err(Error::BadArgs(what.into())),
+        ffi::KZG355_INVALID_BYTES_LENGTH => Err(Error::InvalidBytesLength(what.into())),
+        ffi::KZG355_INVALID_HEX => Err(Error::InvalidHexFormat(what.into())),
+        ffi::KZG355_INVALID_TRUSTED_SETUP => Err(Error::InvalidTrustedSetup(what.into())),
+        _ => Err(Error::InternalError), // INTERNAL, NO_DEVICE, NO_MEMORY
+    }
+}
+
+/// Opaque handle to the device-resident trusted setup; replaces the `Vec`s of the reference's `KzgSettings`.
+#[derive(Debug)]
+pub struct KzgSettings {
+    raw: *mut ffi::kzg355_settings,
+}
+// The handle is immutable after creation and the engine takes a private workspace + stream per call.
+unsafe impl Send for KzgSettings {}
+unsafe impl Sync for KzgSettings {}
+
+impl Drop for KzgSettings {
+    fn drop(&mut self) {
+        unsafe { ffi::kzg355_free_trusted_setup(self.raw) }
+    }
+}
+
+impl KzgSettings {
+    pub fn load_trusted_setup(g1_bytes: Vec<[u8; BYTES_PER_G1]>, g2_bytes: Vec<[u8; BYTES_PER_G2]>) -> Result<Self, Error> {
+        let g1: Vec<u8> = g1_bytes.iter().flatten().copied().collect();
+        let g2: Vec<u8> = g2_bytes.iter().flatten().copied().collect();
+        let mut raw = std::ptr::null_mut();
+        check(
+            unsafe { ffi::kzg355_load_trusted_setup(g1.as_ptr(), g1_bytes.len(), g2.as_ptr(), g2_bytes.len(), &mut raw) },
+            "load_trusted_setup",
+        )?;
+        Ok(Self { raw })
+    }
+
+    /// Extension: the handle spans several GPUs of the node; calls spread their work inside the library.
+    pub fn load_trusted_setup_on_devices(g1_bytes: Vec<[u8; BYTES_PER_G1]>, g2_bytes: Vec<[u8; BYTES_PER_G2]>, devices: &[i32]) -> Result<Self, Error> {
+        let g1: Vec<u8> = g1_bytes.iter().flatten().copied().collect();
+        let g2: Vec<u8> = g2_bytes.iter().flatten().copied().collect();
+        let mut raw = std::ptr::null_mut();
+        check(
+            unsafe {
+                ffi::kzg355_load_trusted_setup_devices(g1.as_ptr(), g1_bytes.len(), g2.as_ptr(), g2_bytes.len(), devices.as_ptr(), devices.len(), &mut raw)
+            },
+            "load_trusted_setup_on_devices",
+        )?;
+        Ok(Self { raw })
+    }
+
+    pub fn load_trusted_setup_file<P: AsRef<Path>>(trusted_setup_file: P) -> Result<Self, Error> {
+        let p = trusted_setup_file.as_ref().to_str().ok_or_else(|| Error::InvalidTrustedSetup("path is not UTF-8".into()))?;
+        let c = CString::new(p).map_err(|_| Error::InvalidTrustedSetup("path contains NUL".into()))?;
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::kzg355_load_trusted_setup_file(c.as_ptr(), &mut raw) }, "load_trusted_setup_file")?;
+        Ok(Self { raw })
+    }
+}
+
+pub(crate) fn hex_to_bytes(hex_str: &str) -> Result<Vec<u8>, Error> {
+    let trimmed = hex_str.strip_prefix("0x").unwrap_or(hex_str);
+    hex::decode(trimmed).map_err(|e| Error::InvalidHexFormat(format!("Failed to decode hex: {}", e)))
+}
+
+macro_rules! fixed_bytes {
+    ($name:ident, $n:expr, $len_err:expr) => {
+        #[derive(Debug, Copy, Clone, PartialEq)]
+        pub struct $name {
+            pub(crate) bytes: [u8; $n],
+        }
+        impl $name {
+            pub fn from_bytes(b: &[u8]) -> Result<Self, Error> {
+                if b.len() != $n {
+                    return Err($len_err(format!("Invalid byte length. Expected {} got {}", $n, b.len())));
+                }
+                let mut bytes = [0u8; $n];
+                bytes.copy_from_slice(b);
+                Ok(Self { bytes })
+            }
+            pub fn from_hex(hex_str: &str) -> Result<Self, Error> {
+                Self::from_bytes(&hex_to_bytes(hex_str)?)
+            }
+        }
+        impl Default for $name {
+            fn default() -> Self {
+                Self { bytes: [0u8; $n] }
+            }
+        }
+        impl Deref for $name {
+            type Target = [u8; $n];
+            fn deref(&self) -> &Self::Target {
+                &self.bytes
+            }
+        }
+        impl From<[u8; $n]> for $name {
+            fn from(bytes: [u8; $n]) -> Self {
+                Self { bytes }
+            }
+        }
+    };
+}
+fixed_bytes!(Bytes32, 32, Error::BadArgs); // the reference reports a wrong Bytes32 length as BadArgs (kzg.rs:107-112)
+fixed_bytes!(Bytes48, 48, Error::InvalidBytesLength);
+
+#[derive(Debug, Clone, PartialEq)]
+pub struct Blob {
+    bytes: Box<[u8; BYTES_PER_BLOB]>,
+}
+impl Blob {
+    pub fn from_bytes(bytes: &[u8]) -> Result<Self, Error> {
+        if bytes.len() != BYTES_PER_BLOB {
+            return Err(Error::InvalidBytesLength(format!("Invalid byte length. Expected {} got {}", BYTES_PER_BLOB, bytes.len())));
+        }
+        let mut v = vec![0u8; BYTES_PER_BLOB].into_boxed_slice();
+        v.copy_from_slice(bytes);
+        let bytes: Box<[u8; BYTES_PER_BLOB]> = v.try_into().map_err(|_| Error::InternalError)?;
+        Ok(Self { bytes })
+    }
+    pub fn from_hex(hex_str: &str) -> Result<Self, Error> {
+        Self::from_bytes(&hex_to_bytes(hex_str)?)
+    }
+}
+impl Deref for Blob {
+    type Target = [u8; BYTES_PER_BLOB];
+    fn deref(&self) -> &Self::Target {
+        &self.bytes
+    }
+}
+
+macro_rules! g1_newtype {
+    ($name:ident, $n:expr) => {
+        #[derive(Debug, Copy, Clone, PartialEq)]
+        pub struct $name(pub Bytes48);
+        impl $name {
+            pub fn from_hex(hex_str: &str) -> Result<Self, Error> {
+                Ok(Self(Bytes48::from_bytes(&hex_to_bytes(hex_str)?)?))
+            }
+            pub fn to_bytes(self) -> [u8; $n] {
+                self.0.bytes
+            }
+        }
+        impl From<[u8; $n]> for $name {
+            fn from(b: [u8; $n]) -> Self {
+                Self(Bytes48 { bytes: b })
+            }
+        }
+        impl Deref for $name {
+            type Target = [u8; $n];
+            fn deref(&self) -> &Self::Target {
+                &self.0.bytes
+            }
+        }
+    };
+}
+g1_newtype!(KzgCommitment, BYTES_PER_COMMITMENT);
+g1_newtype!(KzgProof, BYTES_PER_PROOF);
+
+pub struct Kzg;
+
+impl Kzg {
+    pub fn load_trusted_setup_file<P: AsRef<Path>>(trusted_setup_file: P) -> Result<KzgSettings, Error> {
+        KzgSettings::load_trusted_setup_file(trusted_setup_file)
+    }
+
+    pub fn load_trusted_setup(g1_bytes: Vec<[u8; BYTES_PER_G1]>, g2_bytes: Vec<[u8; BYTES_PER_G2]>) -> Result<KzgSettings, Error> {
+        KzgSettings::load_trusted_setup(g1_bytes, g2_bytes)
+    }
+
+    pub fn blob_to_kzg_commitment(blob: &Blob, s: &KzgSettings) -> Result<KzgCommitment, Error> {
+        let mut out = [0u8; BYTES_PER_COMMITMENT];
+        check(unsafe { ffi::kzg355_blob_to_kzg_commitment(out.as_mut_ptr(), blob.as_ptr(), s.raw) }, "blob_to_kzg_commitment")?;
+        Ok(out.into())
+    }
+
+    pub fn compute_kzg_proof(blob: &Blob, z_bytes: &Bytes32, s: &KzgSettings) -> Result<(KzgProof, Bytes32), Error> {
+        let (mut proof, mut y) = ([0u8; BYTES_PER_PROOF], [0u8; 32]);
+        check(
+            unsafe { ffi::kzg355_compute_kzg_proof(proof.as_mut_ptr(), y.as_mut_ptr(), blob.as_ptr(), z_bytes.as_ptr(), s.raw) },
+            "compute_kzg_proof",
+        )?;
+        Ok((proof.into(), y.into()))
+    }
+
+    pub fn compute_blob_kzg_proof(blob: &Blob, commitment_bytes: &KzgCommitment, s: &KzgSettings) -> Result<KzgProof, Error> {
+        let mut proof = [0u8; BYTES_PER_PROOF];
+        check(
+            unsafe { ffi::kzg355_compute_blob_kzg_proof(proof.as_mut_ptr(), blob.as_ptr(), commitment_bytes.as_ptr(), s.raw) },
+            "compute_blob_kzg_proof",
+        )?;
+        Ok(proof.into())
+    }
+
+    pub fn verify_kzg_proof(
+        commitment_bytes: &KzgCommitment,
+        z_bytes: &Bytes32,
+        y_bytes: &Bytes32,
+        proof_bytes: &KzgProof,
+        s: &KzgSettings,
+    ) -> Result<bool, Error> {
+        let mut ok = false;
+        check(
+            unsafe { ffi::kzg355_verify_kzg_proof(&mut ok, commitment_bytes.as_ptr(), z_bytes.as_ptr(), y_bytes.as_ptr(), proof_bytes.as_ptr(), s.raw) },
+            "verify_kzg_proof",
+        )?;
+        Ok(ok)
+    }
+
+    pub fn verify_blob_kzg_proof(blob: &Blob, commitment_bytes: &KzgCommitment, proof_bytes: &KzgProof, s: &KzgSettings) -> Result<bool, Error> {
+        let mut ok = false;
+        check(
+            unsafe { ffi::kzg355_verify_blob_kzg_proof(&mut ok, blob.as_ptr(), commitment_bytes.as_ptr(), proof_bytes.as_ptr(), s.raw) },
+            "verify_blob_kzg_proof",
+        )?;
+        Ok(ok)
+    }
+
+    pub fn verify_blob_kzg_proof_batch(blobs: &[Blob], commitment_bytes: &[KzgCommitment], proof_bytes: &[KzgProof], s: &KzgSettings) -> Result<bool, Error> {
+        // `&[Blob]` is a slice of boxes: the blobs are not contiguous in memory, the ABI wants one buffer
+        let mut staged = Vec::with_capacity(blobs.len() * BYTES_PER_BLOB);
+        for b in blobs {
+            staged.extend_from_slice(&b[..]);
+        }
+        let c: Vec<u8> = commitment_bytes.iter().flat_map(|x| x.to_bytes()).collect();
+        let p: Vec<u8> = proof_bytes.iter().flat_map(|x| x.to_bytes()).collect();
+        let mut ok = false;
+        // all three lengths cross the boundary: the mismatch check of the reference (kzg.rs:644-651) is the library's
+        check(
+            unsafe {
+                ffi::kzg355_verify_blob_kzg_proof_batch(&mut ok, staged.as_ptr(), blobs.len(), c.as_ptr(), commitment_bytes.len(), p.as_ptr(), proof_bytes.len(), s.raw)
+            },
+            "verify_blob_kzg_proof_batch",
+        )?;
+        Ok(ok)
+    }
+}

@@ -84,8 +84,22 @@ def _worker(rank, world, port, blobs, cs, ps, q):
     tb = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[0])), dtype=torch.uint8)
     tc = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[1])), dtype=torch.uint8)
     tp = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[2])), dtype=torch.uint8)
-    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, OracleEngine())
-    q.put((rank, ok, st))
+    eng = OracleEngine()
+    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng)
+    # ONE batch over two ranks: rank 0's share of the batches is EMPTY (groups * 0 // 2 == groups * 1 // 2), rank 1 runs stage 2
+    # alone, and the all-reduce still has to hand rank 0 the verdict -- honest first, then with rank 0's proofs swapped, then with
+    # an invalid proof on rank 0 (Err raised by a rank that verifies nothing itself)
+    one = lambda t, per: t[:n_local * per].clone()
+    ok1, st1 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), one(tp, 48), n_local, 1, eng)
+    sw = one(tp, 48)
+    if rank == 0:
+        tmp = sw[:48].clone(); sw[:48] = sw[48:96]; sw[48:96] = tmp
+    ok2, st2 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), sw, n_local, 1, eng)
+    bad = one(tp, 48)
+    if rank == 0:
+        bad[:48] = torch.frombuffer(bytearray(bytes([0x9A]) + b"\xff" * 47), dtype=torch.uint8)
+    ok3, st3 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), bad, n_local, 1, eng)
+    q.put((rank, ok, st, (ok1, st1, ok2, st2, ok3, st3)))
     dist.destroy_process_group()
 
 
@@ -103,9 +117,13 @@ def test_sharded_verify_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, st in res:                                  # identical verdicts on every rank
+    for rank, ok, st, single in res:                          # identical verdicts on every rank
         assert ok == [True, False, False], (rank, ok)
         assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, st)
+        ok1, st1, ok2, st2, ok3, st3 = single
+        assert (ok1, st1) == ([True], [0]), (rank, ok1, st1)
+        assert (ok2, st2) == ([False], [0]), (rank, ok2, st2)
+        assert ok3 == [False] and st3[0] != 0, (rank, ok3, st3)
 
 
 def test_partition():
