@@ -604,6 +604,7 @@ extern "C" {
 
 const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montgomery, fixed-base Pippenger, precomputed-line pairing)"; }
 
+static int device_self_test(kzg355_settings *s);
 static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, kzg355_settings **out) {
     if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
     // FIELD_ELEMENTS_PER_BLOB is a compile-time constant of the reference (consts.rs:13: 4096; its README's minimal preset: 4); here
@@ -702,7 +703,69 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
             (void)hipGetLastError();
         }
     }
+    {   // known-answer self-test of the freshly built handle (KZG355_SELFTEST=0 skips it)
+        const char *e = getenv("KZG355_SELFTEST");
+        if (!(e && atoi(e) == 0)) {
+            const int rc = device_self_test(s);
+            if (rc != KZG355_OK) { kzg355_free_trusted_setup(s); return rc; }
+        }
+    }
     *out = s;
+    return KZG355_OK;
+}
+
+// Known-answer self-test run once per handle (~10 ms).  It needs no fixture: for ANY Lagrange-form setup over the domain w_i,
+//   sum_i L_i(tau) = 1        =>  the commitment of the all-ones blob is the G1 generator;
+//   sum_i w_i L_i(tau) = tau  =>  the commitment C of the blob (w_0, .., w_{N-1}) is [tau]G1, the polynomial p(X) = X, and with
+//                                 quotient (X - z)/(X - z) = 1 its proof at any z is the generator:  verify_kzg_proof(C, z, z, G) is
+//                                 true, verify_kzg_proof(C, z, z + 1, G) is false.
+// This runs the MSM (table build, kernel, finalize, compression), point validation, the r-power kernel, the per-term lincomb and
+// the cooperative pairing on the device they will run on, and turns a toolchain that miscompiles one of them (DESIGN.md section 4
+// records such a case with hipcc 7.2 and four inlined G1 routines) into a load error instead of wrong verdicts.
+static int device_self_test(kzg355_settings *s) {
+    static const uint8_t G1_GEN[48] = {0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f, 0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05,
+                                       0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58, 0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
+    const size_t n = (size_t)s->t.n_fe, BB = 32 * n;
+    DevBuf blobs;
+    int rc = blobs.ensure(2 * BB);
+    if (rc) return rc;
+    auto fail = [&](const char *what) {
+        fprintf(stderr, "kzg355: device self-test FAILED (%s): this build of the library does not compute correctly on this device\n", what);
+        blobs.release();
+        return KZG355_INTERNAL;
+    };
+    std::vector<uint8_t> ones(BB, 0);
+    for (size_t i = 0; i < n; i++) ones[32 * i + 31] = 1;
+    if (hipMemcpy(blobs.p, ones.data(), BB, hipMemcpyHostToDevice) != hipSuccess) { blobs.release(); return KZG355_NO_DEVICE; }
+    launch_fr_to_bytes(s->t.roots, (int)n, blobs.as<uint8_t>() + BB, nullptr);            // the blob (w_0, .., w_{N-1}), big-endian canonical
+    if (hipDeviceSynchronize() != hipSuccess) { blobs.release(); return KZG355_NO_DEVICE; }
+    uint8_t c[96]; int st[2] = {0, 0};
+    rc = msm_op_many_device_impl(c, st, blobs.as<uint8_t>(), nullptr, 2, s);
+    if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) { blobs.release(); return rc; }
+    if (rc != KZG355_OK) return fail("commitment kernels report an error on canonical blobs");
+    if (memcmp(c, G1_GEN, 48) != 0) {
+        // Either the arithmetic is wrong or the caller's points are not a Lagrange basis of this domain (the reference loads any
+        // on-curve points that pass its pairing check, kzg.rs:833-899).  Tell the two apart with the other, independent MSM form:
+        // if both forms agree the setup is merely unusual and the identities above do not apply -- nothing more can be checked.
+        if (!s->t.wide_table) { blobs.release(); return KZG355_OK; }
+        WideRow *keep = s->t.wide_table;
+        uint8_t c2[96];
+        s->t.wide_table = nullptr;
+        rc = msm_op_many_device_impl(c2, st, blobs.as<uint8_t>(), nullptr, 2, s);
+        s->t.wide_table = keep;
+        if (rc != KZG355_OK || memcmp(c, c2, 96) != 0) return fail("the wide-table and the bucket form of the MSM disagree");
+        blobs.release();
+        return KZG355_OK;
+    }
+    uint8_t z[32] = {0}, y_bad[32] = {0};
+    z[31] = 5; y_bad[31] = 6;
+    bool ok = false;
+    rc = kzg355_verify_kzg_proof(&ok, c + 48, z, z, G1_GEN, s);
+    if (rc != KZG355_OK || !ok) return fail("verify_kzg_proof([tau]G1, z, z, G1) is not true");
+    ok = true;
+    rc = kzg355_verify_kzg_proof(&ok, c + 48, z, y_bad, G1_GEN, s);
+    if (rc != KZG355_OK || ok) return fail("verify_kzg_proof([tau]G1, z, z + 1, G1) is not false");
+    blobs.release();
     return KZG355_OK;
 }
 
