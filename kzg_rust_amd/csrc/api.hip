@@ -85,8 +85,7 @@ struct Workspace {
         if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_join) hipEventDestroy(ev_join);
-        if (side) hipStreamDestroy(side);
-        if (stream) hipStreamDestroy(stream);
+        if (stream) hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
     }
 };
 
@@ -155,13 +154,15 @@ struct kzg355_settings {
     DeviceTables t{};
     DevBuf roots, eval_tab, wide, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
-    bool split_big_calls = false;   // KZG355_SPLIT=1: verify calls of >= 131,072 blobs run as two overlapped halves
+    int split_parts = 0, split_streams = 2;   // KZG355_SPLIT=parts[,streams] (0: two sets once each has >= 131,072 blobs; 1: never split)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
     std::mutex mu;
+    hipStream_t side_stream = nullptr;   // shared by the workspaces (point validation of small calls next to the hash chain)
     std::vector<Workspace *> pool;
     CopyPool *copy_pool = nullptr;  // created with the handle (KZG355_COPY_THREADS, default min(8, cores / 2) - 1 workers)
-    size_t chunk_bytes = (size_t)512 << 20;   // blobs per chunk of a host-buffer call (KZG355_CHUNK_MB)
+    size_t chunk_bytes = (size_t)1024 << 20;  // blobs per chunk of a host-buffer call (KZG355_CHUNK_MB): 1 GiB = 18 ms of PCIe traffic, more than
+                                              // the ~11 ms kernel chain of a chunk even when the chains of successive chunks end up on one hardware queue
     int chunks_in_flight = 3;                 // workspaces (pinned slot + device buffers + stream) a host-buffer call rotates over
     bool pinned_ring = false;                 // KZG355_STAGING=ring: stage caller memory through the workspaces' pinned slots; default: let the
                                               // runtime lock the caller's pages and DMA from them (measured on MI355X hosts: 56 GB/s, no CPU copy)
@@ -180,8 +181,9 @@ Workspace *ws_acquire(kzg355_settings *s) {
     }
     Workspace *w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
-    // (the side stream is created on first use: HIP multiplexes its streams onto a handful of hardware queues, and every extra
-    // stream makes it likelier that the main streams of two workspaces share one and serialise)
+    // (ONE side stream per handle, created on first use and shared by its workspaces: HIP multiplexes streams onto a handful of
+    // hardware queues -- 4 unless GPU_MAX_HW_QUEUES says otherwise -- and two workspaces whose main streams land on the same queue
+    // run their launch sets one after the other.  Measured: with a side stream per workspace no more than two calls overlapped.)
     if (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { delete w; return nullptr; }
     bool ok = true;
     for (auto &e : w->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -250,7 +252,11 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     // are first needed (join_side()).  With many batches in flight both kernels fill the card on their own and sharing the
     // SIMDs only slows the challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together:
     // one-wave workgroups of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
-    if (n_total <= 16384 && !w->side && hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) { w->side = nullptr; (void)hipGetLastError(); }
+    if (n_total <= 16384 && !w->side) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->side_stream && hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking) != hipSuccess) { s->side_stream = nullptr; (void)hipGetLastError(); }
+        w->side = s->side_stream;
+    }
     if (n_total <= 16384 && w->side) {
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
@@ -300,33 +306,37 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
 }
 
 // Enqueue one launch set on w->stream (no host synchronisation) ...
-int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G) {
+int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
+                   size_t res_off = 0, size_t res_cap = 0) {
+    // res_off / res_cap: several launch sets queued on one workspace (stream order keeps the device scratch safe) park their
+    // verdicts at different offsets of the pinned result buffers, sized res_cap entries up front
     const int n_total = npg * G;
     int rc;
+    if (res_cap < (size_t)G) res_cap = (size_t)G;
     if ((rc = w->records.ensure((size_t)RECORD_BYTES * n_total))) return rc;
     if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * (size_t)n_total))) return rc;
     if ((rc = w->err.ensure(sizeof(int) * (size_t)G))) return rc;
     if ((rc = w->ok.ensure(sizeof(int) * (size_t)G))) return rc;
-    if ((rc = w->h_ok.ensure(sizeof(int) * (size_t)G))) return rc;
-    if ((rc = w->h_err.ensure(sizeof(int) * (size_t)G))) return rc;
+    if ((rc = w->h_ok.ensure(sizeof(int) * res_cap))) return rc;
+    if ((rc = w->h_err.ensure(sizeof(int) * res_cap))) return rc;
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
     if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
     if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
-    HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
-    HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_ok.as<int>() + res_off, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipMemcpyAsync(w->h_err.as<int>() + res_off, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     return KZG355_OK;
 }
 // ... and wait for it: verdicts / statuses of its G batches.  Returns the first non-OK status.
-int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G) {
+int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G, size_t res_off = 0) {
     HIPCHK(hipStreamSynchronize(w->stream));
     w->in_flight = false;
     tm.collect();
     int first = KZG355_OK;
     for (int i = 0; i < G; i++) {
-        int st = status_from_err(w->h_err.as<int>()[i]);
+        int st = status_from_err(w->h_err.as<int>()[res_off + i]);
         if (status) status[i] = st;
-        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
+        if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[res_off + i] != 0;
         else if (first == KZG355_OK) first = st;
     }
     return first;
@@ -341,13 +351,21 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         return KZG355_OK;
     }
     if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
-    // A launch set ends in ~7 ms of narrow kernels (r powers, Horner tail, pairing: one wave or less per batch).  A big call is
-    // cut in two halves on two workspaces / streams so that the narrow tail of one half runs under the wide kernels of the
-    // other (measured: two sets of 2048 batches in flight 3.2 M blobs/s against 2.9 M one after the other).
-    // Opt-in (KZG355_SPLIT=1 when the handle is created): the co-running kernels stretch each other, so per-kernel timings and
-    // roofline fractions read lower although the call finishes ~4 % sooner; the default keeps one kernel on the card at a time.
-    const size_t halves = (cs->split_big_calls && npg * groups >= (size_t)1 << 17 && groups >= 2) ? 2 : 1;
-    if (halves == 1) {
+    // A launch set ends in narrow kernels (r powers, Horner tail: a quarter of the SIMDs or fewer have a wave) and even its wide
+    // kernels leave issue slots unused (SHA-256 runs at 2 waves per SIMD).  A big call is therefore cut into `parts` launch sets
+    // dealt round-robin to `lanes` workspaces / streams: the sets of different streams run concurrently, the narrow kernels of
+    // one under the wide kernels of another (KZG355_SPLIT=parts[,streams]; 1 = one set at a time, the form the per-kernel
+    // timings of the bench's roofline pass are taken in).
+    // Measured (profiles/r02/split_sweep.txt): two sets of >= 2048 64-blob batches each in flight 3.44 M blobs/s against 3.15 M for one
+    // set at a time; smaller sets lose more to their fixed latency than the overlap returns, more than two streams add nothing.
+    // Default: two sets when each gets at least 131,072 blobs.
+    size_t parts = 1, lanes = 1;
+    if (!cs->timing) {
+        if (cs->split_parts > 1 && npg * groups >= (size_t)1 << 16 && groups >= (size_t)cs->split_parts) parts = (size_t)cs->split_parts;
+        else if (cs->split_parts == 0 && npg * groups >= (size_t)1 << 18 && groups >= 2) parts = 2;
+        lanes = (size_t)cs->split_streams < parts ? (size_t)cs->split_streams : parts;
+    }
+    if (parts == 1) {
         WsGuard g(cs);
         if (!g.w) return KZG355_NO_DEVICE;
         Timed tm(g.s, g.w);
@@ -355,17 +373,33 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         if (rc) return rc;
         return verify_collect(g.w, tm, ok, status, (int)groups);
     }
-    const size_t ga = groups / 2, gb = groups - ga;
-    WsGuard a(cs), b(cs);
-    if (!a.w || !b.w) return KZG355_NO_DEVICE;
-    Timed ta(a.s, a.w), tb(b.s, b.w);
-    int rc = verify_enqueue(a.s, a.w, ta, d_blobs, d_c, d_p, (int)npg, (int)ga);
-    if (rc) return rc;
-    rc = verify_enqueue(b.s, b.w, tb, d_blobs + blob_bytes_of(cs) * npg * ga, d_c + 48 * npg * ga, d_p + 48 * npg * ga, (int)npg, (int)gb);
-    if (rc) return rc;                            // (the guards wait for whatever is in flight)
-    const int ra = verify_collect(a.w, ta, ok, status, (int)ga);
-    const int rb = verify_collect(b.w, tb, ok + ga, status ? status + ga : nullptr, (int)gb);
-    return ra != KZG355_OK ? ra : rb;
+    std::vector<WsGuard *> gs;
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{gs};
+    std::vector<Timed> tms;
+    for (size_t l = 0; l < lanes; l++) {
+        gs.push_back(new WsGuard(cs));
+        if (!gs.back()->w) return KZG355_NO_DEVICE;
+        tms.emplace_back(gs.back()->s, gs.back()->w);
+    }
+    const size_t BB = blob_bytes_of(cs);
+    std::vector<size_t> g0(parts + 1, 0), res_off(parts, 0), lane_fill(lanes, 0);
+    for (size_t k = 0; k < parts; k++) g0[k + 1] = g0[k] + groups / parts + (k < groups % parts ? 1 : 0);      // larger parts first: a later set never outgrows the scratch
+    const size_t cap = (groups / parts + 1) * ((parts + lanes - 1) / lanes);
+    for (size_t k = 0; k < parts; k++) {
+        const size_t l = k % lanes, cnt = g0[k + 1] - g0[k];
+        res_off[k] = lane_fill[l]; lane_fill[l] += cnt;
+        int rc = verify_enqueue(gs[l]->s, gs[l]->w, tms[l], d_blobs + BB * npg * g0[k], d_c + 48 * npg * g0[k], d_p + 48 * npg * g0[k], (int)npg, (int)cnt, res_off[k], cap);
+        if (rc) return rc;                        // (the guards wait for whatever is in flight)
+    }
+    int first = KZG355_OK;
+    std::vector<bool> synced(lanes, false);
+    for (size_t k = 0; k < parts; k++) {          // a lane's stream is synchronised once; its sets are then read back in order
+        const size_t l = k % lanes, cnt = g0[k + 1] - g0[k];
+        const int rc = verify_collect(gs[l]->w, tms[l], ok + g0[k], status ? status + g0[k] : nullptr, (int)cnt, res_off[k]);
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return rc;
+        if (rc != KZG355_OK && first == KZG355_OK) first = rc;
+    }
+    return first;
 }
 
 int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes) {
@@ -675,7 +709,12 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         if (const char *e = getenv("KZG355_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->chunks_in_flight = v; }
     }
     if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
-    if (const char *e = getenv("KZG355_SPLIT")) s->split_big_calls = atoi(e) != 0;
+    if (const char *e = getenv("KZG355_SPLIT")) {
+        int a = 1, b = 2;
+        const int got = sscanf(e, "%d,%d", &a, &b);
+        if (got >= 1 && a >= 0 && a <= 64) s->split_parts = a;
+        if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
+    }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
@@ -932,6 +971,7 @@ static void free_single(kzg355_settings *s) {
     hipSetDevice(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
+    if (s->side_stream) { hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
     delete s->copy_pool; s->copy_pool = nullptr;
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();

@@ -33,7 +33,10 @@ def run(G, threads, steps):
     for t in ths: t.join()
     dt = time.perf_counter() - t0
     return threads * steps * G * n / dt
-for G, threads in ((2048, 1), (1024, 2), (2048, 2), (1024, 3), (512, 4)):
+CASES = ((2048, 1), (2048, 2), (2048, 3), (256, 1), (256, 2), (256, 4), (64, 1), (64, 2), (64, 4), (1, 1), (1, 2), (1, 4))
+if len(sys.argv) > 1:
+    CASES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for G, threads in CASES:
     run(G, threads, 1)
     print(f"G={G} x {threads} thread(s) in flight: {run(G, threads, 6) / 1e6:.3f} M blobs/s")
 s.free()
