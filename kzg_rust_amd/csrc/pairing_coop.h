@@ -261,9 +261,9 @@ KZG_HD void coop_combine(Fp &out, const Fp *red, const uint8_t *lanes, const int
     for (int i = 0; i < NFP; i++) acc[i] = (int64_t)K * (int64_t)m[i];
     for (int j = 0; j < n; j++) {
         const Fp &v = red[lanes[j]];
-        const int64_t c = coefs[j];
+        const int32_t c = coefs[j];                               // 32 x 32 -> 64 signed products: one v_mad_i64_i32 per limb
 #pragma unroll
-        for (int i = 0; i < NFP; i++) acc[i] += c * (int64_t)v.l[i];
+        for (int i = 0; i < NFP; i++) acc[i] += (int64_t)c * (int64_t)(int32_t)v.l[i];
     }
     int64_t cy = 0;
 #pragma unroll
