@@ -408,6 +408,10 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
         total_insts += insts
         out["per_kernel"][fam] = {"valu_wave_insts_per_blob": round(insts, 1), "achieved_wave_insts_per_s": rate,
                                   "frac_of_nominal": round(rate / NOMINAL_WAVE_INSTS_PER_S, 4), "wait_inst_any_frac": wait}
+        if ceiling:      # SHA-256 kernels against the measured SHA body rate, field-arithmetic kernels against the Fp-product body rate
+            mix = ceiling.get("sha256_mix_wave_insts_per_s" if fam in ("challenge", "rpowers") else "field_mix_wave_insts_per_s")
+            if mix:
+                out["per_kernel"][fam]["frac_of_measured_ceiling"] = round(rate / mix, 4)
         out["source"] = os.path.relpath(f, ROOT)
     if total_insts:
         out["path_valu_wave_insts_per_blob"] = round(total_insts, 1)

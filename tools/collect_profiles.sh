@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box: kernel-trace stats and the three counter passes (separately, as
+# MI355X_MICROARCH.md prescribes) over the same bench.py command, plus the secondary bench lines.  usage: collect_profiles.sh rNN vK
+set -u
+R=${1:-r02}; V=${2:-v1}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-leg"
+echo "== kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err; echo rc=$?
+echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/fetch.err; echo rc=$?
+echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/write.err; echo rc=$?
+echo "== SQ"; rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $BENCH > /dev/null 2> $OUT/sq.err; echo rc=$?
+cd $ROOT
+python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 262144 $OUT/pmc_traffic_$V.json > /dev/null
+python tools/sq_summary.py $OUT/pmc_sq 262144 $OUT/sq_$V.json > /dev/null
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_default_$V.csv \;
+for op in commit proof; do
+  echo "== $op"
+  cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$op -- python3 $ROOT/bench.py --op $op --steps 6 --warmup 2 > $OUT/bench_${op}_$V.json 2> $OUT/$op.err; echo rc=$?
+  cd $ROOT; find $OUT/trace_$op -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_${op}_$V.csv \;
+done
+rm -rf $OUT/trace $OUT/trace_commit $OUT/trace_proof      # the raw traces are large; the stats CSVs are what is kept
+echo "== default bench (un-profiled)"; python bench.py > $OUT/bench_default_$V.json 2> $OUT/bench_default.err; echo rc=$?
+echo "== sweep"; python bench.py --sweep > $OUT/bench_sweep_$V.json 2> $OUT/sweep.err; echo rc=$?
+ls -la $OUT
