@@ -13,7 +13,7 @@ namespace kzg {
 
 // ------------------------------------------------------------------------------------------------ points
 // thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
-__global__ void __launch_bounds__(256) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+__global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
                                                          G1Affine *pts, int *err, int stride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
