@@ -361,7 +361,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
     // Default: two sets when each gets at least 131,072 blobs.
     size_t parts = 1, lanes = 1;
     if (!cs->timing) {
-        if (cs->split_parts > 1 && npg * groups >= (size_t)1 << 16 && groups >= (size_t)cs->split_parts) parts = (size_t)cs->split_parts;
+        if (cs->split_parts > 1 && groups >= (size_t)cs->split_parts) parts = (size_t)cs->split_parts;      // explicit request: any size
         else if (cs->split_parts == 0 && npg * groups >= (size_t)1 << 18 && groups >= 2) parts = 2;
         lanes = (size_t)cs->split_streams < parts ? (size_t)cs->split_streams : parts;
     }

@@ -758,3 +758,85 @@ def test_invalid_blobs_on_the_bucket_msm_handle(kz, setup_bytes, golden_vectors,
         assert res[1].to_bytes() == kz.Kzg.blob_to_kzg_commitment(kz.Blob(good), sb).to_bytes()
     finally:
         sb.free()
+
+
+def _handle_with_env(kz, setup_bytes, **env):
+    g1, g2 = setup_bytes
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("staging", ["direct", "ring"])
+def test_host_pipeline_chunks_keep_order_and_status(staging, kz, setup_bytes, settings, random_set):
+    """Host-buffer *_many calls cut into many chunks (KZG355_CHUNK_MB=1: one 8-blob batch per chunk, three workspaces in flight), in both
+    staging modes: verdicts and per-unit statuses come back in call order, an Err in a middle chunk neither stops nor reorders the
+    others, and commitments / proofs of a chunked call equal the unchunked ones."""
+    blobs, cs, ps = random_set
+    s = _handle_with_env(kz, setup_bytes, KZG355_CHUNK_MB="1", KZG355_STAGING=staging, KZG355_MSM="bucket")
+    try:
+        B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+        sw = list(Pr); sw[0], sw[1] = sw[1], sw[0]
+        bad_c = list(Cm); bad_c[5] = kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)
+        bb = bytearray(blobs[2]); bb[32 * 100:32 * 101] = b"\xff" * 32
+        bad_b = list(B); bad_b[2] = kz.Blob(bytes(bb))
+        groups, want = [], []
+        for g in range(11):
+            if g == 3:
+                groups.append((B, Cm, sw)); want.append(False)
+            elif g == 6:
+                groups.append((B, bad_c, Pr)); want.append("err")
+            elif g == 9:
+                groups.append((bad_b, Cm, Pr)); want.append("err")
+            else:
+                groups.append((B, Cm, Pr)); want.append(True)
+        res = kz.Kzg.verify_blob_kzg_proof_batch_many(groups, s)
+        assert [("err" if isinstance(r, kz.Error) else r) for r in res] == want
+        many = [kz.Blob(random_blob(8800 + i)) for i in range(21)]               # 21 blobs at 8 per chunk: 3 chunks, the last one short
+        many[13] = kz.Blob(bytes(bb))
+        ref_c = kz.Kzg.blob_to_kzg_commitment_many(many, settings)
+        got_c = kz.Kzg.blob_to_kzg_commitment_many(many, s)
+        assert [isinstance(x, kz.Error) for x in got_c] == [i == 13 for i in range(21)]
+        assert [x.to_bytes() for i, x in enumerate(got_c) if i != 13] == [x.to_bytes() for i, x in enumerate(ref_c) if i != 13]
+        cm_ok = [ref_c[i] if i != 13 else ref_c[0] for i in range(21)]
+        ref_p = kz.Kzg.compute_blob_kzg_proof_many(many, cm_ok, settings)
+        got_p = kz.Kzg.compute_blob_kzg_proof_many(many, cm_ok, s)
+        assert [isinstance(x, kz.Error) for x in got_p] == [i == 13 for i in range(21)]
+        assert [x.to_bytes() for i, x in enumerate(got_p) if i != 13] == [x.to_bytes() for i, x in enumerate(ref_p) if i != 13]
+    finally:
+        s.free()
+
+
+def test_overlapped_launch_sets_keep_order(kz, setup_bytes, random_set):
+    """Device-resident verify calls run as several launch sets on several streams (default: two sets from 262,144 blobs; here
+    KZG355_SPLIT=3,2 on a small call): 13 batches dealt 5 + 4 + 4 over two streams, two sets queued on one workspace -- verdicts and
+    statuses must land at their batch's index."""
+    import torch
+    blobs, cs, ps = random_set
+    n = len(blobs)
+    s = _handle_with_env(kz, setup_bytes, KZG355_SPLIT="3,2", KZG355_MSM="bucket")
+    try:
+        dev = torch.device("cuda", s.device)
+        G = 13
+        P = [list(ps) for _ in range(G)]; Cc = [list(cs) for _ in range(G)]
+        P[4][0], P[4][1] = P[4][1], P[4][0]                                   # false, first set
+        P[7][2], P[7][3] = P[7][3], P[7][2]                                   # false, second set
+        Cc[11][1] = bytes([0x9a]) + b"\xff" * 47                               # Err, third set (second one on its stream)
+        tb = torch.frombuffer(bytearray(b"".join(blobs) * G), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(b"".join(b"".join(c) for c in Cc)), dtype=torch.uint8).to(dev)
+        tp = torch.frombuffer(bytearray(b"".join(b"".join(p) for p in P)), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        ok = (C.c_bool * G)(); st = (C.c_int * G)()
+        rc = kz.kzg.lib().kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, s.handle)
+        assert rc == 1
+        assert [st[g] for g in range(G)] == [1 if g == 11 else 0 for g in range(G)]
+        assert [ok[g] for g in range(G) if g != 11] == [g not in (4, 7) for g in range(G) if g != 11]
+    finally:
+        s.free()
