@@ -154,7 +154,7 @@ struct kzg355_settings {
     DeviceTables t{};
     DevBuf roots, eval_tab, wide, msm_table, lines, lines_inf, g1_first2, lines_w, frob, prog, scheds;
     bool lane_pairing = false;
-    int split_parts = 0, split_streams = 2;   // KZG355_SPLIT=parts[,streams] (0: two sets once each has >= 131,072 blobs; 1: never split)
+    int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
     std::mutex mu;
@@ -351,18 +351,14 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         return KZG355_OK;
     }
     if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
-    // A launch set ends in narrow kernels (r powers, Horner tail: a quarter of the SIMDs or fewer have a wave) and even its wide
-    // kernels leave issue slots unused (SHA-256 runs at 2 waves per SIMD).  A big call is therefore cut into `parts` launch sets
-    // dealt round-robin to `lanes` workspaces / streams: the sets of different streams run concurrently, the narrow kernels of
-    // one under the wide kernels of another (KZG355_SPLIT=parts[,streams]; 1 = one set at a time, the form the per-kernel
-    // timings of the bench's roofline pass are taken in).
-    // Measured (profiles/r02/split_sweep.txt): two sets of >= 2048 64-blob batches each in flight 3.44 M blobs/s against 3.15 M for one
-    // set at a time; smaller sets lose more to their fixed latency than the overlap returns, more than two streams add nothing.
-    // Default: two sets when each gets at least 131,072 blobs.
+    // Optional (KZG355_SPLIT=parts[,streams]): cut the call into `parts` launch sets dealt round-robin to `streams` workspaces, so
+    // that the narrow kernels of one set (r powers, Horner tail) run under the wide kernels of another.  Measured
+    // (profiles/r02/split_sweep.txt): what counts is the SIZE of a launch set -- 2048 batches 3.13 M blobs/s, 4096 3.44 M, 8192
+    // 3.63 M, whether or not the sets overlap (4096 as 2 x 2048 overlapped: 3.44 M; 8192 as 2 x 4096: 3.64 M) -- and splitting a
+    // set only costs (2048 as 2 / 4 / 8 parts: -2 / -20 / -44 %).  So the default is one set per call, as large as the caller makes it.
     size_t parts = 1, lanes = 1;
-    if (!cs->timing) {
-        if (cs->split_parts > 1 && groups >= (size_t)cs->split_parts) parts = (size_t)cs->split_parts;      // explicit request: any size
-        else if (cs->split_parts == 0 && npg * groups >= (size_t)1 << 18 && groups >= 2) parts = 2;
+    if (!cs->timing && cs->split_parts > 1 && groups >= (size_t)cs->split_parts) {
+        parts = (size_t)cs->split_parts;
         lanes = (size_t)cs->split_streams < parts ? (size_t)cs->split_streams : parts;
     }
     if (parts == 1) {
@@ -712,7 +708,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (const char *e = getenv("KZG355_SPLIT")) {
         int a = 1, b = 2;
         const int got = sscanf(e, "%d,%d", &a, &b);
-        if (got >= 1 && a >= 0 && a <= 64) s->split_parts = a;
+        if (got >= 1 && a >= 1 && a <= 64) s->split_parts = a;
         if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
     }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
