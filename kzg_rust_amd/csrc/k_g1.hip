@@ -127,18 +127,23 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 // Throughput form of the same two sums: a variable-base Pippenger MSM per batch ("the batched G1 MSM" of
 // verify_kzg_proof_batch).  Independent scalar multiplications cost ~1830 field-product equivalents per lane whatever the
 // batch; the bucket method shares the doublings:
-//   k_lc_prep     one lane per term: GLV split, signed 4-bit recoding of both halves (33 digits in [-8, 8]),
-//                 the two points P and -phi(P)                                    -> items[2(3n+1)], digits[item][33]
-//   k_lc_buckets  one wave = 16 windows of one class x 8 buckets = 128 lists: LDS counting sort of the class's items by
-//                 |digit|, every lane adds up two lists (longest + shortest)        -> bucket sums B[class][window][b]
-//   k_lc_horner   one lane per (batch, class, b): Horner over the 33 windows (4 doublings + 1 addition each), then the
-//                 weights b over the 8 lanes of a class (suffix scan + butterfly), to affine
-// ~2.3x less issue work per batch than the windowed form above; its dependent chain is no shorter (the Horner tail),
+//   k_lc_prep     one lane per term: GLV split, signed 5-bit recoding of both halves (25 digits in [-16, 15] and an unsigned top
+//                 digit), the two points P and -phi(P)                             -> items[2(3n+1)], digits[item][26]
+//   k_lc_buckets  one 256-thread workgroup per batch, a wave = 6 or 7 windows of both classes x 16 buckets <= 224 lists: LDS
+//                 counting sort of the class's items by |digit|; the lists are ranked by length and dealt to the lanes in
+//                 snake order                                                       -> bucket sums B[class][window][b]
+//   k_lc_horner   one lane per (batch, class, b): Horner over the 26 windows (5 doublings + 1 addition each), then the
+//                 weights b over the 16 lanes of a class (suffix scan + butterfly), to affine
+// Window width: the bucket kernel's work is (items x windows) additions -- 4-bit digits 11.6 k per 64-blob batch, 5-bit 9.7 k,
+// 6-bit 8.4 k -- while the Horner tail has one chain per bucket index: 16 lanes per class at 5 bits still leave it a
+// latency-bound kernel of ~one wave per SIMD at 2048 batches; at 6 bits it would be as much work as the buckets.
+// ~2.7x less issue work per batch than the windowed form above; its dependent chain is no shorter (the Horner tail),
 // so it is used when many batches are in flight and the windowed form otherwise.
-constexpr int LC_DIG_STRIDE = 36;
-constexpr int LC_WINDOWS = 33;          // 32 nibbles of a 128-bit half-scalar + the carry digit
+constexpr int LC_BITS = 5;
+constexpr int LC_BUCKETS = 1 << (LC_BITS - 1);       // |digit| in 1..16
+constexpr int LC_WINDOWS = 26;                       // 25 signed 5-bit digits + the top digit (3 value bits and the carry)
+constexpr int LC_DIG_STRIDE = 28;
 __host__ __device__ inline int lc_items(int n) { return 2 * (3 * n + 1); }
-constexpr int LC_WAVES_PER_CLASS = 2;   // windows 0-15 and 16-31 (the carry window has its own small kernel)
 
 __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint32_t *scal_a, const uint32_t *scal_b, const uint32_t *scal_c, int n,
                                                  G1Affine *items, int8_t *digits) {
@@ -161,53 +166,47 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
     G1Affine q2; g1a_neg_phi(q2, p);
     const size_t base = (size_t)g * lc_items(n) + 2 * (size_t)t;
     items[base] = p; items[base + 1] = q2;
+    // k = sum_w d_w 32^w with d_w = chunk_w(k + BIAS) - 16 for w < 25 and d_25 = the remaining top bits: BIAS has bit 4 of every
+    // 5-bit chunk below the top one set (sum_{w<25} 16 * 32^w)
+    const uint32_t bias[4] = {0x21084210u, 0x08421084u, 0x42108421u, 0x10842108u};
     for (int h = 0; h < 2; h++) {
-        uint32_t e4[5]; uint64_t c = 0;
-        for (int i = 0; i < 4; i++) { c += (uint64_t)half[h][i] + 0x88888888u; e4[i] = (uint32_t)c; c >>= 32; }
-        e4[4] = (uint32_t)c;
+        uint32_t e[6]; uint64_t c = 0;
+        for (int i = 0; i < 4; i++) { c += (uint64_t)half[h][i] + bias[i]; e[i] = (uint32_t)c; c >>= 32; }
+        e[4] = (uint32_t)c; e[5] = 0;
         int8_t *d = digits + (base + h) * LC_DIG_STRIDE;
-        for (int w = 0; w < 32; w++) d[w] = (int8_t)((int)((e4[w >> 3] >> (4 * (w & 7))) & 15u) - 8);
-        d[32] = (int8_t)e4[4];
+        for (int w = 0; w < LC_WINDOWS; w++) {
+            const int bit = LC_BITS * w;
+            const uint64_t two = (uint64_t)e[bit >> 5] | ((uint64_t)e[(bit >> 5) + 1] << 32);
+            const int chunk = (int)((two >> (bit & 31)) & 31u);
+            d[w] = (int8_t)(w < LC_WINDOWS - 1 ? chunk - 16 : chunk);
+        }
     }
 }
 
-// Lists: per task, item | sign << 15 grouped by bucket.  In LDS up to 128 blobs per batch; beyond that (multi-GPU batches of
-// 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~5,000 instructions either way.
-// Balance: a bucket list has 30 +- 5 items (258 items over 8 buckets), and with one list per lane a wave runs as long as its
-// longest list (~43).  So a wave takes SIXTEEN windows = 128 lists, ranks them by length and gives lane i the i-th longest
-// and the i-th shortest: every lane walks ~61 items.  The bucket sums B[window][b] are NOT weighted here: since
-//   sum_w 16^w sum_b b B[w][b] = sum_b b ( sum_w 16^w B[w][b] ),
-// the Horner kernel runs one chain per bucket index (8 lanes per class instead of 1: same latency) and applies the weights b
-// once per class -- 6 additions per class instead of 6 per window (a quarter of this kernel's work before).
-constexpr int LC_TASKS = 16;                     // windows per regular wave
+// Lists: per task (= window x class), item | sign << 15 grouped by bucket.  In LDS up to 129 blobs per batch; beyond that
+// (multi-GPU batches of 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~5,000
+// instructions either way.  Balance: with one list per lane a wave would run as long as its longest list, so the <= 224 lists of
+// a wave are ranked by length and dealt in snake order (lane i takes ranks i, 127 - i, 128 + i, 255 - i): every lane walks about
+// the same number of items.  The bucket sums B[window][b] are NOT weighted here: since
+//   sum_w 32^w sum_b b B[w][b] = sum_b b ( sum_w 32^w B[w][b] ),
+// the Horner kernel runs one chain per bucket index and applies the weights b once per class.
+constexpr int LC_TASKS = 14;                     // 7 windows x 2 classes at most per wave
 constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
 __host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
-// the carry digit (0 or 1) of every item: a single bucket holding about half of the class -> one wave per (batch, class)
-__global__ void __launch_bounds__(64) k_lc_carry(const G1Affine *items, const int8_t *digits, int n, G1Jac *S) {
-    const int g = blockIdx.x >> 1, cls = blockIdx.x & 1, lane = threadIdx.x;
-    const int ni = lc_items(n), w0 = LC_WINDOWS - 1;
-    const int lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;
-    const G1Affine *it = items + (size_t)g * ni;
-    const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
-    G1Jac acc = g1_inf();
-    for (int j = lo + lane; j < hi; j += 64)
-        if (dg[(size_t)j * LC_DIG_STRIDE + w0]) { G1Affine p = it[j]; g1_add_mixed(acc, acc, p); }
-#pragma unroll 1
-    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
-    if (lane == 0) S[(((size_t)g * 2 + cls) * LC_WINDOWS + w0) * 8] = acc;          // bucket 1 of the carry window
-}
-// One 256-thread workgroup per batch: wave j takes the windows 8 j .. 8 j + 7 of both classes -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see k_pairing.hip), each
-// with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach the same number of times.
+__host__ __device__ inline int lc_wave_w0(int wid) { return wid < 2 ? 7 * wid : 14 + 6 * (wid - 2); }       // windows 0-6, 7-13, 14-19, 20-25
+__host__ __device__ inline int lc_wave_nw(int wid) { return wid < 2 ? 7 : 6; }
+// One 256-thread workgroup per batch -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see
+// k_pairing.hip), each with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach
+// the same number of times.
 __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
     __shared__ uint16_t lists_all[4][LC_TASKS][LC_LDS_LIST];
-    __shared__ int cnt_all[4][LC_TASKS][9], start_all[4][LC_TASKS][9], cursor_all[4][LC_TASKS][9];
-    __shared__ uint8_t order_all[4][8 * LC_TASKS];
+    __shared__ int cnt_all[4][LC_TASKS][LC_BUCKETS + 1], start_all[4][LC_TASKS][LC_BUCKETS + 1], cursor_all[4][LC_TASKS][LC_BUCKETS + 1];
+    __shared__ uint8_t order_all[4][LC_BUCKETS * LC_TASKS];
     const int g = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // wave `wid`: windows 8 wid .. 8 wid + 7 of BOTH classes: tasks 0-7 are class 1 (2 (2n+1) items), tasks 8-15 class 0 (2n items), so
-    // the four waves carry equal work and the length ranking below pairs every long class-1 list with a short class-0 list
-    const int w0 = wid * 8;
+    // wave `wid`: its windows of BOTH classes: tasks 0..nw-1 are class 1 (2 (2n+1) items), tasks nw..2nw-1 class 0 (2n items)
+    const int w0 = lc_wave_w0(wid), nw = lc_wave_nw(wid), ntasks = 2 * nw, nlists = LC_BUCKETS * ntasks;
     uint16_t (*lists_lds)[LC_LDS_LIST] = lists_all[wid];
-    int (*cnt)[9] = cnt_all[wid], (*start)[9] = start_all[wid], (*cursor)[9] = cursor_all[wid];
+    int (*cnt)[LC_BUCKETS + 1] = cnt_all[wid], (*start)[LC_BUCKETS + 1] = start_all[wid], (*cursor)[LC_BUCKETS + 1] = cursor_all[wid];
     uint8_t *order = order_all[wid];
     const int ni = lc_items(n);
     const G1Affine *it = items + (size_t)g * ni;
@@ -215,39 +214,41 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
     const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
     const int stride = in_lds ? LC_LDS_LIST : lc_list_stride(n);
     uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + ((size_t)blockIdx.x * 4 + wid) * LC_TASKS * stride;
-    for (int q = lane; q < 9 * LC_TASKS; q += 64) cnt[q / 9][q % 9] = 0;
+    for (int q = lane; q < (LC_BUCKETS + 1) * LC_TASKS; q += 64) cnt[q / (LC_BUCKETS + 1)][q % (LC_BUCKETS + 1)] = 0;
     __syncthreads();
 #pragma unroll 1
-    for (int tk = 0; tk < LC_TASKS; tk++) {
-        const int w = w0 + (tk & 7), lo = tk < 8 ? 2 * n : 0, hi = tk < 8 ? ni : 2 * n;      // item range of the task's class (terms t < n are class 0)
+    for (int tk = 0; tk < ntasks; tk++) {
+        const int w = w0 + (tk < nw ? tk : tk - nw), lo = tk < nw ? 2 * n : 0, hi = tk < nw ? ni : 2 * n;      // item range of the task's class (terms t < n are class 0)
         for (int j = lo + lane; j < hi; j += 64) { const int d = dg[(size_t)j * LC_DIG_STRIDE + w]; if (d) atomicAdd(&cnt[tk][d < 0 ? -d : d], 1); }
     }
     __syncthreads();
-    if (lane < LC_TASKS) { int run = 0; for (int b = 1; b <= 8; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
+    if (lane < ntasks) { int run = 0; for (int b = 1; b <= LC_BUCKETS; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
     __syncthreads();
 #pragma unroll 1
-    for (int tk = 0; tk < LC_TASKS; tk++) {
-        const int w = w0 + (tk & 7), lo = tk < 8 ? 2 * n : 0, hi = tk < 8 ? ni : 2 * n;
+    for (int tk = 0; tk < ntasks; tk++) {
+        const int w = w0 + (tk < nw ? tk : tk - nw), lo = tk < nw ? 2 * n : 0, hi = tk < nw ? ni : 2 * n;
         for (int j = lo + lane; j < hi; j += 64) {
             const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
             if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk * stride + pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
         }
     }
-    // rank the 128 lists by length (ties by index): order[rank] = list
+    // rank the lists by length (ties by index): order[rank] = list
 #pragma unroll 1
-    for (int L = lane; L < 8 * LC_TASKS; L += 64) {
-        const int len = cnt[L >> 3][(L & 7) + 1];
+    for (int L = lane; L < nlists; L += 64) {
+        const int len = cnt[L / LC_BUCKETS][(L % LC_BUCKETS) + 1];
         int rank = 0;
-        for (int M = 0; M < 8 * LC_TASKS; M++) { const int lm = cnt[M >> 3][(M & 7) + 1]; rank += (lm > len) || (lm == len && M < L); }
+        for (int M = 0; M < nlists; M++) { const int lm = cnt[M / LC_BUCKETS][(M % LC_BUCKETS) + 1]; rank += (lm > len) || (lm == len && M < L); }
         order[rank] = (uint8_t)L;
     }
     __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    G1Jac *out = S + (size_t)g * 2 * LC_WINDOWS * 8;               // bucket sums [class][window][bucket - 1]; weighted by the Horner kernel
+    G1Jac *out = S + (size_t)g * 2 * LC_WINDOWS * LC_BUCKETS;       // bucket sums [class][window][bucket - 1]; weighted by the Horner kernel
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {           // the i-th longest list, then the i-th shortest
-        const int L = order[pass == 0 ? lane : 8 * LC_TASKS - 1 - lane];
-        const int tk = L >> 3, b = (L & 7) + 1;
+    for (int pass = 0; pass < 4; pass++) {           // snake order over the ranked lists
+        const int r = 64 * pass + ((pass & 1) ? 63 - lane : lane);
+        if (r >= nlists) continue;
+        const int L = order[r];
+        const int tk = L / LC_BUCKETS, b = (L % LC_BUCKETS) + 1;
         const int s0 = start[tk][b], c = cnt[tk][b];
         G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
         // the list entry two steps ahead and the point one step ahead are in flight during an addition (with the lists in the
@@ -267,35 +268,42 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
         }
         G1X cx; g1x_from_lazy(cx, accx, started);
         G1Jac acc; g1x_to_jac(acc, cx);
-        out[((size_t)(tk < 8 ? 1 : 0) * LC_WINDOWS + w0 + (tk & 7)) * 8 + (b - 1)] = acc;
+        out[((size_t)(tk < nw ? 1 : 0) * LC_WINDOWS + w0 + (tk < nw ? tk : tk - nw)) * LC_BUCKETS + (b - 1)] = acc;
     }
 }
 
-__global__ void __launch_bounds__(64) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, bucket - 1): 8-lane segments never straddle a wave
-    const int lane = threadIdx.x;
-    const bool live = id < 16 * groups;
-    const int gc = live ? id >> 3 : 0, bi = id & 7;               // gc = 2 g + class
-    const G1Jac *s = S + (size_t)gc * LC_WINDOWS * 8;
-    G1Jac acc = g1_inf();
-    if (live && bi == 0) acc = s[(size_t)(LC_WINDOWS - 1) * 8];   // the carry window has the single bucket 1
+__device__ __forceinline__ G1Jac g1_shfl_down16(const G1Jac &v, int delta) {     // within segments of 16 lanes
+    G1Jac r;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 16); r.y.l[i] = __shfl_down(v.y.l[i], delta, 16); r.z.l[i] = __shfl_down(v.z.l[i], delta, 16); }
+    return r;
+}
+// 256-thread workgroups: four waves, one per SIMD of the CU the workgroup lands on (64-thread workgroups of this latency-bound chain
+// were placed two to a SIMD while other SIMDs idled: 2.9 instead of 1.9 ms per 2048 batches); the waves share nothing.
+__global__ void __launch_bounds__(256) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, bucket - 1): 16-lane segments never straddle a wave
+    const int lane = threadIdx.x & 63;
+    const bool live = id < 2 * LC_BUCKETS * groups;
+    const int gc = live ? id / LC_BUCKETS : 0, bi = id % LC_BUCKETS;     // gc = 2 g + class
+    const G1Jac *s = S + (size_t)gc * LC_WINDOWS * LC_BUCKETS;
+    G1Jac acc = live ? s[(size_t)(LC_WINDOWS - 1) * LC_BUCKETS + bi] : g1_inf();
     // lazy chain (g1.h): no reductions until the end; one doubling body, one addition body
 #pragma unroll 1
-    for (int k = 4 * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
+    for (int k = LC_BITS * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
         g1_dbl_lazy(acc, acc);
-        if ((k & 3) == 0) { G1Jac v = live ? s[(size_t)(k >> 2) * 8 + bi] : g1_inf(); g1_add_lazy(acc, acc, v); }
+        if (k % LC_BITS == 0) { G1Jac v = live ? s[(size_t)(k / LC_BITS) * LC_BUCKETS + bi] : g1_inf(); g1_add_lazy(acc, acc, v); }
     }
     g1_canon_lazy(acc, acc);
-    // sum_b b * A_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} A_b: 3-step suffix scan over the 8 lanes, 3-step butterfly
+    // sum_b b * A_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} A_b: 4-step suffix scan over the 16 lanes, 4-step butterfly
     G1Jac r = acc;
 #pragma unroll 1
-    for (int off = 1; off < 8; off <<= 1) {
-        G1Jac o = g1_shfl_down8(r, off), t;
+    for (int off = 1; off < LC_BUCKETS; off <<= 1) {
+        G1Jac o = g1_shfl_down16(r, off), t;
         g1_add(t, r, o);
-        if ((lane & 7) + off < 8) r = t;
+        if ((lane % LC_BUCKETS) + off < LC_BUCKETS) r = t;
     }
 #pragma unroll 1
-    for (int off = 1; off < 8; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
+    for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
     if (!live || bi != 0) return;
     G1Affine a; g1_to_affine(a, r);
     if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
@@ -347,20 +355,17 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
     G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
-    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * 8 * groups);
+    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) {
-        hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists);
-        hipLaunchKernelGGL(k_lc_carry, dim3(2 * groups), dim3(64), 0, st, items, digits, n_per_group, S);
-    }
-    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((16 * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists);
+    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * LC_BUCKETS * groups + 255) / 256), dim3(256), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
-    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 2 * LC_WAVES_PER_CLASS * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
-    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * 8 * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
+    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
