@@ -88,6 +88,7 @@ def main():
                     help="time the host-buffer drop-in entry point (H2D over PCIe inside the timed region); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the config.host_inputs measurements of the default run")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-batch latency calls (profiling runs: every launch is then a full-size one)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels of the timed region (A/B of their cost; no roofline)")
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (two-stage HipEngine driver of sharded.py) even at world size 1")
@@ -205,10 +206,12 @@ def main():
         torch.cuda.synchronize()
 
     # single-batch latency (reported, not the metric)
-    run_steps(1)
-    lat = []
-    for _ in range(5):
-        barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
+    lat = [float("nan")]
+    if not args.no_latency:
+        run_steps(1)
+        lat = []
+        for _ in range(5):
+            barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
     latency_ms = statistics.median(lat)
 
     for _ in range(W):
@@ -286,7 +289,7 @@ def main():
                        "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
                        "msm_form": s.msm_form,
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
-                       "latency_ms_single_batch": round(latency_ms, 3), "latency_ms_single_batch_min": round(min(lat), 3),
+                       "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
                        "host_inputs": host_inputs},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
