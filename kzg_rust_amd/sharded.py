@@ -58,6 +58,13 @@ def partition(n_total, world):
     return [(r * n_local, (r + 1) * n_local) for r in range(world)]
 
 
+def _on_host(group):
+    """gloo moves host memory: with device tensors the two collectives are staged through the host (CPU tests, and the two-ranks-on-
+    one-GPU test of the HIP engine); nccl = RCCL takes the device tensors as they are."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
 def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group=None):
     """`groups` independent batches; this rank holds n_local blobs of each (group-major uint8 tensors).
     Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err."""
@@ -73,8 +80,13 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         return [o and s == 0 for o, s in zip(ok, status)], status
     nloc = groups * n_local * RECORD
     rank = dist.get_rank(group)
-    gathered = torch.empty(world * nloc, dtype=torch.uint8, device=rec.device)
-    dist.all_gather_into_tensor(gathered, rec, group=group)         # the ONE data-path collective
+    if _on_host(group) and rec.is_cuda:
+        host = torch.empty(world * nloc, dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        gathered = host.to(rec.device)
+    else:
+        gathered = torch.empty(world * nloc, dtype=torch.uint8, device=rec.device)
+        dist.all_gather_into_tensor(gathered, rec, group=group)     # the ONE data-path collective
     # this rank's share of the batches: [rank][batch][n_local*160] -> [batch in share][rank][n_local*160]
     g_lo, g_hi = (groups * rank) // world, (groups * (rank + 1)) // world
     code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
@@ -85,6 +97,8 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
             torch.cuda.synchronize(rec.device)
         ok, st2 = engine.verify_records(recs, n_local * world, g_hi - g_lo)
         code[groups + g_lo:groups + g_hi] = torch.tensor([1 + int(o) + 256 * int(s) for o, s in zip(ok, st2)], dtype=torch.int32, device=rec.device)
+    if _on_host(group) and code.is_cuda:
+        code = code.cpu()
     dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)        # verdicts of every share + status merge, one small collective
     code = code.tolist()
     status = [int(code[g]) or (code[groups + g] >> 8) for g in range(groups)]
