@@ -68,7 +68,8 @@ struct Workspace {
     hipStream_t stream = nullptr, side = nullptr;     // side: kernels independent of the main chain (point validation)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;      // work on the side stream that the main stream has not waited for yet
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts;
+    bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
     PinBuf h_ok, h_err, h_out;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
     hipEvent_t ev[32];
@@ -80,7 +81,7 @@ struct Workspace {
         in_flight = false; side_pending = false;
     }
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials}) b->release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release();
         if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
@@ -156,7 +157,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
-    int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method (KZG355_LINCOMB=window|bucket)
+    int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
     std::mutex mu;
     hipStream_t side_stream = nullptr;   // shared by the workspaces (point validation of small calls next to the hash chain)
     std::vector<Workspace *> pool;
@@ -232,6 +233,18 @@ struct Timed {
 inline bool is_small(const kzg355_settings *s) { return s->t.n_fe != N_FE; }
 inline size_t blob_bytes_of(const kzg355_settings *s) { return (size_t)32 * s->t.n_fe; }
 
+// which form the batch linear combination takes (KZG355_LINCOMB pins it: 1 window, 2 bucket, 3 pre-shifted)
+enum { LC_FORM_WINDOW = 1, LC_FORM_BUCKET = 2, LC_FORM_PRESHIFT = 3 };
+int lincomb_form(const kzg355_settings *s, int npg, int groups) {
+    const bool bucket_ok = npg >= 8 && npg <= 4096, pre_ok = lincomb_preshift_fits(npg, groups);
+    if (s->lincomb_mode == LC_FORM_PRESHIFT) return pre_ok ? LC_FORM_PRESHIFT : LC_FORM_WINDOW;
+    if (s->lincomb_mode == LC_FORM_BUCKET) return bucket_ok ? LC_FORM_BUCKET : LC_FORM_WINDOW;
+    if (s->lincomb_mode == LC_FORM_WINDOW) return LC_FORM_WINDOW;
+    // few batches: shift every point under the hash, finish with ~25 additions; many: least issue work (buckets); in between: per-term ladders
+    if (pre_ok) return LC_FORM_PRESHIFT;
+    return bucket_ok && groups >= 64 ? LC_FORM_BUCKET : LC_FORM_WINDOW;
+}
+
 int status_from_err(int err) {
     if (err == 0) return KZG355_OK;
     return KZG355_BADARGS;   // validate_kzg_g1 / bytes_to_bls_field failures are Error::BadArgs (utils.rs:268, 292, 304)
@@ -261,6 +274,12 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
         tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
+        if (d_pts && !is_small(s) && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT) {
+            // the doubling chains of the linear combination depend on the points alone: walk them now, beside the hash
+            if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, n_total / npg)))) return rc;
+            tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side);
+            w->shift_ready = true;
+        }
         HIPCHK(hipEventRecord(w->ev_join, w->side));
         w->side_pending = true;
     } else {
@@ -282,21 +301,31 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
-    if ((rc = w->lc_partials.ensure(lincomb_partials_bytes(npg, groups)))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe); tm.end();
-    // windowed per-term form (shortest chain) for few batches, bucket method (least issue work) when many are in flight
-    const bool buckets = npg >= 8 && npg <= 4096 && (s->lincomb_mode == 2 || (s->lincomb_mode == 0 && groups >= 64));
-    if (buckets && (rc = w->lc_partials.ensure(lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
-    if ((rc = join_side(w))) return rc;                           // the validated points are needed from here on
-    if (buckets) {
+    const int form = lincomb_form(s, npg, groups);
+    const bool buckets = form == LC_FORM_BUCKET;
+    if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
+    if ((rc = join_side(w))) return rc;                           // the validated points (and their shifts) are needed from here on
+    if (form == LC_FORM_PRESHIFT) {
+        if (!w->shift_ready) {                                    // entry points without a stage 1 (single proofs, gathered records)
+            if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, groups)))) return rc;
+            tm.begin("lincomb_shift"); launch_lincomb_preshift(d_pts, npg, groups, w->shifts.as<G1Jac>(), w->stream); tm.end();
+        }
+        w->shift_ready = false;
+        tm.begin("lincomb");
+        launch_lincomb_preshifted(d_pts, w->shifts.as<G1Jac>(), w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p,
+                                  w->pair_pts.as<G1Affine>(), w->stream);
+    } else if (buckets) {
         static const char *names[3] = {"lincomb_prep", "lincomb", "lincomb_horner"};       // "lincomb" = the bucket kernel itself
         for (int stage = 1; stage <= 3; stage++) {
             if (stage > 1) tm.end();
             tm.begin(names[stage - 1]);
             launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream, stage);
         }
-    } else tm.begin("lincomb");
-    if (!buckets) launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
+    } else {
+        tm.begin("lincomb");
+        launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
+    }
     tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
@@ -712,7 +741,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
     }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
-    if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : 0;
+    if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);

@@ -310,6 +310,111 @@ __global__ void __launch_bounds__(256) k_lc_horner(const G1Jac *S, int groups, G
     pair_pts[gc] = a;
 }
 
+// ------------------------------------------------------------------------------------------------ lincomb, pre-shifted form
+// Latency form for FEW batches.  The three sums need the batch challenge r, and r needs every y_i, i.e. the whole SHA-256 chain
+// of the blobs (3.7 ms for one batch) -- but the POINTS are inputs.  So while the hash runs, a side-stream kernel walks the
+// doubling chain of every input point once and keeps  Q[pt][w] = 32^w P  for the 26 windows (k_ps_shift: 125 doublings per
+// lane, the whole dependent chain of a scalar multiplication).  Once r is known the sums are pure bucket sums with NO doubling
+// left:  sum_items sum_w d_w Q[item][w] = sum_b b (sum of the +-Q with |digit| = b):
+//   k_lc_prep      (as above)  GLV split + signed 5-bit digits of the 2 (3n + 1) half-scalars
+//   k_ps_buckets   one 512-thread workgroup per (batch, class): LDS counting sort of the (item, window) pairs by |digit|; 32 lanes
+//                  per bucket add up their share (~13 Jacobian additions each at n = 64), butterfly over the 32 lanes, then
+//                  the weights b over 16 lanes (suffix scan + butterfly), to affine.
+// ~25 dependent additions after r instead of 125 doublings + 33 additions: 2.0 -> 0.5 ms for one 64-blob batch, and the
+// shifting hides under the hash next to the point validation.  More total work than either other form (every point is doubled
+// 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (<= 32 batches of <= 128 blobs).
+constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
+constexpr int PS_THREADS = 512, PS_LANES_PER_BUCKET = PS_THREADS / LC_BUCKETS;     // 32
+__host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
+// thread (g, pt): Q[w] = 32^w P for w = 0..25, canonical Jacobian.  Point 2n of every batch is -G (the term -[sum r^i y_i] G).
+__global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, int n, int groups, G1Jac *shifts) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
+    if (id >= np * groups) return;
+    const int g = id / np, pt = id % np;
+    G1Affine p;
+    if (pt < 2 * n) p = pts[(size_t)g * 2 * n + pt];
+    else {
+        const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT;
+        for (int q = 0; q < NFP; q++) { p.x.l[q] = gx[q]; p.y.l[q] = gy[q]; }
+        fp_neg(p.y, p.y);
+    }
+    G1Jac acc; g1_from_affine(acc, p);
+    G1Jac *out = shifts + (size_t)id * LC_WINDOWS;
+    out[0] = acc;
+#pragma unroll 1
+    for (int k = 1; k <= LC_BITS * (LC_WINDOWS - 1); k++) {
+        g1_dbl_lazy(acc, acc);
+        if (k % LC_BITS == 0) { G1Jac c; g1_canon_lazy(c, acc); out[k / LC_BITS] = c; acc = c; }
+    }
+}
+// item j of a batch -> index of its point in the shift table (items 2t, 2t+1 belong to term t; see k_lc_prep)
+__device__ __forceinline__ int ps_point_of_item(int j, int n) {
+    const int t = j >> 1;
+    return t < n ? n + t : t < 2 * n ? n + (t - n) : t < 3 * n ? t - 2 * n : 2 * n;
+}
+__global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const int8_t *digits, int n, G1Affine *pair_pts) {
+    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15, grouped by bucket
+    __shared__ int cnt[LC_BUCKETS + 1], start[LC_BUCKETS + 1], cursor[LC_BUCKETS + 1];
+    __shared__ G1Jac sb[LC_BUCKETS];
+    const int g = blockIdx.x >> 1, cls = blockIdx.x & 1, tid = threadIdx.x;
+    const int ni = lc_items(n), lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;      // the class's items (terms t < n are class 0)
+    const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
+    const G1Jac *sh = shifts + (size_t)g * ps_points(n) * LC_WINDOWS;
+    const int npairs = (hi - lo) * LC_WINDOWS;
+    if (tid <= LC_BUCKETS) cnt[tid] = 0;
+    __syncthreads();
+    for (int q = tid; q < npairs; q += PS_THREADS) {
+        const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
+        const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
+        if (d) atomicAdd(&cnt[d < 0 ? -d : d], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int b = 1; b <= LC_BUCKETS; b++) { start[b] = run; cursor[b] = run; run += cnt[b]; } }
+    __syncthreads();
+    for (int q = tid; q < npairs; q += PS_THREADS) {
+        const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
+        const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
+        if (d) { const int pos = atomicAdd(&cursor[d < 0 ? -d : d], 1); list[pos] = (uint16_t)((j - lo) | (w << 10) | (d < 0 ? 0x8000 : 0)); }
+    }
+    __syncthreads();
+    // 32 lanes per bucket: lane s takes entries s, s + 32, ... of the bucket's list
+    const int b = tid / PS_LANES_PER_BUCKET + 1, sl = tid % PS_LANES_PER_BUCKET;
+    const uint32_t bc[NFP] = FP_BETA_INIT;
+    Fp beta; for (int i = 0; i < NFP; i++) beta.l[i] = bc[i];
+    G1Jac acc = g1_inf();
+    const int s0 = start[b], c = cnt[b];
+#pragma unroll 1
+    for (int q = sl; q < c; q += PS_LANES_PER_BUCKET) {
+        const uint32_t v = list[s0 + q];
+        const int j = lo + (int)(v & 0x3ff), w = (int)((v >> 10) & 31);
+        G1Jac p = sh[(size_t)ps_point_of_item(j, n) * LC_WINDOWS + w];
+        bool neg = (v & 0x8000) != 0;
+        if (j & 1) { Fp bx; fp_mul(bx, p.x, beta); p.x = bx; neg = !neg; }       // the odd item of a term is -phi(P) = (beta x, -y)
+        if (neg) fp_neg(p.y, p.y);
+        g1_add_lazy(acc, acc, p);
+    }
+    g1_canon_lazy(acc, acc);
+#pragma unroll 1
+    for (int off = 1; off < PS_LANES_PER_BUCKET; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
+    if (sl == 0) sb[b - 1] = acc;
+    __syncthreads();
+    if (tid >= 64) return;
+    // sum_b b * S_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} S_b (as in k_lc_horner)
+    G1Jac r = tid < LC_BUCKETS ? sb[tid] : g1_inf();
+#pragma unroll 1
+    for (int off = 1; off < LC_BUCKETS; off <<= 1) {
+        G1Jac o = g1_shfl_down16(r, off), t;
+        g1_add(t, r, o);
+        if ((tid % LC_BUCKETS) + off < LC_BUCKETS) r = t;
+    }
+#pragma unroll 1
+    for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
+    if (tid != 0) return;
+    G1Affine a; g1_to_affine(a, r);
+    if (cls == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);            // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[2 * (size_t)g + cls] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
                             hipStream_t st, int stride) {
@@ -366,6 +471,24 @@ size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
     return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
+}
+bool lincomb_preshift_fits(int n_per_group, int groups) { return n_per_group >= 1 && n_per_group <= PS_MAX_N && groups >= 1 && groups <= 32; }
+size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac) * (size_t)ps_points(n_per_group) * LC_WINDOWS * groups; }
+void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
+    if (groups <= 0) return;
+    const int total = ps_points(n_per_group) * groups;
+    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, d_pts, n_per_group, groups, d_shifts);
+}
+void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
+                               int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st) {
+    if (groups <= 0) return;
+    const size_t ni = (size_t)lc_items(n_per_group) * groups;
+    G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);          // same scratch layout as the bucket form (lincomb_buckets_scratch_bytes)
+    G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
+    int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
+    const int nt = 3 * n_per_group + 1;
+    hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups), dim3(PS_THREADS), 0, st, d_shifts, digits, n_per_group, d_pair_pts);
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;

@@ -78,6 +78,13 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
                             int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, G1Affine *d_pair_pts, hipStream_t st,
                             int stage = 0 /* 0: all three kernels; 1 prep, 2 buckets, 3 horner (per-kernel timing) */);
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups);
+// pre-shifted form for few batches: launch_lincomb_preshift needs only the validated points (it can run beside the Fiat-Shamir
+// hash), launch_lincomb_preshifted finishes once the r powers exist.  d_scratch: lincomb_buckets_scratch_bytes().
+bool lincomb_preshift_fits(int n_per_group, int groups);
+size_t lincomb_preshift_bytes(int n_per_group, int groups);
+void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
+void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
+                               int n_per_group, int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st);
 void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 

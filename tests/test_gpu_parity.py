@@ -646,7 +646,7 @@ def lincomb_handles(kz, setup_bytes):
     """One handle per form of the batch linear combination (KZG355_LINCOMB pins it when the handle is created)."""
     g1, g2 = setup_bytes
     hs = {}
-    for form in ("window", "bucket"):
+    for form in ("window", "bucket", "preshift"):
         os.environ["KZG355_LINCOMB"] = form
         try:
             hs[form] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
