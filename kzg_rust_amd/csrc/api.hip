@@ -1375,13 +1375,24 @@ int kzg355_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
     Timed tm(s, w);
     const uint8_t *d_rec = w->records.as<uint8_t>();
-    // bytes_to_kzg_commitment / bytes_to_kzg_proof (kzg.rs:436, 439): full validation incl. subgroup
-    tm.begin("validate_points"); launch_validate_points(d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
+    // bytes_to_kzg_commitment / bytes_to_kzg_proof (kzg.rs:436, 439): full validation incl. subgroup.  Decoding first; the subgroup
+    // test only feeds the error word, so it runs on the side stream beside the r powers, the linear combination and most of the pairing
+    tm.begin("decompress_points"); launch_decompress_points(d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream, 48); tm.end();
+    w->in_flight = true;
+    const bool sub_on_side = ensure_side(s, w);
+    if (sub_on_side) {
+        HIPCHK(hipEventRecord(w->ev_fork, w->stream));
+        HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+        tm.begin("validate_points", w->side); launch_subgroup_points(w->pts.as<G1Affine>(), 1, 1, w->err.as<int>(), w->side); tm.end(w->side);
+        HIPCHK(hipEventRecord(w->ev_join, w->side));
+    } else { tm.begin("validate_points"); launch_subgroup_points(w->pts.as<G1Affine>(), 1, 1, w->err.as<int>(), w->stream); tm.end(); }
     // z, y canonical checks (kzg.rs:437-438) happen in k_rpowers (check_zy = 1)
     if ((rc = run_stage2(s, w, tm, d_rec, 1, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if (sub_on_side) HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0));       // the subgroup verdict, before the error word goes back
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     int st = status_from_err(w->h_err.as<int>()[0]);
     if (st == KZG355_OK) *ok = w->h_ok.as<int>()[0] != 0;

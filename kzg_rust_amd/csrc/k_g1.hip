@@ -31,6 +31,30 @@ __global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commi
     if (pts) pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
 }
 
+// The two halves of k_validate_points as kernels of their own, for the single-proof entry point: the linear combination only needs
+// the decompressed points, the subgroup test only feeds the error word -- so the test runs on the side stream beside the rest of the
+// chain (1.2 of verify_kzg_proof's 6.1 ms).
+__global__ void __launch_bounds__(64) k_decompress_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+                                                          G1Affine *pts, int *err, int stride) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * n_total) return;
+    const bool is_proof = j >= n_total;
+    const int i = is_proof ? j - n_total : j;
+    const uint8_t *src = (is_proof ? proofs : commitments) + (size_t)stride * i;
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = src[k];
+    G1Affine p;
+    const int g = i / n_per_group, k = i % n_per_group;
+    if (g1_decompress(p, b) != 0) { atomicOr(&err[g], ERR_BAD_POINT); p = g1a_inf(); }
+    pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
+}
+__global__ void __launch_bounds__(64) k_subgroup_points(const G1Affine *pts, int n_points, int n_per_group, int *err) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_points) return;
+    const G1Affine p = pts[j];
+    if (!g1a_is_inf(p) && !g1_in_subgroup(p)) atomicOr(&err[j / (2 * n_per_group)], ERR_BAD_POINT);      // infinity is accepted (utils.rs:298-301)
+}
+
 // Decompress the C_i / proof_i fields of gathered records (already validated by their owner rank).
 __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *records, int n_total, int n_per_group, G1Affine *pts, int *err) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,6 +464,14 @@ __global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_
 void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out, hipStream_t st) {
     if (groups <= 0) return;
     hipLaunchKernelGGL(k_dump_intermediates, dim3((2 * groups + 63) / 64), dim3(64), 0, st, d_scal_a, d_pair_pts, n_per_group, groups, d_out);
+}
+void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st, int stride) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_decompress_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+}
+void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_subgroup_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_pts, 2 * n_total, n_per_group, d_err);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
     if (n_total <= 0) return;

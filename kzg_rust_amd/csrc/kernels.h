@@ -60,6 +60,10 @@ void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTa
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group,
                             G1Affine *d_pts /* [group][2*npg]: commitments then proofs; may be null */, int *d_err /* per group */,
                             hipStream_t st, int stride = 48 /* bytes between consecutive inputs: 48 packed, 160 inside records */);
+// validate_kzg_g1 in two launches: decoding (-> points, error on a bad encoding / off-curve x) and the subgroup test (-> error only)
+void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st,
+                              int stride = 48);
+void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st);
 void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
