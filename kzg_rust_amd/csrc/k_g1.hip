@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k_lc_horner(const G1Jac *S, int groups, G
 //                  the weights b over 16 lanes (suffix scan + butterfly), to affine.
 // ~25 dependent additions after r instead of 125 doublings + 33 additions: 2.0 -> 0.5 ms for one 64-blob batch, and the
 // shifting hides under the hash next to the point validation.  More total work than either other form (every point is doubled
-// 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (<= 32 batches of <= 128 blobs).
+// 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (fewer than 64 batches of <= 128 blobs; from 64 batches on the bucket form).
 constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
 constexpr int PS_THREADS = 512, PS_LANES_PER_BUCKET = PS_THREADS / LC_BUCKETS;     // 32
 __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
@@ -504,7 +504,7 @@ size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
     return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
 }
-bool lincomb_preshift_fits(int n_per_group, int groups) { return n_per_group >= 1 && n_per_group <= PS_MAX_N && groups >= 1 && groups <= 32; }
+bool lincomb_preshift_fits(int n_per_group, int groups) { return n_per_group >= 1 && n_per_group <= PS_MAX_N && groups >= 1 && groups < 64; }
 size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac) * (size_t)ps_points(n_per_group) * LC_WINDOWS * groups; }
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
     if (groups <= 0) return;

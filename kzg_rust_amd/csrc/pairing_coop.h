@@ -485,8 +485,10 @@ KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, con
         if (lane < 24) { m.line[lane / 12].c[lane % 12] = fp_zero(); }
     }
     COOP_SYNC();
+    CoopInsn nxt = prog[0];
     for (int pc = 0; pc < n_insn; pc++) {
-        const CoopInsn in = prog[pc];
+        const CoopInsn in = nxt;
+        if (pc + 1 < n_insn) nxt = prog[pc + 1];                 // fetched a whole operation ahead of its use
         Fp12W &dst = coop_slot(m, in.dst);
         const Fp12W &a = coop_slot(m, in.a);
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
