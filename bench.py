@@ -267,7 +267,7 @@ def main():
                     "path_bytes_per_blob": OP_BYTES_PER_BLOB[args.op],
                     "path_frac_of_hbm_peak": value * OP_BYTES_PER_BLOB[args.op] / (world * HBM_PEAK_GBPS * 1e9),
                     "measured_stream_copy_gbps": stream_copy_peak(torch, dev) if rank == 0 else None,
-                    "alu": alu_roofline(stats, blobs_per_launch_of, value / world),
+                    "alu": alu_roofline(stats, blobs_per_launch_of, value / world) if args.op == "verify" else None,      # (the committed SQ pass is over the verify bench)
                     "note": "integer-issue-bound path (~1e3 integer ops per byte): the HBM fraction is small by construction; roofline.alu is the bound that binds"}
 
     host_inputs = None
