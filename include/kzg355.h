@@ -132,6 +132,15 @@ int kzg355_verify_shard_records_device(uint8_t *d_records /* groups*n_local*160,
 /* Stage 2, replicated on every rank, over ALL gathered records (device): `groups` batches of n records each
  * (group-major).  r-powers (utils.rs:426-474), the three linear combinations and the pairing check (kzg.rs:579-627).
  * n == 1 reproduces the single-blob path (kzg.rs:658); n == 0 is an error like kzg.rs:588-592. */
+/* The same two stages with the decoded points travelling next to the records: stage 1 also writes the validated affine points of its
+ * shard (d_points: groups x [n_local commitments, n_local proofs] x KZG355_BYTES_PER_POINT opaque bytes), and stage 2 takes the points
+ * of the gathered batches (groups x [n commitments, n proofs]) instead of decompressing C_i / proof_i again (a 381-bit square root
+ * per point).  The caller gathers both buffers (kzg_rust_amd/sharded.py does it in the same all-gather). */
+#define KZG355_BYTES_PER_POINT 112
+int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                              const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *s);
+int kzg355_verify_records_points_device(bool *ok, int *status, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups,
+                                        const kzg355_settings *s);
 /* PRECONDITION: the records come from kzg355_verify_shard_records_device (here or on another rank) and every rank's stage-1
  * status has been merged into the verdict by the caller (kzg_rust_amd/sharded.py does): this entry point decompresses C_i and
  * proof_i WITHOUT the subgroup test and does not re-check that z_i, y_i are canonical -- stage 1 already did both.  A caller

@@ -49,6 +49,8 @@ def load():
         "kzg355_compute_blob_kzg_proof_many_device": [u8p, ip, vp, vp, sz, vp],
         "kzg355_verify_shard_records_device": [vp, ip, vp, vp, vp, sz, sz, vp],
         "kzg355_verify_records_device": [bp, ip, vp, sz, sz, vp],
+        "kzg355_verify_shard_records_points_device": [vp, vp, ip, vp, vp, vp, sz, sz, vp],
+        "kzg355_verify_records_points_device": [bp, ip, vp, vp, sz, sz, vp],
         "kzg355_verify_records_checked_device": [bp, ip, vp, sz, sz, vp],
         "kzg355_debug_batch_intermediates": [u8p, bp, ip, vp, sz, sz, vp],
         "kzg355_kernel_ms_stats": [vp, u8p, C.POINTER(C.c_double), C.POINTER(C.c_long)],
@@ -85,5 +87,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_compute_blob_kzg_proof_many_device", "kzg355_verify_shard_records_device", "kzg355_verify_records_device",
     "kzg355_settings_device", "kzg355_last_kernel_ms", "kzg355_set_kernel_timing", "kzg355_version",
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
-    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
+    "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_verify_shard_records_points_device", "kzg355_verify_records_points_device", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
 ]

@@ -261,7 +261,7 @@ int status_from_err(int err) {
 
 // ---- stage drivers (all asynchronous on w->stream) -------------------------------------------------
 int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total,
-               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err) {
+               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true) {
     int rc;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
     if (is_small(s)) {   // minimal preset: one lane per blob does conversion, challenge and evaluation (k_small.hip)
@@ -278,7 +278,7 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
         tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
-        if (d_pts && !is_small(s) && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT) {
+        if (allow_preshift && d_pts && !is_small(s) && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT) {
             // the doubling chains of the linear combination depend on the points alone: walk them now, beside the hash
             if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, n_total / npg)))) return rc;
             tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side);
@@ -1070,8 +1070,8 @@ int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out, int *status, const u
     return msm_op_many_device_impl(out, status, d_blobs, d_commitments, n, s);
 }
 
-int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
-                                       const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
+static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                              const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
     if (!cs || !status) return KZG355_BADARGS;
     for (size_t i = 0; i < groups; i++) status[i] = KZG355_OK;
     if (n_local == 0 || groups == 0) return KZG355_OK;
@@ -1085,7 +1085,8 @@ int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const ui
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
     Timed tm(s, w);
     // any error poisons its batch, as the `?`s at kzg.rs:673-682 do for the call
-    if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, nullptr, w->err.as<int>()))) return rc;
+    // (no window shifts here: stage 2 runs on the gathered batch, on whichever rank gets it)
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, reinterpret_cast<G1Affine *>(d_points), w->err.as<int>(), false))) return rc;
     if ((rc = join_side(w))) return rc;
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
@@ -1098,9 +1099,21 @@ int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const ui
     return first;
 }
 
+int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                       const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
+    return shard_records_impl(d_records, nullptr, status, d_blobs, d_commitments, d_proofs, n_local, groups, cs);
+}
+int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                              const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
+    if (!d_points) return KZG355_BADARGS;
+    return shard_records_impl(d_records, d_points, status, d_blobs, d_commitments, d_proofs, n_local, groups, cs);
+}
+
 namespace {
-// stage 2 over gathered records; `dump` (host, groups*128 bytes or null) receives r | proof_lincomb | rhs per batch
-int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs) {
+// stage 2 over gathered records; `dump` (host, groups*128 bytes or null) receives r | proof_lincomb | rhs per batch; d_points (or
+// null): the validated affine points of the records as stage 1 produced them ([batch][commitments, proofs]), sparing their decompression
+int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs,
+                        const uint8_t *d_points = nullptr) {
     if (!cs || !ok) return KZG355_BADARGS;
     if (groups == 0) return KZG355_OK;
     if (n == 0) return KZG355_BADARGS;                           // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
@@ -1110,7 +1123,8 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     kzg355_settings *s = g.s; Workspace *w = g.w;
     int rc;
     const int G = (int)groups;
-    if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * n * groups))) return rc;
+    if (!d_points && (rc = w->pts.ensure(sizeof(G1Affine) * 2 * n * groups))) return rc;
+    const G1Affine *pts = d_points ? reinterpret_cast<const G1Affine *>(d_points) : w->pts.as<G1Affine>();
     if ((rc = w->err.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->ok.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->h_ok.ensure(sizeof(int) * groups))) return rc;
@@ -1118,14 +1132,16 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     if (dump && ((rc = w->out48.ensure(128 * groups)) || (rc = w->h_out.ensure(128 * groups)))) return rc;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
     Timed tm(s, w);
-    if (validate) {   // full validate_kzg_g1 on C_i / proof_i (decompression + subgroup test) straight from the records
+    if (d_points) {
+        // nothing to decode
+    } else if (validate) {   // full validate_kzg_g1 on C_i / proof_i (decompression + subgroup test) straight from the records
         tm.begin("validate_points");
         launch_validate_points(d_records, d_records + 112, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream, RECORD_BYTES);
         tm.end();
     } else {
         tm.begin("points_from_records"); launch_points_from_records(d_records, (int)(n * groups), (int)n, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
     }
-    if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, validate, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, validate, pts, w->err.as<int>(), w->ok.as<int>()))) return rc;
     if (dump) {
         launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<G1Affine>(), (int)n, G, w->out48.as<uint8_t>(), w->stream);
         HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 128 * groups, hipMemcpyDeviceToHost, w->stream));
@@ -1148,6 +1164,10 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
 
 int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
     return verify_records_impl(ok, status, nullptr, d_records, n, groups, 0, cs);
+}
+int kzg355_verify_records_points_device(bool *ok, int *status, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups, const kzg355_settings *cs) {
+    if (!d_points) return KZG355_BADARGS;
+    return verify_records_impl(ok, status, nullptr, d_records, n, groups, 0, cs, d_points);
 }
 int kzg355_verify_records_checked_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
     return verify_records_impl(ok, status, nullptr, d_records, n, groups, 1, cs);

@@ -7,7 +7,9 @@ combination challenge r, a hash over ALL (C_i, z_i, y_i, proof_i) (utils.rs:454-
 
   stage 1 (per rank, its shard)        -> 160-byte records  C_i | z_i | y_i | proof_i      (no communication)
   ONE all-gather of the records         (torch.distributed; backend "nccl" = RCCL over xGMI; 10 KiB per rank per batch:
-                                         latency-bound, so a single collective and no bandwidth-optimal ring design)
+                                         latency-bound, so a single collective and no bandwidth-optimal ring design); the decoded
+                                         points of the shard (224 bytes per blob) ride in the same buffer, so that stage 2 does not
+                                         take 2n square roots to decompress what stage 1 already decoded
   stage 2 (per rank, its share of the BATCHES: every rank now holds every record) -> r-powers, the linear combinations,
                                          the pairing.  On the GPU stage 2 costs about a third of stage 1, so replicating it on
                                          every rank would cap the scaling; splitting it by batch keeps the work per rank constant.
@@ -23,8 +25,12 @@ RECORD = 160
 BLOB = 131072
 
 
+POINT = 112       # KZG355_BYTES_PER_POINT: one validated affine point as stage 1 leaves it (opaque)
+
+
 class HipEngine:
-    """Stages on the HIP engine; tensors are uint8 CUDA tensors on the settings' device."""
+    """Stages on the HIP engine; tensors are uint8 CUDA tensors on the settings' device.  Stage 1 also hands out the decoded points of
+    its shard and stage 2 takes the gathered ones, so that no rank decompresses (a square root per point) what another rank already has."""
 
     def __init__(self, settings):
         from . import kzg
@@ -34,17 +40,21 @@ class HipEngine:
     def shard_records(self, blobs, commitments, proofs, n_local, groups):
         import torch
         rec = torch.empty(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
+        pts = torch.empty(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
         st = (C.c_int * max(groups, 1))()
-        rc = self.L.kzg355_verify_shard_records_device(rec.data_ptr(), st, blobs.data_ptr(), commitments.data_ptr(), proofs.data_ptr(),
-                                                       n_local, groups, self.s.handle)
+        rc = self.L.kzg355_verify_shard_records_points_device(rec.data_ptr(), pts.data_ptr(), st, blobs.data_ptr(), commitments.data_ptr(), proofs.data_ptr(),
+                                                              n_local, groups, self.s.handle)
         if rc not in (0, 1):
-            raise RuntimeError(f"kzg355_verify_shard_records_device: status {rc}")
-        return rec, [st[i] for i in range(groups)]
+            raise RuntimeError(f"kzg355_verify_shard_records_points_device: status {rc}")
+        return rec, pts, [st[i] for i in range(groups)]
 
-    def verify_records(self, records, n, groups):
+    def verify_records(self, records, points, n, groups):
         ok = (C.c_bool * max(groups, 1))()
         st = (C.c_int * max(groups, 1))()
-        rc = self.L.kzg355_verify_records_device(ok, st, records.data_ptr(), n, groups, self.s.handle)
+        if points is None:
+            rc = self.L.kzg355_verify_records_device(ok, st, records.data_ptr(), n, groups, self.s.handle)
+        else:
+            rc = self.L.kzg355_verify_records_points_device(ok, st, records.data_ptr(), points.data_ptr(), n, groups, self.s.handle)
         if rc not in (0, 1):
             raise RuntimeError(f"kzg355_verify_records_device: status {rc}")
         return [bool(ok[i]) for i in range(groups)], [st[i] for i in range(groups)]
@@ -73,29 +83,37 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if n_local == 0:
         return [True] * groups, [0] * groups                       # kzg.rs:653-655
-    rec, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
+    rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
     if world == 1:
-        ok, st2 = engine.verify_records(rec, n_local, groups)
+        ok, st2 = engine.verify_records(rec, pts, n_local, groups)
         status = [a or b for a, b in zip(st_local, st2)]
         return [o and s == 0 for o, s in zip(ok, status)], status
-    nloc = groups * n_local * RECORD
+    # the ONE data-path collective carries the records and (when the engine has them) the decoded points of the shard
+    nrec = groups * n_local * RECORD
+    npts = 0 if pts is None else groups * 2 * n_local * POINT
+    send = rec if pts is None else torch.cat([rec, pts])
+    nloc = nrec + npts
     rank = dist.get_rank(group)
-    if _on_host(group) and rec.is_cuda:
+    if _on_host(group) and send.is_cuda:
         host = torch.empty(world * nloc, dtype=torch.uint8)
-        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
-        gathered = host.to(rec.device)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        gathered = host.to(send.device)
     else:
-        gathered = torch.empty(world * nloc, dtype=torch.uint8, device=rec.device)
-        dist.all_gather_into_tensor(gathered, rec, group=group)     # the ONE data-path collective
+        gathered = torch.empty(world * nloc, dtype=torch.uint8, device=send.device)
+        dist.all_gather_into_tensor(gathered, send, group=group)
     # this rank's share of the batches: [rank][batch][n_local*160] -> [batch in share][rank][n_local*160]
     g_lo, g_hi = (groups * rank) // world, (groups * (rank + 1)) // world
     code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
     code[:groups] = torch.tensor(st_local, dtype=torch.int32, device=rec.device)
     if g_hi > g_lo:
-        recs = gathered.view(world, groups, n_local * RECORD)[:, g_lo:g_hi, :].permute(1, 0, 2).contiguous().view(-1)
+        per_rank = gathered.view(world, nloc)
+        recs = per_rank[:, :nrec].reshape(world, groups, n_local * RECORD)[:, g_lo:g_hi, :].permute(1, 0, 2).contiguous().view(-1)
+        points = None
+        if pts is not None:     # [rank][batch][C | proofs][n_local] -> [batch in share][C | proofs][rank][n_local]
+            points = per_rank[:, nrec:].reshape(world, groups, 2, n_local * POINT)[:, g_lo:g_hi].permute(1, 2, 0, 3).contiguous().view(-1)
         if rec.is_cuda:
             torch.cuda.synchronize(rec.device)
-        ok, st2 = engine.verify_records(recs, n_local * world, g_hi - g_lo)
+        ok, st2 = engine.verify_records(recs, points, n_local * world, g_hi - g_lo)
         code[groups + g_lo:groups + g_hi] = torch.tensor([1 + int(o) + 256 * int(s) for o, s in zip(ok, st2)], dtype=torch.int32, device=rec.device)
     if _on_host(group) and code.is_cuda:
         code = code.cpu()

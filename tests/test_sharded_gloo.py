@@ -38,9 +38,9 @@ class OracleEngine:
                 st.append(0)
             except OracleError as e:
                 st.append(e.code)
-        return torch.frombuffer(out, dtype=torch.uint8).clone(), st
+        return torch.frombuffer(out, dtype=torch.uint8).clone(), None, st       # (no decoded points: the oracle's stage 2 decodes the records)
 
-    def verify_records(self, records, n, groups):
+    def verify_records(self, records, points, n, groups):
         from oracle.oracle import OracleError
         r = bytes(records.numpy())
         ok, st = [], []
