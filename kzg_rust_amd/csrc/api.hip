@@ -1220,6 +1220,7 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
                 const size_t n_loc = cnt[d], n_tot = n_loc * groups;
                 int rc;
                 if ((rc = w->records.ensure((size_t)RECORD_BYTES * (n_tot ? n_tot : 1)))) return rc;
+                if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * (n_tot ? n_tot : 1)))) return rc;       // the decoded points travel with the records
                 if (n_loc == 0) return KZG355_OK;
                 if ((rc = w->blobs.ensure(BB * n_tot)) || (rc = w->commitments.ensure(48 * n_tot)) || (rc = w->proofs.ensure(48 * n_tot))) return rc;
                 if ((rc = w->err.ensure(sizeof(int) * groups)) || (rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
@@ -1233,7 +1234,7 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
                 HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
                 Timed tm(rs, w);
                 if ((rc = run_stage1(rs, w, tm, w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)n_tot, (int)n_loc,
-                                     w->records.as<uint8_t>(), nullptr, w->err.as<int>()))) return rc;
+                                     w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>(), false))) return rc;
                 if ((rc = join_side(w))) return rc;
                 HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
                 HIPCHK(hipStreamSynchronize(w->stream));
@@ -1295,14 +1296,28 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
                         }
                     }
                 }
-                if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * npg * G))) return rc;
+                // the decoded points of every block, into [batch][commitments of all blocks | proofs of all blocks] (the stage-2 layout)
+                DevBuf &gpts = w->partials;
+                if ((rc = gpts.ensure(sizeof(G1Affine) * 2 * npg * G))) return rc;
+                for (size_t k = 0; k < G; k++) {
+                    const size_t g = mine[k];
+                    for (size_t d = 0; d < D; d++) {
+                        if (!cnt[d]) continue;
+                        for (int half = 0; half < 2; half++) {
+                            G1Affine *dst = gpts.as<G1Affine>() + (k * 2 + half) * npg + off[d];
+                            const G1Affine *src = gs[d]->w->pts.as<G1Affine>() + (g * 2 + half) * cnt[d];
+                            const size_t bytes = sizeof(G1Affine) * cnt[d];
+                            if (gs[d]->s->device == rs->device) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, w->stream));
+                            else HIPCHK(hipMemcpyPeerAsync(dst, rs->device, src, gs[d]->s->device, bytes, w->stream));
+                        }
+                    }
+                }
                 if ((rc = w->err.ensure(sizeof(int) * G)) || (rc = w->ok.ensure(sizeof(int) * G))) return rc;
                 if ((rc = w->h_ok.ensure(sizeof(int) * G)) || (rc = w->h_err.ensure(sizeof(int) * G))) return rc;
                 w->in_flight = true;
                 HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * G, w->stream));
                 Timed tm(rs, w);
-                tm.begin("points_from_records"); launch_points_from_records(gath.as<uint8_t>(), (int)(npg * G), (int)npg, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream); tm.end();
-                if ((rc = run_stage2(rs, w, tm, gath.as<uint8_t>(), (int)npg, (int)G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+                if ((rc = run_stage2(rs, w, tm, gath.as<uint8_t>(), (int)npg, (int)G, 0, gpts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
                 HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
                 HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
                 HIPCHK(hipStreamSynchronize(w->stream));
