@@ -318,12 +318,69 @@ __constant__ uint32_t SHA_K[64] = {
     0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
     0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
     0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+// Many batches: the same transcript hash with one LANE per batch (schedule and rounds in the lane's registers), 64 batches per
+// wave.  The one-wave-per-batch form above keeps 63 lanes idle during the rounds: fine while every wave has a SIMD to itself,
+// 64x the issue slots once the batches outnumber the SIMDs.  Writes the digest words (as fr_from_words takes them) to
+// digests[g][8]; k_rpowers then starts from those.
+__global__ void __launch_bounds__(64) k_rhash_lanes(const uint8_t *records, int n, int groups, uint32_t *digests, int n_fe) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= groups) return;
+    const uint8_t *rec = records + (size_t)RECORD_BYTES * n * g;
+    const uint32_t total_words = 8u + 40u * (uint32_t)n;
+    const uint32_t nblocks = (total_words * 4u + 9u + 63u) / 64u;
+    const uint64_t bits = (uint64_t)total_words * 32u;
+    uint32_t hs[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblocks; b++) {
+        uint32_t w[16];
+        if (b >= 1u && 16u * b + 16u <= total_words) {                  // a block of record bytes only: four 16-byte loads
+            const uint4 *p = reinterpret_cast<const uint4 *>(rec + 64u * (size_t)b - 32u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = p[q];
+                w[4 * q] = bswap32(v.x); w[4 * q + 1] = bswap32(v.y); w[4 * q + 2] = bswap32(v.z); w[4 * q + 3] = bswap32(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t idx = 16u * b + (uint32_t)t;
+                uint32_t v;
+                if (idx < 8u) {
+                    const uint32_t hdr[8] = {0x52434b5au, 0x47424154u, 0x43485f5fu, 0x5f56315fu, 0u, (uint32_t)n_fe, 0u, (uint32_t)n};
+                    v = hdr[idx];
+                } else if (idx < total_words) v = bswap32(reinterpret_cast<const uint32_t *>(rec)[idx - 8u]);
+                else if (idx == total_words) v = 0x80000000u;
+                else if (idx == 16u * nblocks - 2u) v = (uint32_t)(bits >> 32);
+                else if (idx == 16u * nblocks - 1u) v = (uint32_t)bits;
+                else v = 0u;
+                w[t] = v;
+            }
+        }
+        uint32_t a = hs[0], bb = hs[1], c = hs[2], d = hs[3], e = hs[4], f = hs[5], gg = hs[6], h = hs[7];
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            if (t >= 16) {
+                const uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                const uint32_t s0 = xor3(ror(w15, 7), ror(w15, 18), w15 >> 3);
+                const uint32_t s1 = xor3(ror(w2, 17), ror(w2, 19), w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+            }
+            const uint32_t t1 = h + xor3(ror(e, 6), ror(e, 11), ror(e, 25)) + ch3(e, f, gg) + w[t & 15] + SHA_K[t];
+            const uint32_t t2 = xor3(ror(a, 2), ror(a, 13), ror(a, 22)) + maj3(a, bb, c);
+            h = gg; gg = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        hs[0] += a; hs[1] += bb; hs[2] += c; hs[3] += d; hs[4] += e; hs[5] += f; hs[6] += gg; hs[7] += h;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) digests[8 * (size_t)g + k] = hs[7 - k];
+}
+
 // Four batches (waves) per workgroup, one per SIMD of the CU it lands on (one-wave workgroups of long chains are placed
 // unevenly); the waves share nothing: each keeps to its own LDS slice behind wave-local fences.
 #define RP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, int groups, int check_zy, uint32_t *scal_a, uint32_t *scal_b,
-                                                  uint32_t *scal_c, int *err, int n_fe) {
+                                                  uint32_t *scal_c, int *err, int n_fe, int have_digest) {
     __shared__ uint32_t wk_all[4][64][64];           // per wave: [t][block of the chunk]
     __shared__ uint32_t digest_all[4][8];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -335,7 +392,12 @@ __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, 
     uint32_t *digest = digest_all[wid];
     const uint8_t *rec = records + (size_t)RECORD_BYTES * n * g;
     Fr r = fr_one();
-    if (n > 1) {   // for n == 1 only r^0 = 1 is used (the reference takes the single-proof path, kzg.rs:658-660)
+    if (n > 1 && have_digest) {                                        // k_rhash_lanes left the digest where c goes (read here, overwritten at the end)
+        uint32_t dw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dw[k] = scal_c[8 * (size_t)g + k];
+        fr_from_words(r, dw);
+    } else if (n > 1) {   // for n == 1 only r^0 = 1 is used (the reference takes the single-proof path, kzg.rs:658-660)
         const uint32_t total_words = 8u + 40u * (uint32_t)n;            // message length / 4
         const uint32_t nblocks = (total_words * 4u + 9u + 63u) / 64u;
         const uint64_t bits = (uint64_t)total_words * 32u;
@@ -460,7 +522,11 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
     // four waves per workgroup once there are more batches than CUs can take one each (even placement); below that one wave per
     // workgroup: four of these LDS-latency-bound single-lane chains on one CU slow each other down (512-blob batches: 3x)
     const int wpw = groups > 512 ? 4 : 1;
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe);
+    // from two waves per SIMD on, hash with a lane per batch first (k_rhash_lanes)
+    static const int lanes_from = [] { const char *e = getenv("KZG355_RHASH_LANES_FROM"); return e ? atoi(e) : 2048; }();
+    const int lanes = (n_per_group > 1 && groups >= lanes_from) ? 1 : 0;
+    if (lanes) hipLaunchKernelGGL(k_rhash_lanes, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, d_scal_c, n_fe);
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes);
 }
 void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
