@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <sched.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <dlfcn.h>
@@ -78,7 +79,7 @@ struct Workspace {
     // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
     void quiesce() {
         if (in_flight || side_pending) { if (side) hipStreamSynchronize(side); if (stream) hipStreamSynchronize(stream); }
-        in_flight = false; side_pending = false;
+        in_flight = false; side_pending = false; shift_ready = false;
     }
     ~Workspace() {
         for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts}) b->release();
@@ -196,12 +197,27 @@ void ws_release(kzg355_settings *s, Workspace *w) {
     std::lock_guard<std::mutex> lk(s->mu);
     s->pool.push_back(w);
 }
+// Makes `dev` the calling thread's current device and puts the previous one back on scope exit: an entry point of this library
+// leaves the caller's current device as it found it (a host program may be driving other devices from the same thread).
+struct DeviceScope {
+    int prev = -1; bool changed = false;
+    bool enter(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev == dev) return true;
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+        changed = prev >= 0;
+        return true;
+    }
+    void hold() { if (hipGetDevice(&prev) == hipSuccess) changed = true; else (void)hipGetLastError(); }   // put the current device back whatever happens in between
+    ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+};
 struct WsGuard {
     kzg355_settings *s; Workspace *w;
+    DeviceScope scope;
     WsGuard(const kzg355_settings *cs) : s(const_cast<kzg355_settings *>(cs)), w(nullptr) {
-        if (s && hipSetDevice(s->device) == hipSuccess) w = ws_acquire(s);
+        if (s && scope.enter(s->device)) w = ws_acquire(s);
     }
-    ~WsGuard() { if (w) { w->quiesce(); ws_release(s, w); } }
+    ~WsGuard() { if (w) { w->quiesce(); ws_release(s, w); } }     // (scope is destroyed after this body: the device goes back last)
 };
 
 // Optional per-kernel-family timing with HIP events on the launch stream (kzg355_set_kernel_timing).
@@ -263,6 +279,7 @@ int status_from_err(int err) {
 int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total,
                int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true) {
     int rc;
+    w->shift_ready = false;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
     if (is_small(s)) {   // minimal preset: one lane per blob does conversion, challenge and evaluation (k_small.hip)
         tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
@@ -277,6 +294,7 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     if (n_total <= 16384 && ensure_side(s, w)) {
         HIPCHK(hipEventRecord(w->ev_fork, w->stream));
         HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+        w->side_pending = true;                                   // (from here on a failing call has to drain the side stream: quiesce())
         tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
         if (allow_preshift && d_pts && !is_small(s) && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT) {
             // the doubling chains of the linear combination depend on the points alone: walk them now, beside the hash
@@ -301,6 +319,8 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
                int *d_err, int *d_ok) {
     int rc;
     const size_t n_total = (size_t)npg * groups;
+    const bool shift_ready = w->shift_ready;                      // consumed here whatever happens below
+    w->shift_ready = false;
     if ((rc = w->scal_a.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
@@ -311,11 +331,10 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
     if ((rc = join_side(w))) return rc;                           // the validated points (and their shifts) are needed from here on
     if (form == LC_FORM_PRESHIFT) {
-        if (!w->shift_ready) {                                    // entry points without a stage 1 (single proofs, gathered records)
+        if (!shift_ready) {                                       // entry points without a stage 1 (single proofs, gathered records)
             if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, groups)))) return rc;
             tm.begin("lincomb_shift"); launch_lincomb_preshift(d_pts, npg, groups, w->shifts.as<G1Jac>(), w->stream); tm.end();
         }
-        w->shift_ready = false;
         tm.begin("lincomb");
         launch_lincomb_preshifted(d_pts, w->shifts.as<G1Jac>(), w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p,
                                   w->pair_pts.as<G1Affine>(), w->stream);
@@ -403,7 +422,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         return verify_collect(g.w, tm, ok, status, (int)groups);
     }
     std::vector<WsGuard *> gs;
-    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{gs};
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (size_t i = g.size(); i-- > 0;) delete g[i]; } } cleanup{gs};
     std::vector<Timed> tms;
     for (size_t l = 0; l < lanes; l++) {
         gs.push_back(new WsGuard(cs));
@@ -586,7 +605,7 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     // staged copy moves it at link speed (measured 52 GB/s for 8 MiB), one pass over the bytes instead of two
     const bool direct = !s->pinned_ring || (nchunks == 1 && unit_bytes * units <= ((size_t)32 << 20));
     std::vector<WsGuard *> guards;
-    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{guards};
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (size_t i = g.size(); i-- > 0;) delete g[i]; } } cleanup{guards};
     std::vector<Timed> tms;
     for (int i = 0; i < W; i++) {
         guards.push_back(new WsGuard(cs));
@@ -689,8 +708,9 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (dev_or_minus1 >= 0) dev = dev_or_minus1;
     else if (const char *e = getenv("KZG355_DEVICE")) dev = atoi(e);
     else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (dev >= ndev) return KZG355_NO_DEVICE;
-    HIPCHK(hipSetDevice(dev));
+    if (dev < 0 || dev >= ndev) return KZG355_NO_DEVICE;
+    DeviceScope scope;
+    if (!scope.enter(dev)) return KZG355_NO_DEVICE;
     kzg355_settings *s = new kzg355_settings();
     s->device = dev;
     DevBuf g1b, g2b, err;
@@ -885,7 +905,8 @@ struct MultiDev {
     RcclApi rccl;
     std::vector<ncclComm_p> comms;             // one per replica when the RCCL exchange is usable (distinct devices)
     int exchange = 0;                          // 0 peer copies, 1 RCCL all-gather (KZG355_EXCHANGE=peer|rccl; default rccl when available)
-    long n_allgathers = 0, n_peer_exchanges = 0;   // introspection for tests
+    std::mutex ex_mu;                          // collectives on one communicator set are issued by one host thread at a time, in one order on every rank
+    std::atomic<long> n_allgathers{0}, n_peer_exchanges{0};   // introspection for tests
 };
 
 static void free_single(kzg355_settings *s);
@@ -990,7 +1011,8 @@ int kzg355_lagrange_setup_from_monomial(uint8_t *out, const uint8_t *monomial_g1
     if (n < (size_t)SMALL_N_MIN || n > (size_t)SMALL_N_MAX || (n & (n - 1))) return KZG355_BADARGS;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
-    if (const char *e = getenv("KZG355_DEVICE")) HIPCHK(hipSetDevice(atoi(e)));
+    DeviceScope scope;
+    if (const char *e = getenv("KZG355_DEVICE")) { const int dev = atoi(e); if (dev < 0 || dev >= ndev || !scope.enter(dev)) return KZG355_NO_DEVICE; }
     DevBuf in, res, err;
     int rc = KZG355_OK;
     auto done = [&](int code) { in.release(); res.release(); err.release(); return code; };
@@ -1006,7 +1028,8 @@ int kzg355_lagrange_setup_from_monomial(uint8_t *out, const uint8_t *monomial_g1
 
 static void free_single(kzg355_settings *s) {
     if (!s) return;
-    hipSetDevice(s->device);
+    DeviceScope scope;
+    (void)scope.enter(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
     if (s->side_stream) { hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
@@ -1082,6 +1105,7 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     int rc;
     if ((rc = w->err.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
+    w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
     Timed tm(s, w);
     // any error poisons its batch, as the `?`s at kzg.rs:673-682 do for the call
@@ -1090,6 +1114,7 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     if ((rc = join_side(w))) return rc;
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     int first = KZG355_OK;
     for (size_t i = 0; i < groups; i++) {
@@ -1130,6 +1155,7 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     if ((rc = w->h_ok.ensure(sizeof(int) * groups))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * groups))) return rc;
     if (dump && ((rc = w->out48.ensure(128 * groups)) || (rc = w->h_out.ensure(128 * groups)))) return rc;
+    w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * groups, w->stream));
     Timed tm(s, w);
     if (d_points) {
@@ -1149,6 +1175,7 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     if (dump) memcpy(dump, w->h_out.p, 128 * groups);
     int first = KZG355_OK;
@@ -1203,10 +1230,11 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
                          const kzg355_settings *cs) {
     MultiDev *m = cs->multi;
     const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
+    DeviceScope keep; keep.hold();               // this thread visits every replica's device below
     std::vector<size_t> cnt(D), off(D);
     for (size_t d = 0; d < D; d++) { off[d] = npg * d / D; cnt[d] = npg * (d + 1) / D - off[d]; }
     std::vector<WsGuard *> gs(D, nullptr);
-    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (auto *x : g) delete x; } } cleanup{gs};
+    struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (size_t i = g.size(); i-- > 0;) delete g[i]; } } cleanup{gs};
     std::vector<std::vector<int>> st1(D, std::vector<int>(groups, KZG355_OK));
     // stage 1: device d takes blobs [off_d, off_d + cnt_d) of every batch (records in transcript order within the block)
     {
@@ -1258,6 +1286,7 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
             int rc = gs[d]->w->small.ensure(shard_bytes * D);                   // [rank][batch][block] as the collective delivers it
             if (rc) return rc;
         }
+        std::lock_guard<std::mutex> lk(m->ex_mu);
         m->rccl.GroupStart();
         for (size_t d = 0; d < D; d++) {
             hipSetDevice(gs[d]->s->device);
@@ -1497,6 +1526,7 @@ int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uin
     if ((rc = w->z.ensure(sizeof(Fr)))) return rc;
     if ((rc = w->records.ensure(64))) return rc;
     if ((rc = w->h_ok.ensure(64))) return rc;
+    w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
     Timed tm(s, w);
     launch_fr_from_bytes(w->small.as<uint8_t>(), 1, w->z.as<Fr>(), w->err.as<int>(), w->stream);       // kzg.rs:452
@@ -1512,6 +1542,7 @@ int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uin
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->records.p, 32, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
+    w->in_flight = false;
     tm.collect();
     int st = status_from_err(w->h_err.as<int>()[0]);
     if (st == KZG355_OK) { memcpy(proof_out, w->h_out.p, 48); memcpy(y_out, w->h_ok.p, 32); }
