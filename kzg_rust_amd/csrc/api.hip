@@ -39,13 +39,13 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return KZG355_OK;
-        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return KZG355_NO_MEMORY; }
         cap = want;
         return KZG355_OK;
     }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 struct PinBuf {
@@ -53,13 +53,13 @@ struct PinBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return KZG355_OK;
-        if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
         if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return KZG355_NO_MEMORY; }
         cap = want;
         return KZG355_OK;
     }
-    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -78,16 +78,16 @@ struct Workspace {
     bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
     // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
     void quiesce() {
-        if (in_flight || side_pending) { if (side) hipStreamSynchronize(side); if (stream) hipStreamSynchronize(stream); }
+        if (in_flight || side_pending) { if (side) (void)hipStreamSynchronize(side); if (stream) (void)hipStreamSynchronize(stream); }
         in_flight = false; side_pending = false; shift_ready = false;
     }
     ~Workspace() {
         for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release();
-        if (ev_ok) for (auto &e : ev) hipEventDestroy(e);
-        if (ev_fork) hipEventDestroy(ev_fork);
-        if (ev_join) hipEventDestroy(ev_join);
-        if (stream) hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
+        if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream) (void)hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
     }
 };
 
@@ -158,6 +158,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
+    int rhash_lanes_from = 2048;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
     std::mutex mu;
     hipStream_t side_stream = nullptr;   // shared by the workspaces (point validation of small calls next to the hash chain)
@@ -227,11 +228,11 @@ struct Timed {
     // Event pairs are recorded on the stream the kernel is launched on; timing never changes the schedule.
     void begin(const char *name, hipStream_t st = nullptr) {
         if (!s->timing || n + 2 > 32) return;
-        hipEventRecord(w->ev[n], st ? st : w->stream); marks.push_back({name, n}); n++;
+        (void)hipEventRecord(w->ev[n], st ? st : w->stream); marks.push_back({name, n}); n++;
     }
     void end(hipStream_t st = nullptr) {
         if (!s->timing || marks.empty() || n >= 32) return;
-        hipEventRecord(w->ev[n], st ? st : w->stream); n++;
+        (void)hipEventRecord(w->ev[n], st ? st : w->stream); n++;
     }
     void collect() {   // call after the stream has been synchronised
         if (!s->timing) return;
@@ -325,7 +326,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
     if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
-    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe); tm.end();
+    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe, s->rhash_lanes_from); tm.end();
     const int form = lincomb_form(s, npg, groups);
     const bool buckets = form == LC_FORM_BUCKET;
     if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
@@ -630,7 +631,7 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_wait = 0, t_stage = 0, t_enq = 0, t_alloc = 0;
     std::vector<hipEvent_t> dev_ev;                                  // debug only: H2D start / H2D end / kernels end per chunk
-    if (dbg) { dev_ev.resize(3 * nchunks); for (auto &e : dev_ev) hipEventCreate(&e); }
+    if (dbg) { dev_ev.resize(3 * nchunks); for (auto &e : dev_ev) (void)hipEventCreate(&e); }
     const double t_begin = now();
     size_t u0 = 0;
     for (size_t k = 0; k < nchunks; u0 += sizes[k], k++) {
@@ -651,9 +652,9 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
             if ((rc = w->h_stage_cp.ensure(96 * nb))) return rc;
             if ((rc = w->blobs.ensure(BB * nb))) return rc;
             t_alloc += now() - t0; t0 = now();
-            if (dbg) hipEventRecord(dev_ev[3 * k], w->stream);
+            if (dbg) (void)hipEventRecord(dev_ev[3 * k], w->stream);
             if ((rc = stage_via_pinned(s, w, w->h_stage, 0, w->blobs, hc.blobs + BB * off, BB * nb))) return rc;
-            if (dbg) hipEventRecord(dev_ev[3 * k + 1], w->stream);
+            if (dbg) (void)hipEventRecord(dev_ev[3 * k + 1], w->stream);
             if (hc.commitments && (rc = stage_via_pinned(s, w, w->h_stage_cp, 0, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
             if (hc.proofs && (rc = stage_via_pinned(s, w, w->h_stage_cp, 48 * nb, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
         }
@@ -661,7 +662,7 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt);
         else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt);
         if (rc) return rc;
-        if (dbg && !direct) hipEventRecord(dev_ev[3 * k + 2], w->stream);
+        if (dbg && !direct) (void)hipEventRecord(dev_ev[3 * k + 2], w->stream);
         t_enq += now() - t0;
         pend[slot] = Pending{u0, cnt};
     }
@@ -673,13 +674,13 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     if (dbg && !direct) {
         for (size_t k = 0; k < nchunks; k++) {
             float h2d = 0, ker = 0, since = 0;
-            hipEventElapsedTime(&h2d, dev_ev[3 * k], dev_ev[3 * k + 1]); hipEventElapsedTime(&ker, dev_ev[3 * k + 1], dev_ev[3 * k + 2]);
-            hipEventElapsedTime(&since, dev_ev[0], dev_ev[3 * k]);
+            (void)hipEventElapsedTime(&h2d, dev_ev[3 * k], dev_ev[3 * k + 1]); (void)hipEventElapsedTime(&ker, dev_ev[3 * k + 1], dev_ev[3 * k + 2]);
+            (void)hipEventElapsedTime(&since, dev_ev[0], dev_ev[3 * k]);
             fprintf(stderr, "  chunk %zu (%zu units): H2D starts at %.1f ms, takes %.1f ms (%.1f GB/s), kernels %.1f ms\n", k, sizes[k], since, h2d,
                     sizes[k] * unit_bytes / (h2d * 1e6), ker);
         }
-        for (auto &e : dev_ev) hipEventDestroy(e);
     }
+    for (auto &e : dev_ev) (void)hipEventDestroy(e);
     if (dbg) fprintf(stderr, "kzg355 pipe: %zu chunks, W %d: alloc %.1f ms, host copy + H2D enqueue %.1f ms, kernel enqueue %.1f ms, waits in loop %.1f ms, drain %.1f ms, total %.1f ms\n",
                      nchunks, W, t_alloc, t_stage, t_enq, t_wait, now() - t_loop, now() - t_begin);
     return first;
@@ -773,6 +774,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         if (got >= 1 && a >= 1 && a <= 64) s->split_parts = a;
         if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
     }
+    if (const char *e = getenv("KZG355_RHASH_LANES_FROM")) { const int v = atoi(e); if (v >= 1) s->rhash_lanes_from = v; }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
@@ -961,8 +963,8 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
 int kzg355_settings_device_count(const kzg355_settings *s) { return !s ? 0 : s->multi ? (int)s->multi->rep.size() : 1; }
 int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, long *peer_exchanges) {
     if (!s || !allgathers || !peer_exchanges) return KZG355_BADARGS;
-    *allgathers = s->multi ? s->multi->n_allgathers : 0;
-    *peer_exchanges = s->multi ? s->multi->n_peer_exchanges : 0;
+    *allgathers = s->multi ? s->multi->n_allgathers.load() : 0L;
+    *peer_exchanges = s->multi ? s->multi->n_peer_exchanges.load() : 0L;
     return s->multi ? s->multi->exchange : -1;
 }
 
@@ -1032,7 +1034,7 @@ static void free_single(kzg355_settings *s) {
     (void)scope.enter(s->device);
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
-    if (s->side_stream) { hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
+    if (s->side_stream) { (void)hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
     delete s->copy_pool; s->copy_pool = nullptr;
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
@@ -1289,7 +1291,7 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
         std::lock_guard<std::mutex> lk(m->ex_mu);
         m->rccl.GroupStart();
         for (size_t d = 0; d < D; d++) {
-            hipSetDevice(gs[d]->s->device);
+            (void)hipSetDevice(gs[d]->s->device);
             m->rccl.AllGather(gs[d]->w->records.p, gs[d]->w->small.p, shard_bytes, /* ncclUint8 */ 1, m->comms[d], gs[d]->w->stream);
         }
         if (m->rccl.GroupEnd() != 0) return KZG355_NO_DEVICE;

@@ -652,6 +652,12 @@ def lincomb_handles(kz, setup_bytes):
             hs[form] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
         finally:
             del os.environ["KZG355_LINCOMB"]
+    # and one that hashes the r-transcripts one lane per batch whatever the batch count (k_rhash_lanes; by default from 2048 batches on)
+    os.environ["KZG355_RHASH_LANES_FROM"] = "1"
+    try:
+        hs["rhash-lanes"] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_RHASH_LANES_FROM"]
     yield hs
     for h in hs.values():
         h.free()
@@ -704,7 +710,7 @@ def test_stage2_intermediates_match_oracle(kz, settings, lincomb_handles, oracle
     w1 = oracle.verify_batch_intermediates(blobs[:n], cs[:n], ps[:n], oracle_settings)
     w2 = oracle.verify_batch_intermediates(blobs[n:2 * n], cs[n:2 * n], ps[n:2 * n], oracle_settings)
     many = b"".join(rec2 if g % 7 == 3 else rec for g in range(G))
-    for s in (settings, lincomb_handles["bucket"]):
+    for s in (settings, lincomb_handles["bucket"], lincomb_handles["rhash-lanes"]):
         ds = _stage2_dump(kz, s, many, n, G)
         for g in range(G):
             w = w2 if g % 7 == 3 else w1
