@@ -209,90 +209,141 @@ __global__ void __launch_bounds__(64) k_lc_prep(const G1Affine *pts, const uint3
 
 // Lists: per task (= window x class), item | sign << 15 grouped by bucket.  In LDS up to 129 blobs per batch; beyond that
 // (multi-GPU batches of 64 x world blobs) in a global scratch slab of this workgroup -- 2 bytes per addition of ~5,000
-// instructions either way.  Balance: with one list per lane a wave would run as long as its longest list, so the <= 224 lists of
-// a wave are ranked by length and dealt in snake order (lane i takes ranks i, 127 - i, 128 + i, 255 - i): every lane walks about
-// the same number of items.  The bucket sums B[window][b] are NOT weighted here: since
+// instructions either way.  Balance: a wave runs as long as its busiest lane, so the 208 lists of a wave are ranked by length
+// and dealt longest-first to whichever lane has the least to do so far; a lane then walks its lists back to back in ONE loop
+// (per 7-window wave of a 64-blob batch: one list per lane and pass, four passes: 57.6 steps; this: ~42; ideal 40.2).  The bucket
+// sums B[window][b] are NOT weighted here: since
 //   sum_w 32^w sum_b b B[w][b] = sum_b b ( sum_w 32^w B[w][b] ),
 // the Horner kernel runs one chain per bucket index and applies the weights b once per class.
-constexpr int LC_TASKS = 14;                     // 7 windows x 2 classes at most per wave
-constexpr int LC_LDS_LIST = 520;                 // 2 (2 n + 1) entries for n <= 129
+constexpr int LC_TASKS = 13;                     // tasks (window x class) per wave: 26 windows x 2 classes over 4 waves
+constexpr int LC_LDS_LIST = 400;                 // LDS list entries per task: 13 x 400 >= 40 n + 14 entries of a wave for n <= 129
+constexpr int LC_MAX_LISTS = 8;                  // lists one lane may be dealt
 __host__ __device__ inline int lc_list_stride(int n) { return 2 * (2 * n + 1) + 2; }
-__host__ __device__ inline int lc_wave_w0(int wid) { return wid < 2 ? 7 * wid : 14 + 6 * (wid - 2); }       // windows 0-6, 7-13, 14-19, 20-25
-__host__ __device__ inline int lc_wave_nw(int wid) { return wid < 2 ? 7 : 6; }
+// wave wid: class 1 (2 (2n+1) items per window) windows [c1w0, c1w0 + n1), class 0 (2n items) windows [c0w0, c0w0 + 13 - n1):
+// 7 + 6, 7 + 6, 6 + 7, 6 + 7 -- within 5 % of each other in additions (whole windows per wave: 7 against 6, 17 %)
+__host__ __device__ inline int lc_wave_n1(int wid) { return wid < 2 ? 7 : 6; }
+__host__ __device__ inline int lc_wave_c1w0(int wid) { return wid < 2 ? 7 * wid : 14 + 6 * (wid - 2); }
+__host__ __device__ inline int lc_wave_c0w0(int wid) { return wid < 2 ? 6 * wid : 12 + 7 * (wid - 2); }
+// A bucket sum's slot in the scratch: the bucket kernel parks the raw (lazy) accumulator there the moment a list ends and turns it
+// into a canonical Jacobian point -- in place, at the start of the slot -- after its loop; the Horner kernel reads the Jacobian point.
+union LcSlot { G1X raw; G1Jac jac; };
 // One 256-thread workgroup per batch -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see
 // k_pairing.hip), each with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach
 // the same number of times.
-__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, G1Jac *S, uint16_t *glists) {
-    __shared__ uint16_t lists_all[4][LC_TASKS][LC_LDS_LIST];
-    __shared__ int cnt_all[4][LC_TASKS][LC_BUCKETS + 1], start_all[4][LC_TASKS][LC_BUCKETS + 1], cursor_all[4][LC_TASKS][LC_BUCKETS + 1];
+__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, LcSlot *S, uint16_t *glists) {
+    __shared__ uint16_t lists_all[4][LC_TASKS * LC_LDS_LIST];
+    __shared__ int cnt_all[4][LC_TASKS][LC_BUCKETS + 1], cursor_all[4][LC_TASKS][LC_BUCKETS + 1];
     __shared__ uint8_t order_all[4][LC_BUCKETS * LC_TASKS];
+    __shared__ uint8_t seq_all[4][64][LC_MAX_LISTS];
     const int g = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // wave `wid`: its windows of BOTH classes: tasks 0..nw-1 are class 1 (2 (2n+1) items), tasks nw..2nw-1 class 0 (2n items)
-    const int w0 = lc_wave_w0(wid), nw = lc_wave_nw(wid), ntasks = 2 * nw, nlists = LC_BUCKETS * ntasks;
-    uint16_t (*lists_lds)[LC_LDS_LIST] = lists_all[wid];
-    int (*cnt)[LC_BUCKETS + 1] = cnt_all[wid], (*start)[LC_BUCKETS + 1] = start_all[wid], (*cursor)[LC_BUCKETS + 1] = cursor_all[wid];
+    const int n1 = lc_wave_n1(wid), c1w0 = lc_wave_c1w0(wid), c0w0 = lc_wave_c0w0(wid);
+    constexpr int ntasks = LC_TASKS, nlists = LC_BUCKETS * LC_TASKS;
+    int (*cnt)[LC_BUCKETS + 1] = cnt_all[wid], (*cursor)[LC_BUCKETS + 1] = cursor_all[wid];
     uint8_t *order = order_all[wid];
+    uint8_t (*seq)[LC_MAX_LISTS] = seq_all[wid];
     const int ni = lc_items(n);
     const G1Affine *it = items + (size_t)g * ni;
     const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
-    const bool in_lds = lc_list_stride(n) <= LC_LDS_LIST;
-    const int stride = in_lds ? LC_LDS_LIST : lc_list_stride(n);
-    uint16_t *lists = in_lds ? &lists_lds[0][0] : glists + ((size_t)blockIdx.x * 4 + wid) * LC_TASKS * stride;
+    const bool in_lds = 40 * n + 14 <= LC_TASKS * LC_LDS_LIST;
+    // the wave's lists, back to back in the order its lanes walk them (at most 7 * 2 (2n+1) + 6 * 2n = 40 n + 14 entries)
+    uint16_t *lists = in_lds ? lists_all[wid] : glists + ((size_t)blockIdx.x * 4 + wid) * LC_TASKS * lc_list_stride(n);
+    LcSlot *out = S + (size_t)g * 2 * LC_WINDOWS * LC_BUCKETS;      // bucket sums [class][window][bucket - 1]; weighted by the Horner kernel
+    auto task_window = [&](int tk) { return tk < n1 ? c1w0 + tk : c0w0 + (tk - n1); };
+    auto slot_of = [&](int L) { const int tk = L / LC_BUCKETS; return ((tk < n1 ? 1 : 0) * LC_WINDOWS + task_window(tk)) * LC_BUCKETS + (L % LC_BUCKETS); };
+    auto len_of = [&](int L) { return cnt[L / LC_BUCKETS][(L % LC_BUCKETS) + 1]; };
     for (int q = lane; q < (LC_BUCKETS + 1) * LC_TASKS; q += 64) cnt[q / (LC_BUCKETS + 1)][q % (LC_BUCKETS + 1)] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int tk = 0; tk < ntasks; tk++) {
-        const int w = w0 + (tk < nw ? tk : tk - nw), lo = tk < nw ? 2 * n : 0, hi = tk < nw ? ni : 2 * n;      // item range of the task's class (terms t < n are class 0)
+        const int w = task_window(tk), lo = tk < n1 ? 2 * n : 0, hi = tk < n1 ? ni : 2 * n;      // item range of the task's class (terms t < n are class 0)
         for (int j = lo + lane; j < hi; j += 64) { const int d = dg[(size_t)j * LC_DIG_STRIDE + w]; if (d) atomicAdd(&cnt[tk][d < 0 ? -d : d], 1); }
     }
     __syncthreads();
-    if (lane < ntasks) { int run = 0; for (int b = 1; b <= LC_BUCKETS; b++) { start[lane][b] = run; cursor[lane][b] = run; run += cnt[lane][b]; } }
+    // rank the lists by length (ties by index): order[rank] = list; an empty list is the point at infinity
+#pragma unroll 1
+    for (int L = lane; L < nlists; L += 64) {
+        const int len = len_of(L);
+        int rank = 0;
+        for (int M = 0; M < nlists; M++) { const int lm = len_of(M); rank += (lm > len) || (lm == len && M < L); }
+        order[rank] = (uint8_t)L;
+        if (len == 0) out[slot_of(L)].jac = g1_inf();
+    }
+    __syncthreads();
+    // deal: rank i to lane i, then every further list to the least loaded lane (ties: lowest lane)
+    int total = 0, nmine = 0;
+    {
+        const int L = order[lane], len = len_of(L);
+        if (len > 0) { seq[lane][0] = (uint8_t)L; total = len; nmine = 1; }
+    }
+#pragma unroll 1
+    for (int r = 64; r < nlists; r++) {
+        const int L = order[r], len = len_of(L);                 // the same for every lane
+        if (len == 0) break;
+        int key = nmine >= LC_MAX_LISTS ? 0x7fffffff : (total << 6) | lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(key, off); key = v < key ? v : key; }
+        if (lane == (key & 63) && nmine < LC_MAX_LISTS) { seq[lane][nmine++] = (uint8_t)L; total += len; }
+    }
+    int lane_start = total;                           // exclusive prefix sum over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(lane_start, off); if (lane >= off) lane_start += v; }
+    lane_start -= total;
+    {
+        int run = lane_start;
+#pragma unroll 1
+        for (int k = 0; k < nmine; k++) { const int L = seq[lane][k]; cursor[L / LC_BUCKETS][(L % LC_BUCKETS) + 1] = run; run += len_of(L); }
+    }
     __syncthreads();
 #pragma unroll 1
     for (int tk = 0; tk < ntasks; tk++) {
-        const int w = w0 + (tk < nw ? tk : tk - nw), lo = tk < nw ? 2 * n : 0, hi = tk < nw ? ni : 2 * n;
+        const int w = task_window(tk), lo = tk < n1 ? 2 * n : 0, hi = tk < n1 ? ni : 2 * n;
         for (int j = lo + lane; j < hi; j += 64) {
             const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
-            if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[tk * stride + pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
+            if (d) { const int pos = atomicAdd(&cursor[tk][d < 0 ? -d : d], 1); lists[pos] = (uint16_t)(j | (d < 0 ? 0x8000 : 0)); }
         }
-    }
-    // rank the lists by length (ties by index): order[rank] = list
-#pragma unroll 1
-    for (int L = lane; L < nlists; L += 64) {
-        const int len = cnt[L / LC_BUCKETS][(L % LC_BUCKETS) + 1];
-        int rank = 0;
-        for (int M = 0; M < nlists; M++) { const int lm = cnt[M / LC_BUCKETS][(M % LC_BUCKETS) + 1]; rank += (lm > len) || (lm == len && M < L); }
-        order[rank] = (uint8_t)L;
     }
     __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    G1Jac *out = S + (size_t)g * 2 * LC_WINDOWS * LC_BUCKETS;       // bucket sums [class][window][bucket - 1]; weighted by the Horner kernel
-#pragma unroll 1
-    for (int pass = 0; pass < 4; pass++) {           // snake order over the ranked lists
-        const int r = 64 * pass + ((pass & 1) ? 63 - lane : lane);
-        if (r >= nlists) continue;
-        const int L = order[r];
-        const int tk = L / LC_BUCKETS, b = (L % LC_BUCKETS) + 1;
-        const int s0 = start[tk][b], c = cnt[tk][b];
+    int tmax = total, kmax = nmine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(tmax, off), u = __shfl_xor(kmax, off); tmax = v > tmax ? v : tmax; kmax = u > kmax ? u : kmax; }
+    {
         G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
         // the list entry two steps ahead and the point one step ahead are in flight during an addition (with the lists in the
         // global slab each step would otherwise wait for two dependent loads)
-        const uint16_t *lst = lists + tk * stride + s0;
-        auto entry = [&](int q) -> uint32_t { return q < c ? (in_lds ? (uint32_t)lst[q] : (uint32_t)__builtin_nontemporal_load(lst + q)) : 0u; };
+        const uint16_t *lst = lists + lane_start;
+        auto entry = [&](int q) -> uint32_t { return q < total ? (in_lds ? (uint32_t)lst[q] : (uint32_t)__builtin_nontemporal_load(lst + q)) : 0u; };
         uint32_t v0 = entry(0), v1 = entry(1);
         G1Affine pn = it[v0 & 0x7fff];
+        int k = 0, cur = nmine ? (int)seq[lane][0] : 0, end = nmine ? len_of(cur) : 0;      // current list and the position after its last entry
 #pragma unroll 1
-        for (int q = 0; q < c; q++) {
-            G1Affine p = pn;
-            const uint32_t v = v0;
-            v0 = v1; v1 = entry(q + 2);
-            pn = it[v0 & 0x7fff];                    // next point (index 0 when past the end: a harmless in-range load)
-            if (v & 0x8000) fp_neg(p.y, p.y);
-            g1x_add_mixed_lazy(accx, started, p);
+        for (int q = 0; q < tmax; q++) {
+            if (q < total) {
+                G1Affine p = pn;
+                const uint32_t v = v0;
+                v0 = v1; v1 = entry(q + 2);
+                pn = it[v0 & 0x7fff];                // next point (index 0 when past the end: a harmless in-range load)
+                if (v & 0x8000) fp_neg(p.y, p.y);
+                g1x_add_mixed_lazy(accx, started, p);
+                if (q + 1 == end) {                  // the list ends here: park the raw accumulator, start the next list
+                    if (!started) accx = g1x_inf();  // (the items cancelled out: all-zero limbs, which g1x_is_inf sees after canonicalisation)
+                    out[slot_of(cur)].raw = accx;
+                    started = false;
+                    k++;
+                    if (k < nmine) { cur = seq[lane][k]; end += len_of(cur); }
+                }
+            }
         }
-        G1X cx; g1x_from_lazy(cx, accx, started);
+    }
+    // every lane turns the accumulators it parked into canonical Jacobian points, in place
+#pragma unroll 1
+    for (int k = 0; k < kmax; k++) {
+        if (k >= nmine) continue;
+        LcSlot *sl = out + slot_of(seq[lane][k]);
+        G1X raw = sl->raw, cx;
+        g1x_from_lazy(cx, raw, true);
         G1Jac acc; g1x_to_jac(acc, cx);
-        out[((size_t)(tk < nw ? 1 : 0) * LC_WINDOWS + w0 + (tk < nw ? tk : tk - nw)) * LC_BUCKETS + (b - 1)] = acc;
+        sl->jac = acc;
     }
 }
 
@@ -304,18 +355,18 @@ __device__ __forceinline__ G1Jac g1_shfl_down16(const G1Jac &v, int delta) {    
 }
 // 256-thread workgroups: four waves, one per SIMD of the CU the workgroup lands on (64-thread workgroups of this latency-bound chain
 // were placed two to a SIMD while other SIMDs idled: 2.9 instead of 1.9 ms per 2048 batches); the waves share nothing.
-__global__ void __launch_bounds__(256) k_lc_horner(const G1Jac *S, int groups, G1Affine *pair_pts) {
+__global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, G1Affine *pair_pts) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, bucket - 1): 16-lane segments never straddle a wave
     const int lane = threadIdx.x & 63;
     const bool live = id < 2 * LC_BUCKETS * groups;
     const int gc = live ? id / LC_BUCKETS : 0, bi = id % LC_BUCKETS;     // gc = 2 g + class
-    const G1Jac *s = S + (size_t)gc * LC_WINDOWS * LC_BUCKETS;
-    G1Jac acc = live ? s[(size_t)(LC_WINDOWS - 1) * LC_BUCKETS + bi] : g1_inf();
+    const LcSlot *s = S + (size_t)gc * LC_WINDOWS * LC_BUCKETS;
+    G1Jac acc = live ? s[(size_t)(LC_WINDOWS - 1) * LC_BUCKETS + bi].jac : g1_inf();
     // lazy chain (g1.h): no reductions until the end; one doubling body, one addition body
 #pragma unroll 1
     for (int k = LC_BITS * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
         g1_dbl_lazy(acc, acc);
-        if (k % LC_BITS == 0) { G1Jac v = live ? s[(size_t)(k / LC_BITS) * LC_BUCKETS + bi] : g1_inf(); g1_add_lazy(acc, acc, v); }
+        if (k % LC_BITS == 0) { G1Jac v = live ? s[(size_t)(k / LC_BITS) * LC_BUCKETS + bi].jac : g1_inf(); g1_add_lazy(acc, acc, v); }
     }
     g1_canon_lazy(acc, acc);
     // sum_b b * A_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} A_b: 4-step suffix scan over the 16 lanes, 4-step butterfly
@@ -491,7 +542,7 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
-    G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
+    LcSlot *S = reinterpret_cast<LcSlot *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
@@ -501,8 +552,8 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
-    const size_t lists = lc_list_stride(n_per_group) <= LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
-    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(G1Jac) + ni * LC_DIG_STRIDE + 512 + lists;
+    const size_t lists = 40 * (size_t)n_per_group + 14 <= (size_t)LC_TASKS * LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
+    return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(LcSlot) + ni * LC_DIG_STRIDE + 512 + lists;
 }
 bool lincomb_preshift_fits(int n_per_group, int groups) { return n_per_group >= 1 && n_per_group <= PS_MAX_N && groups >= 1 && groups < 64; }
 size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac) * (size_t)ps_points(n_per_group) * LC_WINDOWS * groups; }
@@ -516,7 +567,7 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);          // same scratch layout as the bucket form (lincomb_buckets_scratch_bytes)
-    G1Jac *S = reinterpret_cast<G1Jac *>(items + ni);
+    LcSlot *S = reinterpret_cast<LcSlot *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
     hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
