@@ -158,6 +158,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
+    int lc_chain_from = 2048;      // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM)
     int rhash_lanes_from = 2048;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM)
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
     std::mutex mu;
@@ -344,7 +345,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
         for (int stage = 1; stage <= 3; stage++) {
             if (stage > 1) tm.end();
             tm.begin(names[stage - 1]);
-            launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream, stage);
+            launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream, stage, s->lc_chain_from);
         }
     } else {
         tm.begin("lincomb");
@@ -774,6 +775,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         if (got >= 1 && a >= 1 && a <= 64) s->split_parts = a;
         if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
     }
+    if (const char *e = getenv("KZG355_LC_CHAIN_FROM")) { const int v = atoi(e); if (v >= 1) s->lc_chain_from = v; }
     if (const char *e = getenv("KZG355_RHASH_LANES_FROM")) { const int v = atoi(e); if (v >= 1) s->rhash_lanes_from = v; }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
@@ -781,7 +783,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);
     if (small) launch_setup_small(g1b.as<uint8_t>(), (int)n1, s->t, err.as<int>(), nullptr);
-    launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr);
+    if (launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr)) return fail(KZG355_NO_DEVICE);
     launch_lines_to_w(s->t, nullptr);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_NO_DEVICE);
     int herr = 0;

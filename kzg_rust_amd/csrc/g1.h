@@ -262,6 +262,33 @@ KZG_G1_MID void g1_add_lazy(G1Jac &r, const G1Jac &a, const G1Jac &b) {
     fp_mul_lz(Z3, a.z, b.z); fp_mul_lz(Z3, Z3, H);
     r.x = X3; r.y = Y3; r.z = Z3;
 }
+// The same with BOTH operands lazy (b within the bounds g1_add_lazy leaves: X < 8p, Y < 4p, Z < 2p): b at infinity is then caught
+// by the low-limb filter too, and the rare path canonicalises both operands.
+KZG_G1_MID void g1_add_lazy2(G1Jac &r, const G1Jac &a, const G1Jac &b) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT;
+    Fp Z1Z1, Z2Z2, U1, U2, S1, S2, H, R;
+    fp_sqr_lz(Z1Z1, a.z); fp_sqr_lz(Z2Z2, b.z);
+    fp_mul_lz(U1, a.x, Z2Z2); fp_mul_lz(U2, b.x, Z1Z1);
+    fp_mul_lz(S1, a.y, b.z); fp_mul_lz(S1, S1, Z2Z2);
+    fp_mul_lz(S2, b.y, a.z); fp_mul_lz(S2, S2, Z1Z1);
+    fp_sub_lz(H, U2, U1, m2);                                    // in (0, 4p)
+    fp_sub_lz(R, S2, S1, m2);
+    if (fp_maybe_zero_lz(H) || fp_maybe_zero_lz(a.z) || fp_maybe_zero_lz(b.z)) {      // rare: the complete canonical addition
+        G1Jac c, d; fp_canon64(c.x, a.x); fp_canon64(c.y, a.y); fp_canon64(c.z, a.z); fp_canon64(d.x, b.x); fp_canon64(d.y, b.y); fp_canon64(d.z, b.z);
+        g1_add(r, c, d);
+        return;
+    }
+    Fp HH, HHH, V, t, u;
+    fp_sqr_lz(HH, H); fp_mul_lz(HHH, H, HH); fp_mul_lz(V, U1, HH);
+    Fp X3, Y3, Z3;
+    fp_sqr_lz(X3, R);
+    fp_sub_lz(t, X3, HHH, m2); fp_sub_lz(u, t, V, m2); fp_sub_lz(X3, u, V, m2);        // in (0, 8p)
+    fp_sub_lz(t, V, X3, m8);                                                            // in (0, 10p)
+    fp_mul_lz(Y3, R, t);
+    fp_mul_lz(t, S1, HHH); fp_sub_lz(Y3, Y3, t, m2);                                    // in (0, 4p)
+    fp_mul_lz(Z3, a.z, b.z); fp_mul_lz(Z3, Z3, H);
+    r.x = X3; r.y = Y3; r.z = Z3;
+}
 KZG_HD void g1_canon_lazy(G1Jac &r, const G1Jac &a) { fp_canon64(r.x, a.x); fp_canon64(r.y, a.y); fp_canon64(r.z, a.z); }
 
 // [|x|] P for the BLS parameter |x| = 0xd201000000010000 (weight 6), lazy chain, canonical result.  p canonical.

@@ -385,6 +385,41 @@ __global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, 
     pair_pts[gc] = a;
 }
 
+// Many batches (issue-bound): the 16 chains per class above walk 125 doublings each -- 4000 doublings per batch.  Weighting the
+// buckets first leaves ONE chain per class:
+//   k_lc_wsum    one lane per (batch, class, window):  W = sum_b b B[b]  by running sums (acc += B[b]; W += acc, b = 16 .. 1)
+//   k_lc_hchain  one lane per (batch, class): Horner over the 26 W's (5 doublings + 1 addition each), to affine
+// ~200 k wave instructions per batch instead of ~390 k; the dependent chain is ~20 % longer, so the form above stays for fewer batches.
+__global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups, G1Jac *W) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, window)
+    if (id >= 2 * LC_WINDOWS * groups) return;
+    const LcSlot *s = S + (size_t)id * LC_BUCKETS;
+    G1Jac acc = s[LC_BUCKETS - 1].jac, sum = acc;
+#pragma unroll 1
+    for (int b = LC_BUCKETS - 2; b >= 0; b--) {
+        const G1Jac v = s[b].jac;
+        g1_add_lazy(acc, acc, v);
+        g1_add_lazy2(sum, sum, acc);
+    }
+    G1Jac c; g1_canon_lazy(c, sum);
+    W[id] = c;
+}
+__global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, G1Affine *pair_pts) {
+    const int gc = blockIdx.x * blockDim.x + threadIdx.x;         // 2 g + class
+    if (gc >= 2 * groups) return;
+    const G1Jac *w = W + (size_t)gc * LC_WINDOWS;
+    G1Jac acc = w[LC_WINDOWS - 1];
+#pragma unroll 1
+    for (int k = LC_BITS * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
+        g1_dbl_lazy(acc, acc);
+        if (k % LC_BITS == 0) { const G1Jac v = w[k / LC_BITS]; g1_add_lazy(acc, acc, v); }
+    }
+    G1Jac r; g1_canon_lazy(r, acc);
+    G1Affine a; g1_to_affine(a, r);
+    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[gc] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ lincomb, pre-shifted form
 // Latency form for FEW batches.  The three sums need the batch challenge r, and r needs every y_i, i.e. the whole SHA-256 chain
 // of the blobs (3.7 ms for one batch) -- but the POINTS are inputs.  So while the hash runs, a side-stream kernel walks the
@@ -537,8 +572,13 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
     hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials, d_wtabs);
     hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
 }
+// entries of the global list slab (16-byte aligned count; 0 when the lists fit the LDS)
+static size_t lc_glists_entries(int n_per_group, int groups) {
+    if (40 * (size_t)n_per_group + 14 <= (size_t)LC_TASKS * LC_LDS_LIST) return 0;
+    return (((size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group)) + 7) & ~(size_t)7;
+}
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st, int stage) {
+                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st, int stage, int chain_from) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
@@ -548,11 +588,17 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
     if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists);
-    if (stage == 0 || stage == 3) hipLaunchKernelGGL(k_lc_horner, dim3((2 * LC_BUCKETS * groups + 255) / 256), dim3(256), 0, st, S, groups, d_pair_pts);
+    if (stage == 0 || stage == 3) {
+        if (groups >= chain_from) {
+            G1Jac *W = reinterpret_cast<G1Jac *>(glists + lc_glists_entries(n_per_group, groups));
+            hipLaunchKernelGGL(k_lc_wsum, dim3((2 * LC_WINDOWS * groups + 255) / 256), dim3(256), 0, st, S, groups, W);
+            hipLaunchKernelGGL(k_lc_hchain, dim3((2 * groups + 63) / 64), dim3(64), 0, st, W, groups, d_pair_pts);
+        } else hipLaunchKernelGGL(k_lc_horner, dim3((2 * LC_BUCKETS * groups + 255) / 256), dim3(256), 0, st, S, groups, d_pair_pts);
+    }
 }
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups) {
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
-    const size_t lists = 40 * (size_t)n_per_group + 14 <= (size_t)LC_TASKS * LC_LDS_LIST ? 0 : (size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group) * sizeof(uint16_t);
+    const size_t lists = lc_glists_entries(n_per_group, groups) * sizeof(uint16_t) + (size_t)2 * LC_WINDOWS * groups * sizeof(G1Jac);    // + the window sums W
     return ni * sizeof(G1Affine) + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups * sizeof(LcSlot) + ni * LC_DIG_STRIDE + 512 + lists;
 }
 bool lincomb_preshift_fits(int n_per_group, int groups) { return n_per_group >= 1 && n_per_group <= PS_MAX_N && groups >= 1 && groups < 64; }

@@ -167,14 +167,14 @@ int build_wide_table(DeviceTables t, hipStream_t st) {
     const size_t runs = (size_t)SLAB * N_FE * (ws.rows / WIDE_SEG);
     G1Jac *jac = nullptr; Fp *pre = nullptr;
     if (hipMalloc(&jac, sizeof(G1Jac) * runs * WIDE_SEG) != hipSuccess) return 1;
-    if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { hipFree(jac); return 1; }
+    if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { (void)hipFree(jac); return 1; }
     for (int w = 0; w < ws.windows; w += SLAB) {
         const int wn = w + SLAB <= ws.windows ? SLAB : ws.windows - w;
         hipLaunchKernelGGL(k_wide_base, dim3((wn * N_FE + 63) / 64), dim3(64), 0, st, t.msm_table, t.wide_table, ws, w, wn);
         hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)wn * N_FE * (ws.rows / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, t.wide_table, jac, pre, ws, w, wn);
     }
     const hipError_t e = hipStreamSynchronize(st);
-    hipFree(jac); hipFree(pre);
+    (void)hipFree(jac); (void)hipFree(pre);
     return e == hipSuccess && hipGetLastError() == hipSuccess ? 0 : 1;
 }
 // scalars per lane / window parts for n blobs: one workgroup per blob once the card is full, 32 per blob for a lone blob

@@ -97,9 +97,9 @@ __global__ void __launch_bounds__(64) k_setup_msm_table(G1Affine *table) {
     }
 }
 
-void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTables t, int *d_err, hipStream_t st) {
+int launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTables t, int *d_err, hipStream_t st) {
     G2Affine *d_g2_first2 = nullptr;
-    hipMalloc(&d_g2_first2, 2 * sizeof(G2Affine));
+    if (hipMalloc(&d_g2_first2, 2 * sizeof(G2Affine)) != hipSuccess) { (void)hipGetLastError(); return 1; }
     const bool mainnet = t.n_fe == N_FE;       // small handles: launch_setup_small (k_small.hip) has filled the G1 table and the roots
     if (mainnet) hipLaunchKernelGGL(k_setup_g1, dim3(N_FE / 64), dim3(64), 0, st, d_g1_bytes, t.msm_table, t.g1_first2, d_err);
     hipLaunchKernelGGL(k_setup_g2, dim3(1), dim3(128), 0, st, d_g2_bytes, d_g2_first2, d_err);
@@ -110,8 +110,9 @@ void launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTa
         hipLaunchKernelGGL(k_setup_eval_tab, dim3(N_FE / 4 / 256), dim3(256), 0, st, t.roots, t.eval_tab);
         hipLaunchKernelGGL(k_setup_msm_table, dim3(N_FE / 64), dim3(64), 0, st, t.msm_table);
     }
-    hipStreamSynchronize(st);
-    hipFree(d_g2_first2);
+    const hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(d_g2_first2);
+    return e == hipSuccess ? 0 : 1;
 }
 
 }  // namespace kzg

@@ -652,12 +652,13 @@ def lincomb_handles(kz, setup_bytes):
             hs[form] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
         finally:
             del os.environ["KZG355_LINCOMB"]
-    # and one that hashes the r-transcripts one lane per batch whatever the batch count (k_rhash_lanes; by default from 2048 batches on)
-    os.environ["KZG355_RHASH_LANES_FROM"] = "1"
+    # and one that takes the many-batch kernels whatever the batch count (by default from 2048 batches on): r-transcripts hashed one
+    # lane per batch (k_rhash_lanes), bucket form ending in one Horner chain per class (k_lc_wsum + k_lc_hchain)
+    os.environ["KZG355_RHASH_LANES_FROM"] = "1"; os.environ["KZG355_LC_CHAIN_FROM"] = "1"; os.environ["KZG355_LINCOMB"] = "bucket"
     try:
         hs["rhash-lanes"] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
     finally:
-        del os.environ["KZG355_RHASH_LANES_FROM"]
+        del os.environ["KZG355_RHASH_LANES_FROM"]; del os.environ["KZG355_LC_CHAIN_FROM"]; del os.environ["KZG355_LINCOMB"]
     yield hs
     for h in hs.values():
         h.free()
@@ -704,6 +705,18 @@ def test_stage2_intermediates_match_oracle(kz, settings, lincomb_handles, oracle
         wantb = oracle.verify_batch_intermediates(blobs[:n], cs[:n], bad, oracle_settings)
         d = _stage2_dump(kz, settings, _records_of(kz, settings, blobs[:n], cs[:n], bad), n)[0]
         assert (d["r"], d["proof_lincomb"], d["rhs"], d["ok"]) == (wantb["r"], wantb["proof_lincomb"], wantb["rhs"], False), n
+    # points at infinity among the terms (the zero blob: commitment = proof = infinity, kzg.rs:299-301) and a repeated blob (equal
+    # points meet in one bucket: the doubling case of the accumulation), through every form
+    inf = b"\xc0" + bytes(47)
+    zb = [blobs[0], bytes(131072), blobs[1], blobs[1], bytes(131072), blobs[2], blobs[3], blobs[1], blobs[4]]
+    zc = [cs[0], inf, cs[1], cs[1], inf, cs[2], cs[3], cs[1], cs[4]]
+    zp = [ps[0], inf, ps[1], ps[1], inf, ps[2], ps[3], ps[1], ps[4]]
+    want = oracle.verify_batch_intermediates(zb, zc, zp, oracle_settings)
+    assert want["ok"] is True
+    rec = _records_of(kz, settings, zb, zc, zp)
+    for name, s in [("auto", settings)] + list(lincomb_handles.items()):
+        d = _stage2_dump(kz, s, rec, len(zb))[0]
+        assert (d["r"], d["proof_lincomb"], d["rhs"], d["ok"]) == (want["r"], want["proof_lincomb"], want["rhs"], True), name
     n, G = 6, 520
     rec = _records_of(kz, settings, blobs[:n], cs[:n], ps[:n])
     rec2 = _records_of(kz, settings, blobs[n:2 * n], cs[n:2 * n], ps[n:2 * n])
