@@ -522,7 +522,7 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
     // four waves per workgroup once there are more batches than CUs can take one each (even placement); below that one wave per
     // workgroup: four of these LDS-latency-bound single-lane chains on one CU slow each other down (512-blob batches: 3x)
     const int wpw = groups > 512 ? 4 : 1;
-    // from two waves per SIMD on, hash with a lane per batch first (k_rhash_lanes)
+    // from one wave per SIMD on (lanes_from, default 1024 batches), hash with a lane per batch first (k_rhash_lanes)
     const int lanes = (n_per_group > 1 && groups >= lanes_from) ? 1 : 0;
     if (lanes) hipLaunchKernelGGL(k_rhash_lanes, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, d_scal_c, n_fe);
     hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes);
