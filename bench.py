@@ -5,10 +5,10 @@ Restates benches/kzg_benches.rs:93-126 (criterion group `verify_blob_kzg_proof_b
   * inputs (benches/kzg_benches.rs:7-44): 64 random canonical blobs per batch, honest commitments and proofs made with
     the library itself (untimed setup), so every verification returns true -- asserted for every step;
   * the unit of work is one verify_blob_kzg_proof_batch call over a 64-blob batch (BASELINE.json configs[3]); at N GPUs
-    the batch is 64*N blobs sharded 64 per rank with one all-gather of the 160-byte records (configs[4]);
+    the batch is 64*N blobs sharded 64 per rank with one all-to-all of the 160-byte records (configs[4]);
   * a STEP is one pass of the hot path (one set of kernel launches) over the step's synthetic input: G independent
     64-blob batches (`--batches-per-step G`), submitted together through kzg355_verify_blob_kzg_proof_batch_many_device
-    (or the two stage functions around the all-gather for N > 1).  One 64-blob batch is a chain of latency-bound integer
+    (or the two stage functions around the exchange for N > 1).  One 64-blob batch is a chain of latency-bound integer
     kernels that occupies a handful of the chip's 1024 SIMDs, so whole-job throughput needs many batches in flight;
   * `value` is measured with the inputs resident in HBM when the timed region starts.  The same run also reports, in
     `config.host_inputs`, what the reference's own bench shape gives (host slices through the drop-in C ABI, PCIe H2D
@@ -196,7 +196,7 @@ def main():
             assert rc == 0, rc
             assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
         else:
-            # stage 1 on the local shard -> ONE all-gather of the 160-byte records (RCCL over xGMI) -> stage 2 on this rank's share of the batches
+            # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
             oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
@@ -285,7 +285,7 @@ def main():
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
             "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
-                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-gather of 160-B records"),
+                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-to-all of 160-B records"),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
                        "msm_form": s.msm_form,

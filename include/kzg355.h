@@ -120,7 +120,7 @@ int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int 
                                               size_t n, const kzg355_settings *s);
 
 /* ---- sharded verification (one process per GPU; the exchange between the two stages is the caller's
- *      all-gather of the 160-byte records, e.g. torch.distributed over RCCL) --------------------------- */
+ *      exchange of the 160-byte records, e.g. torch.distributed over RCCL) --------------------------- */
 /* Stage 1, per rank, over its contiguous shard of every batch: `groups` batches, n_local blobs of each (group-major:
  * blob (g, i) at index g*n_local + i).  Validates C_i / proof_i, blob -> field elements, Fiat-Shamir challenge z_i
  * (kzg.rs:298-339), y_i = p_i(z_i) (kzg.rs:346-389).  Writes the records C_i|z_i|y_i|proof_i -- byte for byte the body of
@@ -129,13 +129,13 @@ int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int 
 int kzg355_verify_shard_records_device(uint8_t *d_records /* groups*n_local*160, device */, int *status /* groups, host */,
                                        const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, size_t n_local,
                                        size_t groups, const kzg355_settings *s);
-/* Stage 2, replicated on every rank, over ALL gathered records (device): `groups` batches of n records each
+/* Stage 2 over gathered records (device; every rank its share of the batches, or replicated): `groups` batches of n records each
  * (group-major).  r-powers (utils.rs:426-474), the three linear combinations and the pairing check (kzg.rs:579-627).
  * n == 1 reproduces the single-blob path (kzg.rs:658); n == 0 is an error like kzg.rs:588-592. */
 /* The same two stages with the decoded points travelling next to the records: stage 1 also writes the validated affine points of its
  * shard (d_points: groups x [n_local commitments, n_local proofs] x KZG355_BYTES_PER_POINT opaque bytes), and stage 2 takes the points
  * of the gathered batches (groups x [n commitments, n proofs]) instead of decompressing C_i / proof_i again (a 381-bit square root
- * per point).  The caller gathers both buffers (kzg_rust_amd/sharded.py does it in the same all-gather). */
+ * per point).  The caller exchanges both buffers (kzg_rust_amd/sharded.py: one all-to-all, every rank receives the batches of its share). */
 #define KZG355_BYTES_PER_POINT 112
 int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
                                               const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *s);

@@ -6,11 +6,12 @@ combination challenge r, a hash over ALL (C_i, z_i, y_i, proof_i) (utils.rs:454-
 (kzg.rs:601-625).  So:
 
   stage 1 (per rank, its shard)        -> 160-byte records  C_i | z_i | y_i | proof_i      (no communication)
-  ONE all-gather of the records         (torch.distributed; backend "nccl" = RCCL over xGMI; 10 KiB per rank per batch:
-                                         latency-bound, so a single collective and no bandwidth-optimal ring design); the decoded
-                                         points of the shard (224 bytes per blob) ride in the same buffer, so that stage 2 does not
+  ONE all-to-all of the records          (torch.distributed; backend "nccl" = RCCL over xGMI): stage 2 is split by batch, so rank j
+                                         needs the records of ITS batches only, from every rank -- 1 / world of what an all-gather
+                                         would move, pairwise over the direct links instead of around a ring; the decoded points
+                                         of those records (224 bytes per blob) ride in the same buffer, so that stage 2 does not
                                          take 2n square roots to decompress what stage 1 already decoded
-  stage 2 (per rank, its share of the BATCHES: every rank now holds every record) -> r-powers, the linear combinations,
+  stage 2 (per rank, its share of the BATCHES, now complete) -> r-powers, the linear combinations,
                                          the pairing.  On the GPU stage 2 costs about a third of stage 1, so replicating it on
                                          every rank would cap the scaling; splitting it by batch keeps the work per rank constant.
   ONE all-reduce(MAX) of the per-batch verdict / status words, so every rank returns every verdict and an Err on any rank
@@ -88,32 +89,46 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         ok, st2 = engine.verify_records(rec, pts, n_local, groups)
         status = [a or b for a, b in zip(st_local, st2)]
         return [o and s == 0 for o, s in zip(ok, status)], status
-    # the ONE data-path collective carries the records and (when the engine has them) the decoded points of the shard
-    nrec = groups * n_local * RECORD
-    npts = 0 if pts is None else groups * 2 * n_local * POINT
-    send = rec if pts is None else torch.cat([rec, pts])
-    nloc = nrec + npts
+    # The ONE data-path collective: an all-to-all.  Stage 2 is split by batch, so rank j needs the records (and decoded points) of
+    # the batches in ITS share only, from every rank: rank i sends rank j the slice [g_lo_j, g_hi_j) of its records | points.  An
+    # all-gather would deliver every rank's whole shard to everybody -- world x the bytes, over a ring; here every pair of ranks
+    # exchanges 1 / world of a shard over its own xGMI link (at 8 ranks and 8192 batches per step: 25 MB per link instead of
+    # 1.4 GB around the ring).
     rank = dist.get_rank(group)
+    shares = [((groups * r) // world, (groups * (r + 1)) // world) for r in range(world)]
+    g_lo, g_hi = shares[rank]
+    mine = g_hi - g_lo
+    rec_b = n_local * RECORD                                    # bytes per batch: records, points
+    pts_b = 0 if pts is None else 2 * n_local * POINT
+    rec2 = rec.view(groups, rec_b)
+    pts2 = None if pts is None else pts.view(groups, pts_b)
+    parts = []
+    for lo, hi in shares:
+        parts.append(rec2[lo:hi].reshape(-1))
+        if pts2 is not None:
+            parts.append(pts2[lo:hi].reshape(-1))
+    send = torch.cat(parts)
+    in_splits = [(hi - lo) * (rec_b + pts_b) for lo, hi in shares]
+    out_splits = [mine * (rec_b + pts_b)] * world
     if _on_host(group) and send.is_cuda:
-        host = torch.empty(world * nloc, dtype=torch.uint8)
-        dist.all_gather_into_tensor(host, send.cpu(), group=group)
-        gathered = host.to(send.device)
+        host = torch.empty(sum(out_splits), dtype=torch.uint8)
+        dist.all_to_all_single(host, send.cpu(), out_splits, in_splits, group=group)
+        got = host.to(send.device)
     else:
-        gathered = torch.empty(world * nloc, dtype=torch.uint8, device=send.device)
-        dist.all_gather_into_tensor(gathered, send, group=group)
-    # this rank's share of the batches: [rank][batch][n_local*160] -> [batch in share][rank][n_local*160]
-    g_lo, g_hi = (groups * rank) // world, (groups * (rank + 1)) // world
+        got = torch.empty(sum(out_splits), dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(got, send, out_splits, in_splits, group=group)
     code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
     code[:groups] = torch.tensor(st_local, dtype=torch.int32, device=rec.device)
-    if g_hi > g_lo:
-        per_rank = gathered.view(world, nloc)
-        recs = per_rank[:, :nrec].reshape(world, groups, n_local * RECORD)[:, g_lo:g_hi, :].permute(1, 0, 2).contiguous().view(-1)
+    if mine > 0:
+        per_src = got.view(world, mine * (rec_b + pts_b))          # from rank i: [records of my batches | points of my batches]
+        # [rank][batch][n_local*160] -> [batch][rank][n_local*160]: transcript order (contiguous blocks of blobs per rank)
+        recs = per_src[:, :mine * rec_b].reshape(world, mine, rec_b).permute(1, 0, 2).contiguous().view(-1)
         points = None
-        if pts is not None:     # [rank][batch][C | proofs][n_local] -> [batch in share][C | proofs][rank][n_local]
-            points = per_rank[:, nrec:].reshape(world, groups, 2, n_local * POINT)[:, g_lo:g_hi].permute(1, 2, 0, 3).contiguous().view(-1)
+        if pts is not None:     # [rank][batch][C | proofs][n_local] -> [batch][C | proofs][rank][n_local]
+            points = per_src[:, mine * rec_b:].reshape(world, mine, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
         if rec.is_cuda:
             torch.cuda.synchronize(rec.device)
-        ok, st2 = engine.verify_records(recs, points, n_local * world, g_hi - g_lo)
+        ok, st2 = engine.verify_records(recs, points, n_local * world, mine)
         code[groups + g_lo:groups + g_hi] = torch.tensor([1 + int(o) + 256 * int(s) for o, s in zip(ok, st2)], dtype=torch.int32, device=rec.device)
     if _on_host(group) and code.is_cuda:
         code = code.cpu()

@@ -1,5 +1,5 @@
 """world_size-2 gloo test (CPU) of the sharded verify orchestration in kzg_rust_amd/sharded.py: partitioning, the single
-all-gather of 160-byte records, gather order (= transcript order), status merging.  The compute stages are played by the
+all-to-all of 160-byte records, gather order (= transcript order), status merging.  The compute stages are played by the
 CPU oracle here (test infrastructure); on the GPU box the same driver runs over HipEngine (tests/test_gpu_parity.py and
 bench.py --gpus N)."""
 import os
