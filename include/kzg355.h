@@ -125,7 +125,8 @@ int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int 
  * blob (g, i) at index g*n_local + i).  Validates C_i / proof_i, blob -> field elements, Fiat-Shamir challenge z_i
  * (kzg.rs:298-339), y_i = p_i(z_i) (kzg.rs:346-389).  Writes the records C_i|z_i|y_i|proof_i -- byte for byte the body of
  * the r-transcript (utils.rs:454-463) -- to d_records (device, same indexing), and per-batch status (KZG355_OK or
- * KZG355_BADARGS) to status[g] (host).  Returns the first non-OK status. */
+ * KZG355_BADARGS) to status[g] (host).  Returns the first non-OK status.  Device pointers: d_blobs and d_records 16-byte aligned
+ * (hipMalloc and torch allocations are), else KZG355_BADARGS. */
 int kzg355_verify_shard_records_device(uint8_t *d_records /* groups*n_local*160, device */, int *status /* groups, host */,
                                        const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, size_t n_local,
                                        size_t groups, const kzg355_settings *s);

@@ -405,6 +405,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         return KZG355_OK;
     }
     if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    if (!d_blobs || !d_c || !d_p || ((uintptr_t)d_blobs & 15) || ((uintptr_t)d_c & 3) || ((uintptr_t)d_p & 3)) return KZG355_BADARGS;   // 16-byte loads of the blobs
     // Optional (KZG355_SPLIT=parts[,streams]): cut the call into `parts` launch sets dealt round-robin to `streams` workspaces, so
     // that the narrow kernels of one set (r powers, Horner tail) run under the wide kernels of another.  Measured
     // (profiles/r02/split_sweep.txt): what counts is the SIZE of a launch set -- 2048 batches 3.13 M blobs/s, 4096 3.44 M, 8192
@@ -557,6 +558,7 @@ int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, c
     if (!cs || !out) return KZG355_BADARGS;
     if (n == 0) return KZG355_OK;
     if (n > (size_t)1 << 20) return KZG355_BADARGS;
+    if (!d_blobs || ((uintptr_t)d_blobs & 15) || ((uintptr_t)d_c & 3)) return KZG355_BADARGS;
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     Timed tm(g.s, g.w);
@@ -1103,6 +1105,7 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     for (size_t i = 0; i < groups; i++) status[i] = KZG355_OK;
     if (n_local == 0 || groups == 0) return KZG355_OK;
     if (n_local * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || !d_blobs || ((uintptr_t)d_blobs & 15) || !d_commitments || !d_proofs) return KZG355_BADARGS;
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
@@ -1147,6 +1150,7 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     if (groups == 0) return KZG355_OK;
     if (n == 0) return KZG355_BADARGS;                           // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
     if (n * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3)) return KZG355_BADARGS;      // the kernels read the records 16 bytes at a time
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;

@@ -859,3 +859,21 @@ def test_overlapped_launch_sets_keep_order(kz, setup_bytes, random_set):
         assert [ok[g] for g in range(G) if g != 11] == [g not in (4, 7) for g in range(G) if g != 11]
     finally:
         s.free()
+
+
+def test_device_entry_points_refuse_misaligned_pointers(kz, settings, random_set):
+    """The device-resident entry points read blobs and records 16 bytes at a time: a pointer that is not 16-byte aligned is BadArgs,
+    not a faulting kernel."""
+    import torch
+    blobs, cs, ps = random_set
+    n = len(blobs)
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+    tb = torch.zeros(131072 * n + 64, dtype=torch.uint8, device=dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev); tp = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
+    ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
+    assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr() + 4, tc.data_ptr(), tp.data_ptr(), n, 1, settings.handle) == 1
+    out = C.create_string_buffer(48 * n); sts = (C.c_int * n)()
+    assert L.kzg355_blob_to_kzg_commitment_many_device(out, sts, tb.data_ptr() + 8, n, settings.handle) == 1
+    rec = torch.zeros(160 * n + 64, dtype=torch.uint8, device=dev)
+    assert L.kzg355_verify_records_device(ok, st, rec.data_ptr() + 4, n, 1, settings.handle) == 1
+    assert L.kzg355_verify_shard_records_device(rec.data_ptr() + 2, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 1, settings.handle) == 1
