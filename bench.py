@@ -105,12 +105,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch
     import torch.distributed as dist
+    # Rehearsal hooks for a one-GPU box (never set by the driver): KZG355_BENCH_BACKEND=gloo and KZG355_BENCH_ONE_GPU=1 run the N-rank
+    # code path (sharding, the all-to-all, the status merge, max-over-ranks timing) with every rank on device 0; the line says so.
+    backend = os.environ.get("KZG355_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl" or bool(os.environ.get("KZG355_BENCH_ONE_GPU"))
+    if os.environ.get("KZG355_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("KZG355_DEVICE", str(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import kzg_rust_amd as kz
     from synth import random_blob
     L = kz.kzg.lib()
@@ -230,7 +239,7 @@ def main():
     dt = time.perf_counter() - t0
     s.set_kernel_timing(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -288,7 +297,7 @@ def main():
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-to-all of 160-B records"),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
-                       "msm_form": s.msm_form,
+                       "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
                        "host_inputs": host_inputs},
