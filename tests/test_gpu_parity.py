@@ -877,3 +877,27 @@ def test_device_entry_points_refuse_misaligned_pointers(kz, settings, random_set
     rec = torch.zeros(160 * n + 64, dtype=torch.uint8, device=dev)
     assert L.kzg355_verify_records_device(ok, st, rec.data_ptr() + 4, n, 1, settings.handle) == 1
     assert L.kzg355_verify_shard_records_device(rec.data_ptr() + 2, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 1, settings.handle) == 1
+
+
+def test_many_small_batches_take_the_many_batch_kernels(kz, settings, random_set):
+    """2100 batches of 8 blobs in one launch set: past the thresholds of the lane-per-batch transcript hash (1024) and of the
+    single-chain Horner tail (2048), with short and empty bucket lists (16 items of class 0 over 16 buckets).  Four batches carry two
+    swapped proofs and must be the only false verdicts; one carries an off-curve commitment and must be the only Err."""
+    import torch
+    blobs, cs, ps = random_set
+    n, G = len(blobs), 2100
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+    tb = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev).repeat(G)
+    good_c, good_p = b"".join(cs), b"".join(ps)
+    sw = list(ps); sw[2], sw[5] = sw[5], sw[2]
+    bad_p = b"".join(sw)
+    false_at, err_at = {5, 2047, 2048, 2099}, 1500
+    bad_c = bytearray(good_c); bad_c[48 * 3:48 * 4] = bytes([0x9a]) + b"\xff" * 47        # x >= p: bytes_to_kzg_commitment fails
+    tc = torch.frombuffer(bytearray(b"".join(bytes(bad_c) if g == err_at else good_c for g in range(G))), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(bad_p if g in false_at else good_p for g in range(G))), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    ok = (C.c_bool * G)(); st = (C.c_int * G)()
+    rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle)
+    assert rc == 1
+    assert [g for g in range(G) if st[g] != 0] == [err_at]
+    assert sorted(g for g in range(G) if st[g] == 0 and not ok[g]) == sorted(false_at)
