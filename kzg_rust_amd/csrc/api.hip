@@ -822,8 +822,8 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
 //   sum_i w_i L_i(tau) = tau  =>  the commitment C of the blob (w_0, .., w_{N-1}) is [tau]G1, the polynomial p(X) = X, and with
 //                                 quotient (X - z)/(X - z) = 1 its proof at any z is the generator:  verify_kzg_proof(C, z, z, G) is
 //                                 true, verify_kzg_proof(C, z, z + 1, G) is false.
-// This runs the MSM (table build, kernel, finalize, compression), point validation, the r-power kernel, the per-term lincomb and
-// the cooperative pairing on the device they will run on, and turns a toolchain that miscompiles one of them (DESIGN.md section 4
+// This runs the MSM (table build, kernel, finalize, compression), point validation, the r-power kernel, the linear combination (pre-
+// shifted and bucket forms), the challenge and evaluation kernels and the cooperative pairing on the device they will run on, and turns a toolchain that miscompiles one of them (DESIGN.md section 4
 // records such a case with hipcc 7.2 and four inlined G1 routines) into a load error instead of wrong verdicts.
 static int device_self_test(kzg355_settings *s) {
     static const uint8_t G1_GEN[48] = {0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f, 0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05,
@@ -868,6 +868,29 @@ static int device_self_test(kzg355_settings *s) {
     ok = true;
     rc = kzg355_verify_kzg_proof(&ok, c + 48, z, y_bad, G1_GEN, s);
     if (rc != KZG355_OK || ok) return fail("verify_kzg_proof([tau]G1, z, z + 1, G1) is not false");
+    // The batch path, through the kernels only large launch sets take (bucket-form linear combination with the single-chain tail,
+    // lane-per-batch transcript hash): two batches of 8 copies of the blob of p(X) = X with commitment [tau]G1 and proof G1 (true), the
+    // second one with the proof of its last blob replaced by another valid point (false).
+    {
+        const size_t n = 8, G = 2;
+        DevBuf bb, cc, pp;
+        auto done = [&](int code) { bb.release(); cc.release(); pp.release(); blobs.release(); return code; };
+        if ((rc = bb.ensure(BB * n * G)) || (rc = cc.ensure(48 * n * G)) || (rc = pp.ensure(48 * n * G))) return done(rc);
+        std::vector<uint8_t> hc(48 * n * G), hp(48 * n * G);
+        for (size_t i = 0; i < n * G; i++) { memcpy(&hc[48 * i], c + 48, 48); memcpy(&hp[48 * i], G1_GEN, 48); }
+        memcpy(&hp[48 * (n * G - 1)], c + 48, 48);
+        bool copy_ok = hipMemcpy(cc.p, hc.data(), hc.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pp.p, hp.data(), hp.size(), hipMemcpyHostToDevice) == hipSuccess;
+        for (size_t i = 0; i < n * G && copy_ok; i++) copy_ok = hipMemcpy(bb.as<uint8_t>() + BB * i, blobs.as<uint8_t>() + BB, BB, hipMemcpyDeviceToDevice) == hipSuccess;
+        if (!copy_ok) return done(KZG355_NO_DEVICE);
+        const int keep_mode = s->lincomb_mode, keep_chain = s->lc_chain_from, keep_lanes = s->rhash_lanes_from;
+        s->lincomb_mode = LC_FORM_BUCKET; s->lc_chain_from = 1; s->rhash_lanes_from = 1;
+        bool oks[2] = {false, true}; int sts[2] = {0, 0};
+        rc = verify_many_device_impl(oks, sts, bb.as<uint8_t>(), cc.as<uint8_t>(), pp.as<uint8_t>(), n, G, s);
+        s->lincomb_mode = keep_mode; s->lc_chain_from = keep_chain; s->rhash_lanes_from = keep_lanes;
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return done(rc);
+        bb.release(); cc.release(); pp.release();
+        if (rc != KZG355_OK || !oks[0] || oks[1]) return fail("verify_blob_kzg_proof_batch through the many-batch kernels: expected (true, false)");
+    }
     blobs.release();
     return KZG355_OK;
 }
