@@ -153,11 +153,12 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 // batch; the bucket method shares the doublings:
 //   k_lc_prep     one lane per term: GLV split, signed 5-bit recoding of both halves (25 digits in [-16, 15] and an unsigned top
 //                 digit), the two points P and -phi(P)                             -> items[2(3n+1)], digits[item][26]
-//   k_lc_buckets  one 256-thread workgroup per batch, a wave = 6 or 7 windows of both classes x 16 buckets <= 224 lists: LDS
-//                 counting sort of the class's items by |digit|; the lists are ranked by length and dealt to the lanes in
-//                 snake order                                                       -> bucket sums B[class][window][b]
+//   k_lc_buckets  one 256-thread workgroup per batch, a wave = 13 (window, class) tasks x 16 buckets = 208 lists: LDS counting
+//                 sort of the class's items by |digit|; the lists are ranked by length, dealt longest-first to the least loaded
+//                 lane and walked back to back in one loop                          -> bucket sums B[class][window][b]
 //   k_lc_horner   one lane per (batch, class, b): Horner over the 26 windows (5 doublings + 1 addition each), then the
 //                 weights b over the 16 lanes of a class (suffix scan + butterfly), to affine
+//   k_lc_wsum + k_lc_hchain   the tail for many batches (from 2048 on): window sums weighted first, one Horner chain per class
 // Window width: the bucket kernel's work is (items x windows) additions -- 4-bit digits 11.6 k per 64-blob batch, 5-bit 9.7 k,
 // 6-bit 8.4 k -- while the Horner tail has one chain per bucket index: 16 lanes per class at 5 bits still leave it a
 // latency-bound kernel of ~one wave per SIMD at 2048 batches; at 6 bits it would be as much work as the buckets.
