@@ -901,3 +901,28 @@ def test_many_small_batches_take_the_many_batch_kernels(kz, settings, random_set
     assert rc == 1
     assert [g for g in range(G) if st[g] != 0] == [err_at]
     assert sorted(g for g in range(G) if st[g] == 0 and not ok[g]) == sorted(false_at)
+
+
+def test_sharded_exchange_on_rccl_with_one_rank(kz, settings, random_set):
+    """The collectives of the sharded path on the backend the driver uses (nccl = RCCL) with device tensors: a one-rank process group
+    still goes through torch's all_to_all_single (uneven-split API) and all_reduce(MAX) on the GPU.  Verdicts as the batch call gives."""
+    import torch
+    import torch.distributed as dist
+    from kzg_rust_amd.sharded import HipEngine, verify_blob_kzg_proof_batch_sharded
+    blobs, cs, ps = random_set
+    n = len(blobs) // 2
+    dev = torch.device("cuda", settings.device)
+    bad = list(ps[n:]); bad[0], bad[1] = bad[1], bad[0]
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n] + blobs[n:2 * n] + blobs[:n])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n] + cs[n:2 * n] + cs[:n])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(ps[:n] + bad + ps[:n])), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=dev)
+    try:
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n, 3, HipEngine(settings), force_exchange=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert ok == [True, False, True] and st == [0, 0, 0]
