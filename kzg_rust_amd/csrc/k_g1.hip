@@ -428,14 +428,15 @@ __global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, G1
 // lane, the whole dependent chain of a scalar multiplication).  Once r is known the sums are pure bucket sums with NO doubling
 // left:  sum_items sum_w d_w Q[item][w] = sum_b b (sum of the +-Q with |digit| = b):
 //   k_lc_prep      (as above)  GLV split + signed 5-bit digits of the 2 (3n + 1) half-scalars
-//   k_ps_buckets   one 512-thread workgroup per (batch, class): LDS counting sort of the (item, window) pairs by |digit|; 32 lanes
-//                  per bucket add up their share (~13 Jacobian additions each at n = 64), butterfly over the 32 lanes, then
-//                  the weights b over 16 lanes (suffix scan + butterfly), to affine.
-// ~25 dependent additions after r instead of 125 doublings + 33 additions: 2.0 -> 0.5 ms for one 64-blob batch, and the
+//   k_ps_buckets   four 256-thread workgroups per (batch, class), four buckets each: LDS counting sort of the (item, window)
+//                  pairs of its buckets by |digit|; one wave per bucket adds up its share (~6 Jacobian additions per lane at
+//                  n = 64), butterfly over the 64 lanes                              -> the 16 bucket sums
+//   k_ps_weights   lane per (batch, class, b): the weights b over 16 lanes (suffix scan + butterfly), to affine.
+// ~20 dependent additions after r instead of 125 doublings + 33 additions: 2.0 -> 0.5 ms for one 64-blob batch, and the
 // shifting hides under the hash next to the point validation.  More total work than either other form (every point is doubled
 // 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (fewer than 64 batches of <= 128 blobs; from 64 batches on the bucket form).
 constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
-constexpr int PS_THREADS = 512, PS_LANES_PER_BUCKET = PS_THREADS / LC_BUCKETS;     // 32
+constexpr int PS_THREADS = 256, PS_LANES_PER_BUCKET = 64, PS_BUCKETS_PER_WG = PS_THREADS / PS_LANES_PER_BUCKET, PS_PARTS = LC_BUCKETS / PS_BUCKETS_PER_WG;     // 4 buckets per workgroup, 4 workgroups per (batch, class)
 __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
 // thread (g, pt): Q[w] = 32^w P for w = 0..25, canonical Jacobian.  Point 2n of every batch is -G (the term -[sum r^i y_i] G).
 __global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, int n, int groups, G1Jac *shifts) {
@@ -463,37 +464,40 @@ __device__ __forceinline__ int ps_point_of_item(int j, int n) {
     const int t = j >> 1;
     return t < n ? n + t : t < 2 * n ? n + (t - n) : t < 3 * n ? t - 2 * n : 2 * n;
 }
-__global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const int8_t *digits, int n, G1Affine *pair_pts) {
-    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15, grouped by bucket
-    __shared__ int cnt[LC_BUCKETS + 1], start[LC_BUCKETS + 1], cursor[LC_BUCKETS + 1];
-    __shared__ G1Jac sb[LC_BUCKETS];
-    const int g = blockIdx.x >> 1, cls = blockIdx.x & 1, tid = threadIdx.x;
+// One 256-thread workgroup per (batch, class, quarter of the buckets): 4 buckets x 64 lanes, one wave per SIMD of its CU.  (One
+// 512-thread workgroup per (batch, class) kept all 16 buckets on ONE CU: 8 waves sharing 4 SIMDs through ~26 dependent additions,
+// 0.88 ms for a lone batch; spread over four CUs the same sums take ~13 additions at one wave per SIMD.)  Writes the 16 bucket sums.
+__global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const int8_t *digits, int n, LcSlot *S) {
+    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15, grouped by bucket (this workgroup's buckets only)
+    __shared__ int cnt[PS_BUCKETS_PER_WG + 1], start[PS_BUCKETS_PER_WG + 1], cursor[PS_BUCKETS_PER_WG + 1];
+    const int part = blockIdx.x % PS_PARTS, gc = blockIdx.x / PS_PARTS, g = gc >> 1, cls = gc & 1, tid = threadIdx.x;
+    const int b_lo = part * PS_BUCKETS_PER_WG;                   // this workgroup sums the buckets |digit| = b_lo + 1 .. b_lo + 4
     const int ni = lc_items(n), lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;      // the class's items (terms t < n are class 0)
     const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
     const G1Jac *sh = shifts + (size_t)g * ps_points(n) * LC_WINDOWS;
     const int npairs = (hi - lo) * LC_WINDOWS;
-    if (tid <= LC_BUCKETS) cnt[tid] = 0;
+    if (tid <= PS_BUCKETS_PER_WG) cnt[tid] = 0;
     __syncthreads();
     for (int q = tid; q < npairs; q += PS_THREADS) {
         const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
-        const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
-        if (d) atomicAdd(&cnt[d < 0 ? -d : d], 1);
+        const int d = dg[(size_t)j * LC_DIG_STRIDE + w], k = (d < 0 ? -d : d) - b_lo;
+        if (k >= 1 && k <= PS_BUCKETS_PER_WG) atomicAdd(&cnt[k], 1);
     }
     __syncthreads();
-    if (tid == 0) { int run = 0; for (int b = 1; b <= LC_BUCKETS; b++) { start[b] = run; cursor[b] = run; run += cnt[b]; } }
+    if (tid == 0) { int run = 0; for (int k = 1; k <= PS_BUCKETS_PER_WG; k++) { start[k] = run; cursor[k] = run; run += cnt[k]; } }
     __syncthreads();
     for (int q = tid; q < npairs; q += PS_THREADS) {
         const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
-        const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
-        if (d) { const int pos = atomicAdd(&cursor[d < 0 ? -d : d], 1); list[pos] = (uint16_t)((j - lo) | (w << 10) | (d < 0 ? 0x8000 : 0)); }
+        const int d = dg[(size_t)j * LC_DIG_STRIDE + w], k = (d < 0 ? -d : d) - b_lo;
+        if (k >= 1 && k <= PS_BUCKETS_PER_WG) { const int pos = atomicAdd(&cursor[k], 1); list[pos] = (uint16_t)((j - lo) | (w << 10) | (d < 0 ? 0x8000 : 0)); }
     }
     __syncthreads();
-    // 32 lanes per bucket: lane s takes entries s, s + 32, ... of the bucket's list
-    const int b = tid / PS_LANES_PER_BUCKET + 1, sl = tid % PS_LANES_PER_BUCKET;
+    // 64 lanes (one wave) per bucket: lane s takes entries s, s + 64, ... of the bucket's list
+    const int k = tid / PS_LANES_PER_BUCKET + 1, sl = tid % PS_LANES_PER_BUCKET;
     const uint32_t bc[NFP] = FP_BETA_INIT;
     Fp beta; for (int i = 0; i < NFP; i++) beta.l[i] = bc[i];
     G1Jac acc = g1_inf();
-    const int s0 = start[b], c = cnt[b];
+    const int s0 = start[k], c = cnt[k];
 #pragma unroll 1
     for (int q = sl; q < c; q += PS_LANES_PER_BUCKET) {
         const uint32_t v = list[s0 + q];
@@ -507,23 +511,27 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
     g1_canon_lazy(acc, acc);
 #pragma unroll 1
     for (int off = 1; off < PS_LANES_PER_BUCKET; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
-    if (sl == 0) sb[b - 1] = acc;
-    __syncthreads();
-    if (tid >= 64) return;
-    // sum_b b * S_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} S_b (as in k_lc_horner)
-    G1Jac r = tid < LC_BUCKETS ? sb[tid] : g1_inf();
+    if (sl == 0) S[(size_t)gc * LC_BUCKETS + b_lo + k - 1].jac = acc;
+}
+// The weights of the bucket sums: lane (batch, class, b - 1); sum_b b * S_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} S_b
+// (as in k_lc_horner), to affine.
+__global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, G1Affine *pair_pts) {
+    const int id = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
+    const bool live = id < 2 * LC_BUCKETS * groups;
+    const int gc = live ? id / LC_BUCKETS : 0;
+    G1Jac r = live ? S[id].jac : g1_inf();
 #pragma unroll 1
     for (int off = 1; off < LC_BUCKETS; off <<= 1) {
         G1Jac o = g1_shfl_down16(r, off), t;
         g1_add(t, r, o);
-        if ((tid % LC_BUCKETS) + off < LC_BUCKETS) r = t;
+        if ((lane % LC_BUCKETS) + off < LC_BUCKETS) r = t;
     }
 #pragma unroll 1
     for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
-    if (tid != 0) return;
+    if (!live || id % LC_BUCKETS != 0) return;
     G1Affine a; g1_to_affine(a, r);
-    if (cls == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);            // pairings_verify negates its first G1 argument (utils.rs:198-201)
-    pair_pts[2 * (size_t)g + cls] = a;
+    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    pair_pts[gc] = a;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -618,7 +626,8 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
     hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups), dim3(PS_THREADS), 0, st, d_shifts, digits, n_per_group, d_pair_pts);
+    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * PS_PARTS), dim3(PS_THREADS), 0, st, d_shifts, digits, n_per_group, S);
+    hipLaunchKernelGGL(k_ps_weights, dim3((2 * LC_BUCKETS * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
