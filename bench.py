@@ -199,11 +199,11 @@ def main():
         elif world == 1 and args.host_inputs:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many(ok, stg, h_blobs.ctypes.data_as(C.c_char_p), commitments, proofs, n_local, g, s.handle)
             assert rc == 0, rc
-            assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
+            assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         elif world == 1 and not args.sharded_path:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
             assert rc == 0, rc
-            assert all(ok[i] for i in range(g)), "a verification returned false on honest inputs"
+            assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         else:
             # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
             oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine)

@@ -47,7 +47,7 @@ class HipEngine:
                                                               n_local, groups, self.s.handle)
         if rc not in (0, 1):
             raise RuntimeError(f"kzg355_verify_shard_records_points_device: status {rc}")
-        return rec, pts, [st[i] for i in range(groups)]
+        return rec, pts, _ints(st, groups)
 
     def verify_records(self, records, points, n, groups):
         ok = (C.c_bool * max(groups, 1))()
@@ -58,7 +58,18 @@ class HipEngine:
             rc = self.L.kzg355_verify_records_points_device(ok, st, records.data_ptr(), points.data_ptr(), n, groups, self.s.handle)
         if rc not in (0, 1):
             raise RuntimeError(f"kzg355_verify_records_device: status {rc}")
-        return [bool(ok[i]) for i in range(groups)], [st[i] for i in range(groups)]
+        return _bools(ok, groups), _ints(st, groups)
+
+
+def _ints(c_array, n):
+    """ctypes int array -> numpy (one copy; a Python loop over 8192 ctypes elements costs ~1 ms per step)"""
+    import numpy as np
+    return np.frombuffer(c_array, dtype=np.int32, count=n).copy()
+
+
+def _bools(c_array, n):
+    import numpy as np
+    return np.frombuffer(c_array, dtype=np.uint8, count=n) != 0
 
 
 def partition(n_total, world):
@@ -79,6 +90,7 @@ def _on_host(group):
 def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group=None, force_exchange=False):
     """`groups` independent batches; this rank holds n_local blobs of each (group-major uint8 tensors).
     Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -87,8 +99,9 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
     if world == 1 and not (force_exchange and dist.is_initialized()):      # (force_exchange: run the collectives of a one-rank group too -- test hook)
         ok, st2 = engine.verify_records(rec, pts, n_local, groups)
-        status = [a or b for a, b in zip(st_local, st2)]
-        return [o and s == 0 for o, s in zip(ok, status)], status
+        st1, st2, ok = np.asarray(st_local, dtype=np.int64), np.asarray(st2, dtype=np.int64), np.asarray(ok, dtype=bool)
+        status = np.where(st1 != 0, st1, st2)
+        return (ok & (status == 0)).tolist(), status.tolist()
     # The ONE data-path collective: an all-to-all.  Stage 2 is split by batch, so rank j needs the records (and decoded points) of
     # the batches in ITS share only, from every rank: rank i sends rank j the slice [g_lo_j, g_hi_j) of its records | points.  An
     # all-gather would deliver every rank's whole shard to everybody -- world x the bytes, over a ring; here every pair of ranks
@@ -118,7 +131,7 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         got = torch.empty(sum(out_splits), dtype=torch.uint8, device=send.device)
         dist.all_to_all_single(got, send, out_splits, in_splits, group=group)
     code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
-    code[:groups] = torch.tensor(st_local, dtype=torch.int32, device=rec.device)
+    code[:groups] = torch.from_numpy(np.asarray(st_local, dtype=np.int32)).to(rec.device)
     if mine > 0:
         per_src = got.view(world, mine * (rec_b + pts_b))          # from rank i: [records of my batches | points of my batches]
         # [rank][batch][n_local*160] -> [batch][rank][n_local*160]: transcript order (contiguous blocks of blobs per rank)
@@ -129,10 +142,12 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         if rec.is_cuda:
             torch.cuda.synchronize(rec.device)
         ok, st2 = engine.verify_records(recs, points, n_local * world, mine)
-        code[groups + g_lo:groups + g_hi] = torch.tensor([1 + int(o) + 256 * int(s) for o, s in zip(ok, st2)], dtype=torch.int32, device=rec.device)
+        enc = 1 + np.asarray(ok, dtype=np.int32) + 256 * np.asarray(st2, dtype=np.int32)
+        code[groups + g_lo:groups + g_hi] = torch.from_numpy(enc.astype(np.int32)).to(rec.device)
     if _on_host(group) and code.is_cuda:
         code = code.cpu()
     dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)        # verdicts of every share + status merge, one small collective
-    code = code.tolist()
-    status = [int(code[g]) or (code[groups + g] >> 8) for g in range(groups)]
-    return [((code[groups + g] & 0xFF) == 2) and status[g] == 0 for g in range(groups)], status
+    code = code.cpu().numpy().astype(np.int64)
+    st1, enc = code[:groups], code[groups:]
+    status = np.where(st1 != 0, st1, enc >> 8)
+    return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()
