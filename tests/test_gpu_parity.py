@@ -926,3 +926,41 @@ def test_sharded_exchange_on_rccl_with_one_rank(kz, settings, random_set):
         if created:
             dist.destroy_process_group()
     assert ok == [True, False, True] and st == [0, 0, 0]
+
+
+def test_full_size_launch_set_verdict_positions(kz, settings):
+    """BASELINE.json's measured configuration as ONE launch set: 8192 batches of 64 blobs (524,288 blobs, 69 GB resident).  The batch
+    equation is checked per batch, so the verdict vector is a size-independent property: every batch is true except the three whose
+    proofs were permuted (first, middle, last), and the one with a non-canonical field element in a blob is the only Err."""
+    import torch
+    n, G = 64, 8192
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 90 * 2**30:
+        pytest.skip("needs ~75 GB of free device memory")
+    blobs = [random_blob(31000 + i) for i in range(n)]
+    B = [kz.Blob(b) for b in blobs]
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, settings)
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, settings)
+    cb, pb = [c.to_bytes() for c in cs], [p.to_bytes() for p in ps]
+    base = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    tb = base.repeat(G)
+    tc = torch.frombuffer(bytearray(b"".join(cb)), dtype=torch.uint8).to(dev).repeat(G)
+    good_p = torch.frombuffer(bytearray(b"".join(pb)), dtype=torch.uint8).to(dev)
+    sw = list(pb); sw[7], sw[40] = sw[40], sw[7]
+    bad_p = torch.frombuffer(bytearray(b"".join(sw)), dtype=torch.uint8).to(dev)
+    tp = good_p.repeat(G)
+    false_at, err_at = [0, 4095, 8191], 6000
+    for g in false_at:
+        tp[48 * n * g:48 * n * (g + 1)] = bad_p
+    tb[131072 * (n * err_at + 5) + 32 * 100:131072 * (n * err_at + 5) + 32 * 101] = 0xff       # element 100 of blob 5 of that batch: >= r
+    torch.cuda.synchronize()
+    ok = (C.c_bool * G)(); st = (C.c_int * G)()
+    rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle)
+    assert rc == 1
+    import numpy as np
+    stv = np.frombuffer(st, dtype=np.int32); okv = np.frombuffer(ok, dtype=np.uint8)
+    assert np.flatnonzero(stv).tolist() == [err_at]
+    assert np.flatnonzero((stv == 0) & (okv == 0)).tolist() == false_at
+    del tb, tc, tp
+    torch.cuda.empty_cache()
