@@ -188,6 +188,43 @@ KZG_G1_MID void g1x_to_jac(G1Jac &r, const G1X &a) {
     r.z = a.zz;
 }
 
+// XYZZ + XYZZ on lazy coordinates (add-2008-s, 12M + 2S), both operands within the accumulator invariant above (X < 8p, Y < 4p,
+// ZZ, ZZZ < 2p) and the result within it again:
+//   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1 < 2p;  P = U2 + 2p - U1, R = S2 + 2p - S1 in (0, 4p);  PP, PPP, Q < 2p
+//   X3 = R^2 + (2p - PPP) + 2 (2p - Q) in (0, 8p);  Y3 = R (Q + 8p - X3) + (2p - S1 PPP) in (0, 4p);  ZZ3, ZZZ3 < 2p
+// An operand at infinity (ZZ = 0 mod p) or P possibly = 0 mod p (exact low-limb filters) goes through the canonical Jacobian addition.
+KZG_G1_MID void g1x_add_lazy2(G1X &r, const G1X &a, const G1X &b) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT;
+    Fp U1, U2, S1, S2, ZZ12, ZZZ12, P, R;
+    fp_mul_lz(U1, a.x, b.zz); fp_mul_lz(U2, b.x, a.zz);
+    fp_mul_lz(S1, a.y, b.zzz); fp_mul_lz(S2, b.y, a.zzz);
+    fp_mul_lz(ZZ12, a.zz, b.zz); fp_mul_lz(ZZZ12, a.zzz, b.zzz);     // (the operands are dead from here on)
+    fp_sub_lz(P, U2, U1, m2);
+    fp_sub_lz(R, S2, S1, m2);
+    if (fp_maybe_zero_lz(P) || fp_maybe_zero_lz(a.zz) || fp_maybe_zero_lz(b.zz)) {      // rare: redo canonically
+        G1X ca, cb; g1x_from_lazy(ca, a, true); g1x_from_lazy(cb, b, true);
+        G1Jac ja, jb, jr; g1x_to_jac(ja, ca); g1x_to_jac(jb, cb);
+        g1_add(jr, ja, jb);
+        if (g1_is_inf(jr)) { r = g1x_inf(); return; }
+        r.x = jr.x; r.y = jr.y; fp_sqr(r.zz, jr.z); fp_mul(r.zzz, r.zz, jr.z);
+        return;
+    }
+    Fp PP, PPP, Q, t, u, X3, Y3;
+    fp_sqr_lz(PP, P); fp_mul_lz(PPP, P, PP); fp_mul_lz(Q, U1, PP);
+    fp_sqr_lz(X3, R);
+    fp_sub_lz(t, X3, PPP, m2);                                    // in (0, 4p)
+    fp_sub_lz(u, t, Q, m2);                                       // in (0, 6p)
+    fp_sub_lz(X3, u, Q, m2);                                      // in (0, 8p)
+    fp_sub_lz(t, Q, X3, m8);                                      // in (0, 10p)
+    fp_mul_lz(Y3, R, t);
+    fp_mul_lz(t, S1, PPP);
+    fp_sub_lz(Y3, Y3, t, m2);                                     // in (0, 4p)
+    fp_mul_lz(r.zz, ZZ12, PP);
+    fp_mul_lz(r.zzz, ZZZ12, PPP);
+    r.x = X3; r.y = Y3;
+}
+
+
 KZG_G1_MID void g1_to_affine(G1Affine &r, const G1Jac &a) {
     if (g1_is_inf(a)) { r = g1a_inf(); return; }
     Fp zi, zi2, zi3;

@@ -231,7 +231,7 @@ union LcSlot { G1X raw; G1Jac jac; };
 // One 256-thread workgroup per batch -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see
 // k_pairing.hip), each with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach
 // the same number of times.
-__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, LcSlot *S, uint16_t *glists) {
+__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, LcSlot *S, uint16_t *glists, int keep_raw) {
     __shared__ uint16_t lists_all[4][LC_TASKS * LC_LDS_LIST];
     __shared__ int cnt_all[4][LC_TASKS][LC_BUCKETS + 1], cursor_all[4][LC_TASKS][LC_BUCKETS + 1];
     __shared__ uint8_t order_all[4][LC_BUCKETS * LC_TASKS];
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
         int rank = 0;
         for (int M = 0; M < nlists; M++) { const int lm = len_of(M); rank += (lm > len) || (lm == len && M < L); }
         order[rank] = (uint8_t)L;
-        if (len == 0) out[slot_of(L)].jac = g1_inf();
+        if (len == 0) { if (keep_raw) out[slot_of(L)].raw = g1x_inf(); else out[slot_of(L)].jac = g1_inf(); }
     }
     __syncthreads();
     // deal: rank i to lane i, then every further list to the least loaded lane (ties: lowest lane)
@@ -336,7 +336,9 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
             }
         }
     }
-    // every lane turns the accumulators it parked into canonical Jacobian points, in place
+    // every lane turns the accumulators it parked into canonical Jacobian points, in place -- unless the consumer takes them as they
+    // are (keep_raw: k_lc_wsum adds in the same lazy extended-Jacobian coordinates)
+    if (keep_raw) return;
 #pragma unroll 1
     for (int k = 0; k < kmax; k++) {
         if (k >= nmine) continue;
@@ -394,16 +396,16 @@ __global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, 
 __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups, G1Jac *W) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, window)
     if (id >= 2 * LC_WINDOWS * groups) return;
-    const LcSlot *s = S + (size_t)id * LC_BUCKETS;
-    G1Jac acc = s[LC_BUCKETS - 1].jac, sum = acc;
+    const LcSlot *s = S + (size_t)id * LC_BUCKETS;                // the bucket kernel's raw (lazy extended-Jacobian) sums; all-zero = infinity
+    G1X acc = s[LC_BUCKETS - 1].raw, sum = acc;
 #pragma unroll 1
     for (int b = LC_BUCKETS - 2; b >= 0; b--) {
-        const G1Jac v = s[b].jac;
-        g1_add_lazy(acc, acc, v);
-        g1_add_lazy2(sum, sum, acc);
+        g1x_add_lazy2(acc, acc, s[b].raw);
+        g1x_add_lazy2(sum, sum, acc);
     }
-    G1Jac c; g1_canon_lazy(c, sum);
-    W[id] = c;
+    G1X c; g1x_from_lazy(c, sum, true);
+    G1Jac j; g1x_to_jac(j, c);
+    W[id] = j;
 }
 __global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, G1Affine *pair_pts) {
     const int gc = blockIdx.x * blockDim.x + threadIdx.x;         // 2 g + class
@@ -596,7 +598,7 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
     if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists, groups >= chain_from ? 1 : 0);
     if (stage == 0 || stage == 3) {
         if (groups >= chain_from) {
             G1Jac *W = reinterpret_cast<G1Jac *>(glists + lc_glists_entries(n_per_group, groups));
