@@ -7,6 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# the load-time self-test launches the verify kernels once on 16 blobs: kept out of the per-kernel averages of the profiled runs
+export KZG355_SELFTEST=0
 BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-leg --no-latency"   # every verify launch is a full-size one
 echo "== kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err; echo rc=$?
 echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/fetch.err; echo rc=$?
@@ -22,6 +24,7 @@ for op in commit proof; do
   cd $ROOT; find $OUT/trace_$op -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_${op}_$V.csv \;
 done
 rm -rf $OUT/trace $OUT/trace_commit $OUT/trace_proof      # the raw traces are large; the stats CSVs are what is kept
+unset KZG355_SELFTEST
 echo "== default bench (un-profiled)"; python bench.py > $OUT/bench_default_$V.json 2> $OUT/bench_default.err; echo rc=$?
 echo "== sweep"; python bench.py --sweep > $OUT/bench_sweep_$V.json 2> $OUT/sweep.err; echo rc=$?
 ls -la $OUT
