@@ -28,6 +28,31 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Aff
     if (lane == 0) ok[g] = r ? 1 : 0;
 }
 
+// Few batches (latency): the two Miller loops of a check on TWO waves of one workgroup, each with its own f and only its own pair's
+// line products (two operations per doubling step instead of three), then one product f = f0 f1 and the final exponentiation on
+// wave 0.  68 of ~620 operations off the dependent chain (2.5 -> 2.3 ms for a lone batch) for twice the waves, which idle SIMDs
+// absorb as long as there are few batches.
+__global__ void __launch_bounds__(128) k_pairing_coop2(const G1Affine *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
+                                                       const FrobTables *frob, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
+    __shared__ CoopMem mems[2];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x;
+    CoopMem &m = mems[wid];
+    G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
+    if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
+    if (lines_inf[0]) p2 = g1a_inf();
+    const LineW *lines1 = lines_w + 2 * N_LINES, *lines2 = lines_w;      // lines_w[2] = setup g2[1] = [tau]G2 ; lines_w[0] = G2 generator
+    coop_init(m, scheds, p1, p2);
+    coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && !g1a_is_inf(p1), wid == 1 && !g1a_is_inf(p2), *frob);
+    __syncthreads();                                              // both waves reach this; wave 1 is done afterwards
+    if (wid == 1) return;
+    if (lane < 12) m.t0.c[lane] = mems[1].f.c[lane];
+    COOP_SYNC();
+    coop_product(m, m.sc.mul, m.f, m.f, m.t0, FULL_MASK);
+    coop_run(m, prog, COOP_MILLER_INSNS, n_insn, lines1, lines2, false, false, *frob);
+    const bool r = coop_is_one(m, m.t0);
+    if (lane == 0) ok[g] = r ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, LineW *lines_w, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -37,6 +62,12 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
 
 void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
+    static const int two_wave_upto = [] { const char *e = getenv("KZG355_PAIRING_2W_UPTO"); return e ? atoi(e) : 256; }();
+    if (groups <= two_wave_upto) {          // two waves per batch while that still leaves most SIMDs a single wave
+        hipLaunchKernelGGL(k_pairing_coop2, dim3(groups), dim3(128), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog,
+                           t.pairing_prog_len, t.coop_scheds, d_ok);
+        return;
+    }
     const int wgs = (groups + PAIRING_WAVES - 1) / PAIRING_WAVES;
     // pad the LDS request so that no more than ceil(wgs / 256) workgroups fit on a CU: an even spread by construction
     const int per_cu = (wgs + 255) / 256;

@@ -467,10 +467,15 @@ KZG_HD Fp12W &coop_slot(CoopMem &m, int s) {
     return base[s];
 }
 
-// Interpreter.  p1 / p2 = (0,0) (infinity) makes that pair contribute 1 (its line products are skipped).
-KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,
-                               const LineW *lines2, const G1Affine &p2, const FrobTables &ft) {
-    const bool use1 = !g1a_is_inf(p1), use2 = !g1a_is_inf(p2);
+// number of instructions of the Miller-loop part of the program (everything before the final exponentiation's first CONJ):
+// SET_ONE, then per bit SQR and per line LINE_EVAL + two line products; the conjugation for x < 0 belongs to the tail
+constexpr int COOP_MILLER_INSNS = 1 + 63 + 3 * N_LINES;
+
+// Interpreter, in three pieces so that the two Miller loops of a check can also run on two waves (k_pairing.hip):
+//   coop_init     schedules and the two G1 points into the wave's CoopMem
+//   coop_run      instructions [pc0, pc1); use1 / use2 = false skips that pair's line products (a pair at infinity contributes 1)
+//   coop_is_one   the verdict (slot T0 == 1)
+KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const G1Affine &p1, const G1Affine &p2) {
     COOP_LANES(lane) {
         {   // bring the schedules next to the data (word-wise copy, 64 lanes)
             const uint32_t *src = reinterpret_cast<const uint32_t *>(scheds);
@@ -485,10 +490,13 @@ KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, con
         if (lane < 24) { m.line[lane / 12].c[lane % 12] = fp_zero(); }
     }
     COOP_SYNC();
-    CoopInsn nxt = prog[0];
-    for (int pc = 0; pc < n_insn; pc++) {
+}
+KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const LineW *lines1, const LineW *lines2, bool use1, bool use2, const FrobTables &ft) {
+    if (pc1 <= pc0) return;
+    CoopInsn nxt = prog[pc0];
+    for (int pc = pc0; pc < pc1; pc++) {
         const CoopInsn in = nxt;
-        if (pc + 1 < n_insn) nxt = prog[pc + 1];                 // fetched a whole operation ahead of its use
+        if (pc + 1 < pc1) nxt = prog[pc + 1];                    // fetched a whole operation ahead of its use
         Fp12W &dst = coop_slot(m, in.dst);
         const Fp12W &a = coop_slot(m, in.a);
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
@@ -528,6 +536,12 @@ KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, con
             default: coop_copy(dst, a); break;
         }
     }
+}
+// p1 / p2 = (0,0) (infinity) makes that pair contribute 1.
+KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,
+                               const LineW *lines2, const G1Affine &p2, const FrobTables &ft) {
+    coop_init(m, scheds, p1, p2);
+    coop_run(m, prog, 0, n_insn, lines1, lines2, !g1a_is_inf(p1), !g1a_is_inf(p2), ft);
     return coop_is_one(m, m.t0);
 }
 
