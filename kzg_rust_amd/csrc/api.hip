@@ -326,7 +326,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_a.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
-    if ((rc = w->pair_pts.ensure(sizeof(G1Affine) * 2 * (size_t)groups))) return rc;
+    if ((rc = w->pair_pts.ensure(sizeof(PairPt) * 2 * (size_t)groups))) return rc;
     tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe, s->rhash_lanes_from); tm.end();
     const int form = lincomb_form(s, npg, groups);
     const bool buckets = form == LC_FORM_BUCKET;
@@ -339,22 +339,22 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
         }
         tm.begin("lincomb");
         launch_lincomb_preshifted(d_pts, w->shifts.as<G1Jac>(), w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p,
-                                  w->pair_pts.as<G1Affine>(), w->stream);
+                                  w->pair_pts.as<PairPt>(), w->stream);
     } else if (buckets) {
         static const char *names[3] = {"lincomb_prep", "lincomb", "lincomb_horner"};       // "lincomb" = the bucket kernel itself
         for (int stage = 1; stage <= 3; stage++) {
             if (stage > 1) tm.end();
             tm.begin(names[stage - 1]);
-            launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<G1Affine>(), w->stream, stage, s->lc_chain_from);
+            launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p, w->pair_pts.as<PairPt>(), w->stream, stage, s->lc_chain_from);
         }
     } else {
         tm.begin("lincomb");
-        launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<G1Affine>(), w->stream);
+        launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(), w->pair_pts.as<PairPt>(), w->stream);
     }
     tm.end();
     tm.begin("pairing");
-    if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
-    else launch_pairing(w->pair_pts.as<G1Affine>(), s->t, groups, d_ok, w->stream);
+    if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
+    else launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
     tm.end();
     return KZG355_OK;
 }
@@ -1200,7 +1200,7 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
     }
     if ((rc = run_stage2(s, w, tm, d_records, (int)n, G, validate, pts, w->err.as<int>(), w->ok.as<int>()))) return rc;
     if (dump) {
-        launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<G1Affine>(), (int)n, G, w->out48.as<uint8_t>(), w->stream);
+        launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<PairPt>(), (int)n, G, w->out48.as<uint8_t>(), w->stream);
         HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 128 * groups, hipMemcpyDeviceToHost, w->stream));
     }
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));

@@ -225,11 +225,33 @@ KZG_G1_MID void g1x_add_lazy2(G1X &r, const G1X &a, const G1X &b) {
 }
 
 
+// A G1 argument of the pairing check without the inversion of an affine conversion: (X Z, Y, Z^3) of the Jacobian point.  The line
+// functions are evaluated at x = X / Z^2, y = Y / Z^3 SCALED by Z^3 (l0 Z^3 + l_x (X Z) + l_y Y): a factor in Fp per line, which the
+// final exponentiation kills (p - 1 divides (p^12 - 1) / r).  az = 0: the point at infinity (the pair contributes 1).
+struct PairPt { Fp ax, ay, az; };
+KZG_G1_MID void pairpt_from_jac(PairPt &r, const G1Jac &a, bool negate) {
+    if (g1_is_inf(a)) { r.ax = fp_zero(); r.ay = fp_zero(); r.az = fp_zero(); return; }
+    Fp z2;
+    fp_mul(r.ax, a.x, a.z);
+    fp_sqr(z2, a.z); fp_mul(r.az, z2, a.z);
+    r.ay = a.y;
+    if (negate) fp_neg(r.ay, r.ay);
+}
+KZG_HD void pairpt_from_affine(PairPt &r, const G1Affine &a) {
+    if (g1a_is_inf(a)) { r.ax = fp_zero(); r.ay = fp_zero(); r.az = fp_zero(); return; }
+    r.ax = a.x; r.ay = a.y; r.az = fp_one();
+}
 KZG_G1_MID void g1_to_affine(G1Affine &r, const G1Jac &a) {
     if (g1_is_inf(a)) { r = g1a_inf(); return; }
     Fp zi, zi2, zi3;
     fp_inv(zi, a.z); fp_sqr(zi2, zi); fp_mul(zi3, zi2, zi);
     fp_mul(r.x, a.x, zi2); fp_mul(r.y, a.y, zi3);
+}
+// x = (X Z) / Z^3, y = Y / Z^3
+KZG_G1_MID void pairpt_to_affine(G1Affine &r, const PairPt &a) {
+    if (fp_is_zero(a.az)) { r = g1a_inf(); return; }
+    Fp zi; fp_inv(zi, a.az);
+    fp_mul(r.x, a.ax, zi); fp_mul(r.y, a.ay, zi);
 }
 
 // [k]P, k given as 8 little-endian 32-bit words, processing `nwords` words MSB first (double-and-add).

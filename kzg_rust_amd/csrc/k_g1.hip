@@ -135,15 +135,13 @@ __global__ void __launch_bounds__(64) k_lincomb_terms(const G1Affine *pts, const
     }
 }
 
-__global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, int n, G1Affine *pair_pts) {
+__global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, int n, PairPt *pair_pts) {
     const int wpg = lincomb_waves_per_group(n);
     const int g = blockIdx.x, c = threadIdx.x;
     if (c >= 2) return;
     G1Jac acc = g1_inf();
     for (int wv = 0; wv < wpg; wv++) { G1Jac v = partials[((size_t)g * wpg + wv) * 2 + c]; g1_add(acc, acc, v); }
-    G1Affine a;
-    g1_to_affine(a, acc);
-    if (c == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);          // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    PairPt a; pairpt_from_jac(a, acc, c == 0);                // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[2 * (size_t)g + c] = a;
 }
 
@@ -358,7 +356,7 @@ __device__ __forceinline__ G1Jac g1_shfl_down16(const G1Jac &v, int delta) {    
 }
 // 256-thread workgroups: four waves, one per SIMD of the CU the workgroup lands on (64-thread workgroups of this latency-bound chain
 // were placed two to a SIMD while other SIMDs idled: 2.9 instead of 1.9 ms per 2048 batches); the waves share nothing.
-__global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, G1Affine *pair_pts) {
+__global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, PairPt *pair_pts) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, bucket - 1): 16-lane segments never straddle a wave
     const int lane = threadIdx.x & 63;
     const bool live = id < 2 * LC_BUCKETS * groups;
@@ -383,8 +381,7 @@ __global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, 
 #pragma unroll 1
     for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
     if (!live || bi != 0) return;
-    G1Affine a; g1_to_affine(a, r);
-    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    PairPt a; pairpt_from_jac(a, r, (gc & 1) == 0);               // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[gc] = a;
 }
 
@@ -407,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups,
     G1Jac j; g1x_to_jac(j, c);
     W[id] = j;
 }
-__global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, G1Affine *pair_pts) {
+__global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, PairPt *pair_pts) {
     const int gc = blockIdx.x * blockDim.x + threadIdx.x;         // 2 g + class
     if (gc >= 2 * groups) return;
     const G1Jac *w = W + (size_t)gc * LC_WINDOWS;
@@ -418,8 +415,7 @@ __global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, G1
         if (k % LC_BITS == 0) { const G1Jac v = w[k / LC_BITS]; g1_add_lazy(acc, acc, v); }
     }
     G1Jac r; g1_canon_lazy(r, acc);
-    G1Affine a; g1_to_affine(a, r);
-    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    PairPt a; pairpt_from_jac(a, r, (gc & 1) == 0);               // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[gc] = a;
 }
 
@@ -517,7 +513,7 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
 }
 // The weights of the bucket sums: lane (batch, class, b - 1); sum_b b * S_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} S_b
 // (as in k_lc_horner), to affine.
-__global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, G1Affine *pair_pts) {
+__global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, PairPt *pair_pts) {
     const int id = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
     const bool live = id < 2 * LC_BUCKETS * groups;
     const int gc = live ? id / LC_BUCKETS : 0;
@@ -531,8 +527,7 @@ __global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, 
 #pragma unroll 1
     for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
     if (!live || id % LC_BUCKETS != 0) return;
-    G1Affine a; g1_to_affine(a, r);
-    if ((gc & 1) == 0 && !g1a_is_inf(a)) fp_neg(a.y, a.y);        // pairings_verify negates its first G1 argument (utils.rs:198-201)
+    PairPt a; pairpt_from_jac(a, r, (gc & 1) == 0);               // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[gc] = a;
 }
 
@@ -544,12 +539,12 @@ void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proof
 }
 // Test / audit readback of stage 2 (tests/test_gpu_parity.py): per batch  r (32 bytes big-endian, utils.rs:472) | proof_lincomb (48) |
 // rhs (48), the latter two ZCash-compressed like bytes_from_g1 (utils.rs:221-227).  pair_pts holds -proof_lincomb (utils.rs:198-201).
-__global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_a, const G1Affine *pair_pts, int n, int groups, uint8_t *out) {
+__global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_a, const PairPt *pair_pts, int n, int groups, uint8_t *out) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = id >> 1, which = id & 1;
     if (g >= groups) return;
     uint8_t *o = out + 128 * (size_t)g;
-    G1Affine p = pair_pts[2 * (size_t)g + which];
+    G1Affine p; pairpt_to_affine(p, pair_pts[2 * (size_t)g + which]);
     if (which == 0 && !g1a_is_inf(p)) fp_neg(p.y, p.y);
     uint8_t b[48]; g1_compress_affine(b, p);
     for (int k = 0; k < 48; k++) o[32 + 48 * which + k] = b[k];
@@ -558,7 +553,7 @@ __global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_
         for (int k = 0; k < 8; k++) { const uint32_t v = r[7 - k]; o[4 * k] = (uint8_t)(v >> 24); o[4 * k + 1] = (uint8_t)(v >> 16); o[4 * k + 2] = (uint8_t)(v >> 8); o[4 * k + 3] = (uint8_t)v; }
     }
 }
-void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out, hipStream_t st) {
+void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out, hipStream_t st) {
     if (groups <= 0) return;
     hipLaunchKernelGGL(k_dump_intermediates, dim3((2 * groups + 63) / 64), dim3(64), 0, st, d_scal_a, d_pair_pts, n_per_group, groups, d_out);
 }
@@ -575,7 +570,7 @@ void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per
     hipLaunchKernelGGL(k_points_from_records, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_records, n_total, n_per_group, d_pts, d_err);
 }
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                    int groups, G1Jac *d_partials, G1Affine *d_pair_pts, hipStream_t st) {
+                    int groups, G1Jac *d_partials, PairPt *d_pair_pts, hipStream_t st) {
     if (groups <= 0) return;
     const int wpg = lincomb_waves_per_group(n_per_group);
     // the per-wave window tables follow the partial sums in the same scratch allocation (lincomb_partials_bytes)
@@ -589,7 +584,7 @@ static size_t lc_glists_entries(int n_per_group, int groups) {
     return (((size_t)groups * 4 * LC_TASKS * lc_list_stride(n_per_group)) + 7) & ~(size_t)7;
 }
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                            int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st, int stage, int chain_from) {
+                            int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage, int chain_from) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);
@@ -620,7 +615,7 @@ void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups,
     hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, d_pts, n_per_group, groups, d_shifts);
 }
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                               int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st) {
+                               int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);          // same scratch layout as the bucket form (lincomb_buckets_scratch_bytes)

@@ -11,7 +11,7 @@ namespace kzg {
 // latency-bound kernel gets a SIMD to itself as long as groups <= 1024.  (With one-wave workgroups the placement was left
 // to the dispatcher: 4.1 ms on a good day, 6.1 ms when two waves shared a SIMD -- same wave-cycles, same clocks.)
 constexpr int PAIRING_WAVES = 4;
-__global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Affine *pair_pts, int groups,
+__global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairPt *pair_pts, int groups,
                                                                       const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
                                                                       const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
     __shared__ CoopMem mems[PAIRING_WAVES];
@@ -20,11 +20,12 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Aff
     if (g_raw >= groups) return;                                  // the waves of a workgroup never synchronise with each other
     const int g = g_raw;
     CoopMem &mem = mems[wid];
-    G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
-    if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
-    if (lines_inf[0]) p2 = g1a_inf();
+    const PairPt p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
+    const bool use1 = !fp_is_zero(p1.az) && !lines_inf[2], use2 = !fp_is_zero(p2.az) && !lines_inf[0];      // e(P, infinity) = e(infinity, Q) = 1
     // ML([tau]G2, -proof_lincomb) * ML(G2, rhs): lines_w[2] = setup g2[1] = [tau]G2, lines_w[0] = G2 generator
-    const bool r = coop_pairing_check(mem, prog, n_insn, scheds, lines_w + 2 * N_LINES, p1, lines_w, p2, *frob);
+    coop_init(mem, scheds, p1, p2);
+    coop_run(mem, prog, 0, n_insn, lines_w + 2 * N_LINES, lines_w, use1, use2, *frob);
+    const bool r = coop_is_one(mem, mem.t0);
     if (lane == 0) ok[g] = r ? 1 : 0;
 }
 
@@ -32,17 +33,16 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const G1Aff
 // line products (two operations per doubling step instead of three), then one product f = f0 f1 and the final exponentiation on
 // wave 0.  68 of ~620 operations off the dependent chain (2.5 -> 2.3 ms for a lone batch) for twice the waves, which idle SIMDs
 // absorb as long as there are few batches.
-__global__ void __launch_bounds__(128) k_pairing_coop2(const G1Affine *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
+__global__ void __launch_bounds__(128) k_pairing_coop2(const PairPt *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
                                                        const FrobTables *frob, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
     __shared__ CoopMem mems[2];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x;
     CoopMem &m = mems[wid];
-    G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
-    if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
-    if (lines_inf[0]) p2 = g1a_inf();
+    const PairPt p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
+    const bool use1 = !fp_is_zero(p1.az) && !lines_inf[2], use2 = !fp_is_zero(p2.az) && !lines_inf[0];      // e(P, infinity) = e(infinity, Q) = 1
     const LineW *lines1 = lines_w + 2 * N_LINES, *lines2 = lines_w;      // lines_w[2] = setup g2[1] = [tau]G2 ; lines_w[0] = G2 generator
     coop_init(m, scheds, p1, p2);
-    coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && !g1a_is_inf(p1), wid == 1 && !g1a_is_inf(p2), *frob);
+    coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && use1, wid == 1 && use2, *frob);
     __syncthreads();                                              // both waves reach this; wave 1 is done afterwards
     if (wid == 1) return;
     if (lane < 12) m.t0.c[lane] = mems[1].f.c[lane];
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
     lines_w[i] = o;
 }
 
-void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
     static const int two_wave_upto = [] { const char *e = getenv("KZG355_PAIRING_2W_UPTO"); return e ? atoi(e) : 256; }();
     if (groups <= two_wave_upto) {          // two waves per batch while that still leaves most SIMDs a single wave

@@ -492,10 +492,10 @@ __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, 
 
 // ------------------------------------------------------------------------------------------------ pairing
 // One lane per batch:  ML([tau]G2, -proof_lincomb) * ML(G2, rhs)  ->  final exponentiation  ->  == 1 ?
-__global__ void __launch_bounds__(64) k_pairing(const G1Affine *pair_pts, const LineCoeff *lines, const int *lines_inf, int groups, int *ok) {
+__global__ void __launch_bounds__(64) k_pairing(const PairPt *pair_pts, const LineCoeff *lines, const int *lines_inf, int groups, int *ok) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
-    G1Affine p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
+    G1Affine p1, p2; pairpt_to_affine(p1, pair_pts[2 * (size_t)g]); pairpt_to_affine(p2, pair_pts[2 * (size_t)g + 1]);      // (this A/B kernel works on affine points)
     if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
     if (lines_inf[0]) p2 = g1a_inf();
     Fp12 f;
@@ -527,7 +527,7 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
     if (lanes) hipLaunchKernelGGL(k_rhash_lanes, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, d_scal_c, n_fe);
     hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes);
 }
-void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
+void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;
     hipLaunchKernelGGL(k_pairing, dim3((groups + 63) / 64), dim3(64), 0, st, d_pair_pts, t.lines, t.lines_inf, groups, d_ok);
 }

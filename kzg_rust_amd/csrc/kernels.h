@@ -64,7 +64,7 @@ void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proof
 void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st,
                               int stride = 48);
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st);
-void launch_dump_intermediates(const uint32_t *d_scal_a, const G1Affine *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
+void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
@@ -75,12 +75,12 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
                     uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe = N_FE /* the u64be(FIELD_ELEMENTS_PER_BLOB) field of the transcript */,
                     int lanes_from = 1024 /* batches from which the hash runs one lane per batch (k_rhash_lanes) */);
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                    int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, G1Affine *d_pair_pts /* [group][2] */,
+                    int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, PairPt *d_pair_pts /* [group][2]: -proof_lincomb, rhs */,
                     hipStream_t st);
 size_t lincomb_partials_bytes(int n_per_group, int groups);
 // bucket-method (Pippenger) form of the same sums, for many batches in flight; n_per_group <= 4096 (item indices are 15-bit)
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                            int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, G1Affine *d_pair_pts, hipStream_t st,
+                            int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, PairPt *d_pair_pts, hipStream_t st,
                             int stage = 0 /* 0: all three kernels; 1 prep, 2 buckets, 3 horner (per-kernel timing) */,
                             int chain_from = 2048 /* batches from which the tail is k_lc_wsum + k_lc_hchain instead of k_lc_horner */);
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups);
@@ -90,9 +90,9 @@ bool lincomb_preshift_fits(int n_per_group, int groups);
 size_t lincomb_preshift_bytes(int n_per_group, int groups);
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                               int n_per_group, int groups, void *d_scratch, G1Affine *d_pair_pts, hipStream_t st);
-void launch_pairing(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
-void launch_pairing_lane(const G1Affine *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
+                               int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st);
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
+void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 
 // ---- k_pairing.hip
 void launch_lines_to_w(DeviceTables t, hipStream_t st);

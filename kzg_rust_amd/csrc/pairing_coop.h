@@ -74,7 +74,7 @@ struct CoopMem {
     Fp12W line[2];
     Fp cyc_consts[2];         // 2 (Montgomery form) and 0: entries 12, 13 of the cyclotomic squaring's operand table; must follow line[]
     Fp red[64];               // the reduced partial of every lane (phase 1 -> phase 2)
-    Fp px[2], py[2];
+    Fp px[2], py[2], pz[2];   // the two G1 arguments as (X Z, Y, Z^3) (g1.h: PairPt)
     CoopScheds sc;
     int flag;
 };
@@ -475,7 +475,7 @@ constexpr int COOP_MILLER_INSNS = 1 + 63 + 3 * N_LINES;
 //   coop_init     schedules and the two G1 points into the wave's CoopMem
 //   coop_run      instructions [pc0, pc1); use1 / use2 = false skips that pair's line products (a pair at infinity contributes 1)
 //   coop_is_one   the verdict (slot T0 == 1)
-KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const G1Affine &p1, const G1Affine &p2) {
+KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const PairPt &p1, const PairPt &p2) {
     COOP_LANES(lane) {
         {   // bring the schedules next to the data (word-wise copy, 64 lanes)
             const uint32_t *src = reinterpret_cast<const uint32_t *>(scheds);
@@ -483,7 +483,7 @@ KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const G1Affine &p1, 
             for (int o = lane; o < (int)(sizeof(CoopScheds) / 4); o += 64) dstw[o] = src[o];
         }
         if (lane == 0) {
-            m.px[0] = p1.x; m.py[0] = p1.y; m.px[1] = p2.x; m.py[1] = p2.y;
+            m.px[0] = p1.ax; m.py[0] = p1.ay; m.pz[0] = p1.az; m.px[1] = p2.ax; m.py[1] = p2.ay; m.pz[1] = p2.az;
             Fp two = fp_one(); fp_add(two, two, two);
             m.cyc_consts[0] = two; m.cyc_consts[1] = fp_zero();
         }
@@ -511,19 +511,15 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             case OP_CYC_SQR: coop_cyc_sqr(m, dst, a); break;
             case OP_LINE_EVAL: {
                 const int n = in.a;
-                COOP_LANES(lane) {                          // evaluate both lines at their points: 8 products on 8 lanes
-                    if (lane < 12) {
+                COOP_LANES(lane) {                          // evaluate both lines at their points, scaled by Z^3: 12 products on 12 lanes,
+                    if (lane < 12) {                        // ONE product body for all of them (operands picked per lane, no divergent arms)
                         const int q = lane / 6, e = lane % 6;
                         const LineW &L = q == 0 ? lines1[n] : lines2[n];
-                        Fp v;
-                        switch (e) {
-                            case 0: m.line[q].c[0] = L.l0; break;
-                            case 1: m.line[q].c[6] = L.l6; break;
-                            case 2: fp_mul(v, L.l2, m.px[q]); m.line[q].c[2] = v; break;
-                            case 3: fp_mul(v, L.l8, m.px[q]); m.line[q].c[8] = v; break;
-                            case 4: fp_mul(v, L.l3, m.py[q]); m.line[q].c[3] = v; break;
-                            default: fp_mul(v, L.l9, m.py[q]); m.line[q].c[9] = v; break;
-                        }
+                        const Fp *coef = &L.l0 + e;                                         // l0, l6, l2, l8, l3, l9
+                        const Fp *arg = e < 2 ? &m.pz[q] : e < 4 ? &m.px[q] : &m.py[q];     // * Z^3, Z^3, X Z, X Z, Y, Y
+                        const int dst_k = e == 0 ? 0 : e == 1 ? 6 : e == 2 ? 2 : e == 3 ? 8 : e == 4 ? 3 : 9;
+                        Fp v; fp_mul(v, *coef, *arg);
+                        m.line[q].c[dst_k] = v;
                     }
                 }
                 COOP_SYNC();
@@ -540,7 +536,8 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
 // p1 / p2 = (0,0) (infinity) makes that pair contribute 1.
 KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,
                                const LineW *lines2, const G1Affine &p2, const FrobTables &ft) {
-    coop_init(m, scheds, p1, p2);
+    PairPt q1, q2; pairpt_from_affine(q1, p1); pairpt_from_affine(q2, p2);
+    coop_init(m, scheds, q1, q2);
     coop_run(m, prog, 0, n_insn, lines1, lines2, !g1a_is_inf(p1), !g1a_is_inf(p2), ft);
     return coop_is_one(m, m.t0);
 }
