@@ -200,5 +200,61 @@ int hd_pairings_verify_coop(int *ok, const uint8_t *p1, const uint8_t *q1, const
     delete mem;
     return 0;
 }
+// The same check the way the kernels run it since the G1 arguments became projective: the points lifted to Jacobian coordinates with
+// z = zsel + 2, turned into (X Z, Y, Z^3) (pairpt_from_jac), the Miller loops as two separate runs of the program's prefix (one pair
+// each, as the two waves of k_pairing_coop2 do), one product, then the rest of the program.
+int hd_pairings_verify_coop_proj(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2, int zsel) {
+    G1Affine a, b; G2Affine qa, qb;
+    if (g1_decompress(a, p1) || g1_decompress(b, p2) || g2_decompress(qa, q1) || g2_decompress(qb, q2)) return 1;
+    std::vector<LineCoeff> l1(N_LINES), l2(N_LINES);
+    std::vector<LineW> w1(N_LINES), w2(N_LINES);
+    if (!g2a_is_inf(qa)) precompute_lines(l1.data(), qa);
+    if (!g2a_is_inf(qb)) precompute_lines(l2.data(), qb);
+    for (int i = 0; i < N_LINES; i++) { line_to_w(w1[i], l1[i]); line_to_w(w2[i], l2[i]); }
+    auto lift = [&](PairPt &o, const G1Affine &p, bool negate) {
+        G1Jac j; g1_from_affine(j, p);
+        if (!g1_is_inf(j)) {
+            Fp z = fp_one(); for (int k = 0; k < zsel + 1; k++) fp_add(z, z, fp_one());
+            Fp z2, z3; fp_sqr(z2, z); fp_mul(z3, z2, z); fp_mul(j.x, j.x, z2); fp_mul(j.y, j.y, z3); j.z = z;
+        }
+        pairpt_from_jac(o, j, negate);
+    };
+    PairPt pa, pb; lift(pa, a, true); lift(pb, b, false);
+    const bool use1 = !fp_is_zero(pa.az) && !g2a_is_inf(qa), use2 = !fp_is_zero(pb.az) && !g2a_is_inf(qb);
+    static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
+    FrobTables ft;
+    for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
+    CoopMem *m0 = new CoopMem(), *m1 = new CoopMem();
+    static CoopInsn prog[COOP_PROGRAM_MAX];
+    const int n_insn = build_pairing_program(prog);
+    if (n_insn > COOP_PROGRAM_MAX) return 2;
+    static CoopScheds sc;
+    if (!build_coop_schedules(sc)) return 3;
+    coop_init(*m0, &sc, pa, pb); coop_init(*m1, &sc, pa, pb);
+    coop_run(*m0, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), use1, false, ft);
+    coop_run(*m1, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), false, use2, ft);
+    for (int k = 0; k < 12; k++) m0->t0.c[k] = m1->f.c[k];
+    coop_product(*m0, m0->sc.mul, m0->f, m0->f, m0->t0, FULL_MASK);
+    coop_run(*m0, prog, COOP_MILLER_INSNS, n_insn, w1.data(), w2.data(), false, false, ft);
+    *ok = coop_is_one(*m0, m0->t0) ? 1 : 0;
+    delete m0; delete m1;
+    return 0;
+}
+// W = sum_b b * B_b over 16 buckets the way k_lc_wsum does it: every bucket sum B_b = P_{2(b-1)} + P_{2(b-1)+1} accumulated in lazy
+// extended-Jacobian coordinates (g1x_add_mixed_lazy), then acc += B_b; W += acc for b = 16 .. 1 with the lazy XYZZ + XYZZ addition.
+int hd_weighted_bucket_sum(uint8_t *out, const uint8_t *pts48 /* 32 points */) {
+    G1X B[16];
+    for (int b = 0; b < 16; b++) {
+        G1X acc = g1x_inf(); bool started = false;
+        for (int k = 0; k < 2; k++) { G1Affine p; if (g1_decompress(p, pts48 + 48 * (2 * b + k))) return 1; g1x_add_mixed_lazy(acc, started, p); }
+        if (!started) acc = g1x_inf();
+        B[b] = acc;                                              // raw, as the bucket kernel parks it (all-zero = infinity)
+    }
+    G1X acc = B[15], sum = acc;
+    for (int b = 14; b >= 0; b--) { g1x_add_lazy2(acc, acc, B[b]); g1x_add_lazy2(sum, sum, acc); }
+    G1X c; g1x_from_lazy(c, sum, true);
+    G1Jac j; g1x_to_jac(j, c);
+    G1Affine a; g1_to_affine(a, j); g1_compress_affine(out, a); return 0;
+}
 void hd_sha256(uint8_t *out, const uint8_t *msg, uint64_t len) { sha256_bytes(out, msg, len); }
 }

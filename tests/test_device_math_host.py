@@ -285,3 +285,52 @@ def test_subgroup_check_on_small_order_and_random_curve_points(hd):
             assert rc == (0 if in_g1 else 3), (trial, rc, in_g1)
             n_out += not in_g1
     assert n_out >= 20
+
+
+def test_weighted_bucket_sum_in_lazy_xyzz(hd, setup_bytes):
+    """k_lc_wsum's arithmetic on the host: 16 bucket sums parked as raw lazy XYZZ accumulators, W = sum_b b B_b by running sums with
+    the lazy XYZZ + XYZZ addition (g1x_add_lazy2).  Cases: ordinary points; empty buckets (infinity operands); equal bucket sums
+    (acc = sum: the doubling branch); a bucket that cancels the running accumulator (acc passes through infinity)."""
+    g1, _ = setup_bytes
+    P = [g1[48 * i:48 * i + 48] for i in range(64)]
+    inf = bytes([0xC0]) + bytes(47)
+    def neg(p):
+        return bytes([p[0] ^ 0x20]) + p[1:]
+    def ref(pts):                                       # sum_b b (P_{2(b-1)} + P_{2(b-1)+1}) by the probe's canonical scalar multiplication
+        acc = inf
+        for b in range(16):
+            for k in range(2):
+                out = C.create_string_buffer(48)
+                assert hd.hd_g1_mul_add(out, pts[2 * b + k], (b + 1).to_bytes(32, "big"), acc) == 0
+                acc = out.raw
+        return acc
+    cases = []
+    cases.append(P[:32])
+    c = list(P[:32]); c[0] = c[1] = inf; c[30] = c[31] = inf; c[10] = inf; cases.append(c)                  # empty buckets 1, 16; a one-point bucket
+    c = list(P[:32]); c[28], c[29] = c[30], c[31]; cases.append(c)                                            # B_15 = B_16
+    c = list(P[:32]); c[28], c[29] = neg(c[30]), neg(c[31]); cases.append(c)                                  # B_15 = -B_16: acc = infinity after one step
+    c = [inf] * 32; cases.append(c)                                                                           # everything empty
+    c = [inf] * 32; c[30] = P[5]; cases.append(c)                                                             # only bucket 16
+    c = list(P[32:64]); c[3] = neg(c[2]); cases.append(c)                                                     # a bucket whose two items cancel
+    for pts in cases:
+        out = C.create_string_buffer(48)
+        assert hd.hd_weighted_bucket_sum(out, b"".join(pts)) == 0
+        assert out.raw == ref(pts)
+
+
+def test_pairing_with_projective_arguments_and_split_miller_loops(hd, oracle, setup_bytes):
+    """The pairing check as the kernels run it: G1 arguments as (X Z, Y, Z^3) of a Jacobian point with z != 1 (lines scaled by Z^3:
+    the final exponentiation must kill the factor), the two Miller loops run separately and multiplied.  Same verdicts as the
+    lane-level reference pairing on true, false and infinity cases, for several z."""
+    g1, g2 = setup_bytes
+    G2GEN, TAU2 = g2[:96], g2[96:192]
+    P0, P1 = g1[:48], g1[48:96]
+    inf = bytes([0xC0]) + bytes(47)
+    cases = [(P0, G2GEN, P0, G2GEN), (P0, TAU2, P0, TAU2), (P0, G2GEN, P1, G2GEN), (inf, G2GEN, inf, TAU2), (P0, TAU2, P1, G2GEN), (inf, G2GEN, P1, TAU2)]
+    for (a, qa, b, qb) in cases:
+        want = C.c_int(-1)
+        assert hd.hd_pairings_verify(C.byref(want), a, qa, b, qb) == 0
+        for z in (0, 1, 7):
+            got = C.c_int(-1)
+            assert hd.hd_pairings_verify_coop_proj(C.byref(got), a, qa, b, qb, z) == 0
+            assert got.value == want.value, (z, a.hex()[:8], b.hex()[:8])
