@@ -82,7 +82,7 @@ size_t lincomb_partials_bytes(int n_per_group, int groups);
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                             int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, PairPt *d_pair_pts, hipStream_t st,
                             int stage = 0 /* 0: all three kernels; 1 prep, 2 buckets, 3 horner (per-kernel timing) */,
-                            int chain_from = 2048 /* batches from which the tail is k_lc_wsum + k_lc_hchain instead of k_lc_horner */);
+                            int chain_from = 6144 /* batches from which the tail is k_lc_wsum + k_lc_hchain instead of k_lc_horner */);
 size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups);
 // pre-shifted form for few batches: launch_lincomb_preshift needs only the validated points (it can run beside the Fiat-Shamir
 // hash), launch_lincomb_preshifted finishes once the r powers exist.  d_scratch: lincomb_buckets_scratch_bytes().

@@ -652,7 +652,7 @@ def lincomb_handles(kz, setup_bytes):
             hs[form] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
         finally:
             del os.environ["KZG355_LINCOMB"]
-    # and one that takes the many-batch kernels whatever the batch count (by default from 1024 and 2048 batches on): r-transcripts hashed one
+    # and one that takes the many-batch kernels whatever the batch count (by default from 1024 and 6144 batches on): r-transcripts hashed one
     # lane per batch (k_rhash_lanes), bucket form ending in one Horner chain per class (k_lc_wsum + k_lc_hchain)
     os.environ["KZG355_RHASH_LANES_FROM"] = "1"; os.environ["KZG355_LC_CHAIN_FROM"] = "1"; os.environ["KZG355_LINCOMB"] = "bucket"
     try:
@@ -879,10 +879,11 @@ def test_device_entry_points_refuse_misaligned_pointers(kz, settings, random_set
     assert L.kzg355_verify_shard_records_device(rec.data_ptr() + 2, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 1, settings.handle) == 1
 
 
-def test_many_small_batches_take_the_many_batch_kernels(kz, settings, random_set):
-    """2100 batches of 8 blobs in one launch set: past the thresholds of the lane-per-batch transcript hash (1024) and of the
-    single-chain Horner tail (2048), with short and empty bucket lists (16 items of class 0 over 16 buckets).  Four batches carry two
-    swapped proofs and must be the only false verdicts; one carries an off-curve commitment and must be the only Err."""
+def test_many_small_batches_take_the_many_batch_kernels(kz, settings, lincomb_handles, random_set):
+    """2100 batches of 8 blobs in one launch set: past the threshold of the lane-per-batch transcript hash (1024) with the default
+    handle, and through the single-chain Horner tail (default from 6144 batches) with the handle that pins both thresholds to 1;
+    short and empty bucket lists (16 items of class 0 over 16 buckets).  Four batches carry two swapped proofs and must be the only
+    false verdicts; one carries an off-curve commitment and must be the only Err."""
     import torch
     blobs, cs, ps = random_set
     n, G = len(blobs), 2100
@@ -896,11 +897,12 @@ def test_many_small_batches_take_the_many_batch_kernels(kz, settings, random_set
     tc = torch.frombuffer(bytearray(b"".join(bytes(bad_c) if g == err_at else good_c for g in range(G))), dtype=torch.uint8).to(dev)
     tp = torch.frombuffer(bytearray(b"".join(bad_p if g in false_at else good_p for g in range(G))), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
-    ok = (C.c_bool * G)(); st = (C.c_int * G)()
-    rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle)
-    assert rc == 1
-    assert [g for g in range(G) if st[g] != 0] == [err_at]
-    assert sorted(g for g in range(G) if st[g] == 0 and not ok[g]) == sorted(false_at)
+    for s in (settings, lincomb_handles["rhash-lanes"]):
+        ok = (C.c_bool * G)(); st = (C.c_int * G)()
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, s.handle)
+        assert rc == 1
+        assert [g for g in range(G) if st[g] != 0] == [err_at]
+        assert sorted(g for g in range(G) if st[g] == 0 and not ok[g]) == sorted(false_at)
 
 
 def test_sharded_exchange_on_rccl_with_one_rank(kz, settings, random_set):
