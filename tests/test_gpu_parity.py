@@ -966,3 +966,37 @@ def test_full_size_launch_set_verdict_positions(kz, settings):
     assert np.flatnonzero((stv == 0) & (okv == 0)).tolist() == false_at
     del tb, tc, tp
     torch.cuda.empty_cache()
+
+
+def test_concurrent_mixed_calls_stress(kz, settings, random_set):
+    """Eight host threads, 15 rounds each of every entry point on ONE handle (workspace pool, the shared side stream, the per-handle
+    kernel statistics): every result must equal the single-threaded one."""
+    import threading
+    blobs, cs, ps = random_set
+    B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+    z = kz.Bytes32(random_field_element(3))
+    proof0, y0 = kz.Kzg.compute_kzg_proof(B[0], z, settings)
+    bad = list(Pr); bad[0], bad[1] = bad[1], bad[0]
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(15):
+                k = (t + it) % len(B)
+                assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, settings) is True
+                assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, bad, settings) is False
+                assert kz.Kzg.blob_to_kzg_commitment(B[k], settings).to_bytes() == cs[k]
+                assert kz.Kzg.compute_blob_kzg_proof(B[k], Cm[k], settings).to_bytes() == ps[k]
+                assert kz.Kzg.verify_blob_kzg_proof(B[k], Cm[k], Pr[k], settings) is True
+                p, y = kz.Kzg.compute_kzg_proof(B[0], z, settings)
+                assert p.to_bytes() == proof0.to_bytes() and y.to_bytes() == y0.to_bytes()
+                assert kz.Kzg.verify_kzg_proof(Cm[0], z, y0, proof0, settings) is True
+                assert kz.Kzg.verify_kzg_proof(Cm[1], z, y0, proof0, settings) is False
+        except Exception as e:           # noqa: BLE001 -- collected and re-raised on the main thread
+            errors.append((t, repr(e)))
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
