@@ -391,16 +391,31 @@ __global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, 
 //   k_lc_hchain  one lane per (batch, class): Horner over the 26 W's (5 doublings + 1 addition each), to affine
 // ~200 k wave instructions per batch instead of ~390 k; the dependent chain is ~20 % longer, so the form above stays for fewer batches.
 __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups, G1Jac *W) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;         // (batch, class, window)
-    if (id >= 2 * LC_WINDOWS * groups) return;
+    // the running total is parked in LDS between its additions (limb-major: conflict-free): with acc, the total, the bucket being
+    // added and the temporaries of an addition all in registers the kernel spills 68 VGPRs to scratch
+    __shared__ uint32_t tot[4 * NFP][256];
+    const int id = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;         // (batch, class, window)
+    if (id >= 2 * LC_WINDOWS * groups) return;                    // (no barrier below: every lane keeps to its own LDS column)
     const LcSlot *s = S + (size_t)id * LC_BUCKETS;                // the bucket kernel's raw (lazy extended-Jacobian) sums; all-zero = infinity
-    G1X acc = s[LC_BUCKETS - 1].raw, sum = acc;
+    G1X acc = s[LC_BUCKETS - 1].raw;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { tot[i][tid] = acc.x.l[i]; tot[NFP + i][tid] = acc.y.l[i]; tot[2 * NFP + i][tid] = acc.zz.l[i]; tot[3 * NFP + i][tid] = acc.zzz.l[i]; }
 #pragma unroll 1
     for (int b = LC_BUCKETS - 2; b >= 0; b--) {
         g1x_add_lazy2(acc, acc, s[b].raw);
+        asm volatile("" ::: "memory");                            // the total is fetched only now ...
+        G1X sum;
+#pragma unroll
+        for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid]; sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
         g1x_add_lazy2(sum, sum, acc);
+#pragma unroll
+        for (int i = 0; i < NFP; i++) { tot[i][tid] = sum.x.l[i]; tot[NFP + i][tid] = sum.y.l[i]; tot[2 * NFP + i][tid] = sum.zz.l[i]; tot[3 * NFP + i][tid] = sum.zzz.l[i]; }
+        asm volatile("" ::: "memory");                            // ... and is out of the registers before the next bucket comes in
     }
-    G1X c; g1x_from_lazy(c, sum, true);
+    G1X sum, c;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid]; sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
+    g1x_from_lazy(c, sum, true);
     G1Jac j; g1x_to_jac(j, c);
     W[id] = j;
 }
