@@ -186,6 +186,27 @@ void kzg355_reset_kernel_stats(kzg355_settings *s);
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled);
 const char *kzg355_version(void);
 
+/* ---- host-side Fiat-Shamir hashing ------------------------------------------------ */
+/* compute_challenge (kzg.rs:298-339) hashes 131,152 bytes per blob: on the device a 3.7 ms dependent chain for a small call, on a
+ * host core with the SHA extensions ~60 us.  Host-buffer verify / blob-proof calls of at most `max_blobs` blobs (one chunk) therefore
+ * hash their transcripts on the handle's host threads WHILE the H2D copy and the point kernels run and upload 32-byte digests; larger
+ * and device-resident calls keep the device kernels.  mode: 0 by size (default), 1 always, -1 never; max_blobs 0 keeps the current
+ * crossover (default 1024; KZG355_HOST_HASH=auto|on|off and KZG355_HOST_HASH_MAX in the environment set the same at load). */
+int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs);
+/* How many host-buffer calls on this handle had their challenges hashed on the host so far. */
+long kzg355_settings_host_hashed_calls(const kzg355_settings *s);
+/* The host hash itself, exported for the tests (tests/test_host_sha256.py checks it against hashlib): impl 0 auto, 1 portable C,
+ * 2 SHA extensions (KZG355_INTERNAL if the CPU has none).  kzg355_host_challenge_digests writes the n digests of
+ * "FSBLOBVERIFY_V1_" | u64be(0) | u64be(blob_bytes / 32) | blob_i | commitment_i. */
+/* Test / audit form of kzg355_verify_blob_kzg_proof_batch_many for calls of at most 64 MiB of blobs on a single-device handle: also
+ * returns the stage-1 records C_i | z_i | y_i | proof_i of every blob (the body of the r-transcript, utils.rs:454-463), so that the z_i
+ * of the host-hashed and the device-hashed route can each be diffed against the oracle (tests/test_gpu_host_hash.py). */
+int kzg355_debug_verify_host_records(uint8_t *records_out /* groups*n_per_group*160, host */, bool *ok /* groups */, int *status /* groups or NULL */,
+                                     const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t n_per_group, size_t groups,
+                                     const kzg355_settings *s);
+int kzg355_host_sha256(uint8_t out[32], const uint8_t *msg, size_t len, int impl);
+int kzg355_host_challenge_digests(uint8_t *out /* n*32 */, const uint8_t *blobs, size_t blob_bytes, const uint8_t *commitments /* n*48 */, size_t n, int impl);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,10 @@ def load():
         "kzg355_lagrange_setup_from_monomial": [u8p, u8p, sz],
         "kzg355_settings_field_elements_per_blob": [vp],
         "kzg355_set_kernel_timing": [vp, C.c_int],
+        "kzg355_settings_set_host_hash": [vp, C.c_int, C.c_int],
+        "kzg355_host_sha256": [u8p, u8p, sz, C.c_int],
+        "kzg355_debug_verify_host_records": [u8p, bp, ip, u8p, u8p, u8p, sz, sz, vp],
+        "kzg355_host_challenge_digests": [u8p, u8p, sz, u8p, sz, C.c_int],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -75,6 +79,8 @@ def load():
     lib.kzg355_last_kernel_ms.argtypes = [vp, u8p]
     lib.kzg355_last_kernel_ms.restype = C.c_double
     lib.kzg355_version.restype = C.c_char_p
+    lib.kzg355_settings_host_hashed_calls.argtypes = [vp]
+    lib.kzg355_settings_host_hashed_calls.restype = C.c_long
     return lib
 
 
@@ -88,4 +94,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_settings_device", "kzg355_last_kernel_ms", "kzg355_set_kernel_timing", "kzg355_version",
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
     "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_verify_shard_records_points_device", "kzg355_verify_records_points_device", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
+    "kzg355_settings_set_host_hash", "kzg355_settings_host_hashed_calls", "kzg355_host_sha256", "kzg355_host_challenge_digests", "kzg355_debug_verify_host_records",
 ]

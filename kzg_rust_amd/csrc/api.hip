@@ -4,6 +4,7 @@
 // There is no CPU fallback: without a usable HIP device every entry point returns KZG355_NO_DEVICE.
 #include "../../include/kzg355.h"
 #include "kernels.h"
+#include "host_sha256.h"
 
 #include <sched.h>
 #include <atomic>
@@ -16,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -66,87 +68,119 @@ struct PinBuf {
 // Per-call scratch: a private stream plus grow-on-demand device buffers.  One workspace serves one call at a time;
 // concurrent host threads get different workspaces from the pool in the settings handle.
 struct Workspace {
-    hipStream_t stream = nullptr, side = nullptr;     // side: kernels independent of the main chain (point validation)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_pending = false;      // work on the side stream that the main stream has not waited for yet
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts;
+    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;     // side, side2: kernels independent of the main chain (point validation; window shifts)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pts = nullptr, ev_shift = nullptr;
+    // work on the side streams that the main stream has not waited for yet: everything (ev_join: the validation verdicts are in the error
+    // words), the decoded points alone (ev_pts; recorded only when they are ready before the verdicts), the window shifts (ev_shift)
+    bool side_pending = false, pts_pending = false, shift_pending = false;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests;
     bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
-    PinBuf h_ok, h_err, h_out;
+    PinBuf h_ok, h_err, h_out, h_digests;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
     hipEvent_t ev[32];
     bool ev_ok = false;
     bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
     // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
     void quiesce() {
-        if (in_flight || side_pending) { if (side) (void)hipStreamSynchronize(side); if (stream) (void)hipStreamSynchronize(stream); }
-        in_flight = false; side_pending = false; shift_ready = false;
+        if (in_flight || side_pending || pts_pending || shift_pending) {
+            if (side) (void)hipStreamSynchronize(side);
+            if (side2) (void)hipStreamSynchronize(side2);
+            if (stream) (void)hipStreamSynchronize(stream);
+        }
+        in_flight = false; side_pending = false; pts_pending = false; shift_pending = false; shift_ready = false;
     }
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts}) b->release();
-        h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests}) b->release();
+        h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift}) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
     }
 };
 
 }  // namespace
 
-// Host threads that copy caller memory into pinned staging buffers (one 64 KiB-granular slice each); the calling thread
-// takes a slice too.  A single memcpy stream moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s: the copy into pinned memory has to be
-// parallel for the link to be the limit.
-class CopyPool {
+// Host worker threads of a handle.  Two users: the Fiat-Shamir hashing of small host-buffer calls (host_sha256.h; the blobs of such
+// a call are hashed here while its H2D copy and point kernels run) and the parallel copy into pinned staging buffers
+// (KZG355_STAGING=ring: a single memcpy stream moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s).  A job is a range of indices dealt out
+// through an atomic counter; the calling thread takes indices too.  One job at a time: try_begin() fails while another call's job is
+// running (the caller then takes its other route -- the device hash), begin() waits.
+class HostPool {
+    struct Job {
+        std::function<void(size_t)> fn;
+        size_t count = 0;
+        std::atomic<size_t> next{0}, left{0};
+    };
 public:
-    explicit CopyPool(int workers) {
-        for (int i = 0; i < workers; i++) th_.emplace_back([this, i] { run(i); });
+    explicit HostPool(int workers) {
+        for (int i = 0; i < workers; i++) th_.emplace_back([this] { run(); });
     }
-    ~CopyPool() {
+    ~HostPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
     int workers() const { return (int)th_.size(); }
-    void copy(void *dst, const void *src, size_t bytes) {
-        const size_t parts = th_.size() + 1;
-        if (th_.empty() || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
-        std::unique_lock<std::mutex> call(call_mu_);             // one parallel copy at a time
-        const size_t per = ((bytes / parts) + 65535) & ~(size_t)65535;
+    bool try_begin(size_t count, std::function<void(size_t)> fn) {
+        if (!call_mu_.try_lock()) return false;
+        start(count, std::move(fn));
+        return true;
+    }
+    void begin(size_t count, std::function<void(size_t)> fn) { call_mu_.lock(); start(count, std::move(fn)); }
+    // the caller works through what is left of the job it began, then waits for the indices still in other hands
+    void finish() {
+        std::shared_ptr<Job> j = cur_;
+        work(*j);
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; bytes_ = bytes; per_ = per; pending_ = (int)th_.size(); gen_++;
+            std::unique_lock<std::mutex> lk(mu_);
+            done_.wait(lk, [&] { return j->left.load() == 0; });
+            cur_.reset();
         }
-        cv_.notify_all();
-        slice(th_.size());
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return pending_ == 0; });
+        call_mu_.unlock();
+    }
+    void parallel_for(size_t count, std::function<void(size_t)> fn) { begin(count, std::move(fn)); finish(); }
+    void copy(void *dst, const void *src, size_t bytes) {
+        if (th_.empty() || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
+        const size_t parts = th_.size() + 1, per = ((bytes / parts) + 65535) & ~(size_t)65535;     // 64 KiB-granular slices
+        parallel_for((bytes + per - 1) / per, [=](size_t k) {
+            const size_t lo = k * per, n = bytes - lo < per ? bytes - lo : per;
+            memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, n);
+        });
     }
 private:
-    void slice(size_t k) {
-        const size_t lo = k * per_;
-        if (lo >= bytes_) return;
-        const size_t n = bytes_ - lo < per_ ? bytes_ - lo : per_;
-        memcpy(dst_ + lo, src_ + lo, n);
+    void start(size_t count, std::function<void(size_t)> fn) {
+        auto j = std::make_shared<Job>();
+        j->fn = std::move(fn); j->count = count; j->left = count;
+        { std::lock_guard<std::mutex> lk(mu_); cur_ = j; gen_++; }
+        if (count) cv_.notify_all();
     }
-    void run(int i) {
+    void work(Job &j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1);
+            if (i >= j.count) return;
+            j.fn(i);
+            if (j.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(mu_); done_.notify_all(); }
+        }
+    }
+    void run() {
         unsigned long seen = 0;
         for (;;) {
+            std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
+                j = cur_;
             }
-            slice((size_t)i);
-            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_one(); }
+            if (j) work(*j);
         }
     }
     std::vector<std::thread> th_;
     std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_;
-    uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr;
-    size_t bytes_ = 0, per_ = 0;
-    int pending_ = 0; unsigned long gen_ = 0; bool stop_ = false;
+    std::shared_ptr<Job> cur_;
+    unsigned long gen_ = 0; bool stop_ = false;
 };
 
 struct MultiDev;
@@ -161,10 +195,15 @@ struct kzg355_settings {
     int lc_chain_from = 6144;      // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM); measured: lincomb + tail at 2048 / 4096 / 8192 batches: 6.0 / 11.1 / 21.9 ms with 16 chains per class, 6.7 / 11.2 / 20.2 ms with one
     int rhash_lanes_from = 1024;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM); measured: 1024 batches of 512 records 6.75 -> 3.47 ms, 8192 of 64: 2.44 -> 0.57 ms
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
+    int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
     std::mutex mu;
-    hipStream_t side_stream = nullptr;   // shared by the workspaces (point validation of small calls next to the hash chain)
+    hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
+    int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
+    int host_hash_max = 1024;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX); crossover measured in profiles/r03/host_hash_crossover.txt
+    int sha_impl = 0;                // host SHA-256 form: 0 auto (SHA extensions when the CPU has them), 1 portable, 2 SHA extensions (KZG355_HOST_SHA=portable|shani)
+    std::atomic<long> n_host_hashed{0};   // introspection: host-buffer calls whose challenges were hashed on the host
     std::vector<Workspace *> pool;
-    CopyPool *copy_pool = nullptr;  // created with the handle (KZG355_COPY_THREADS, default min(8, cores / 2) - 1 workers)
+    HostPool *host_pool = nullptr;  // created with the handle: host threads for the Fiat-Shamir hashing of small host-buffer calls and the staging copies
     size_t chunk_bytes = (size_t)1024 << 20;  // blobs per chunk of a host-buffer call (KZG355_CHUNK_MB): 1 GiB = 18 ms of PCIe traffic, more than
                                               // the ~11 ms kernel chain of a chunk even when the chains of successive chunks end up on one hardware queue
     int chunks_in_flight = 3;                 // workspaces (pinned slot + device buffers + stream) a host-buffer call rotates over
@@ -188,7 +227,8 @@ Workspace *ws_acquire(kzg355_settings *s) {
     // (ONE side stream per handle, created on first use and shared by its workspaces: HIP multiplexes streams onto a handful of
     // hardware queues -- 4 unless GPU_MAX_HW_QUEUES says otherwise -- and two workspaces whose main streams land on the same queue
     // run their launch sets one after the other.  Measured: with a side stream per workspace no more than two calls overlapped.)
-    if (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { delete w; return nullptr; }
+    for (hipEvent_t *e : {&w->ev_fork, &w->ev_join, &w->ev_pts, &w->ev_shift})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; delete w; return nullptr; }
     bool ok = true;
     for (auto &e : w->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     w->ev_ok = ok;
@@ -257,6 +297,14 @@ bool ensure_side(kzg355_settings *s, Workspace *w) {
     }
     return w->side != nullptr;
 }
+bool ensure_side2(kzg355_settings *s, Workspace *w) {
+    if (!w->side2) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->side2_stream && hipStreamCreateWithFlags(&s->side2_stream, hipStreamNonBlocking) != hipSuccess) { s->side2_stream = nullptr; (void)hipGetLastError(); }
+        w->side2 = s->side2_stream;
+    }
+    return w->side2 != nullptr;
+}
 inline bool is_small(const kzg355_settings *s) { return s->t.n_fe != N_FE; }
 inline size_t blob_bytes_of(const kzg355_settings *s) { return (size_t)32 * s->t.n_fe; }
 
@@ -278,8 +326,70 @@ int status_from_err(int err) {
 }
 
 // ---- stage drivers (all asynchronous on w->stream) -------------------------------------------------
+// Host-hashed challenges of a small host-buffer call (host_sha256.h): a job on the handle's host threads is writing the digests of
+// the call's challenge transcripts to w->h_digests while the caller queues copies and kernels.  finish() joins it (the calling
+// thread takes what is left); the destructor does the same on every error path -- the job reads caller memory.
+struct HostFront {
+    HostPool *pool = nullptr;
+    const uint8_t *h_blobs = nullptr;   // the call's blobs in caller memory: copied to the device AFTER the point kernels are queued
+    size_t bytes = 0;
+    bool running = false;
+    void finish() { if (running) { running = false; pool->finish(); } }
+    ~HostFront() { finish(); }
+};
+
+// The point work of stage 1 depends on nothing but the inputs, so for small calls it runs BESIDE the main chain:
+//   side    point validation (utils.rs:282-310); in the pre-shifted form of the linear combination as two kernels, so that the decoded
+//           points (ev_pts) are out before the subgroup verdicts (ev_join), which only feed the error words;
+//   side2   the window shifts of the pre-shifted form (k_ps_shift), straight from the compressed bytes: they need x only and run next to
+//           the square roots of the decoding instead of after them (ev_shift).
+// The main stream waits where the results are first needed: join_points() in front of the linear combination, join_side() in front of
+// the copy of the error words.
+int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_c, const uint8_t *d_p, int n_total, int npg, G1Affine *d_pts,
+                          int *d_err, bool allow_preshift) {
+    int rc;
+    HIPCHK(hipEventRecord(w->ev_fork, w->stream));
+    const bool pre = allow_preshift && d_pts && d_p && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT;
+    bool shift_on_side2 = false;
+    if (pre) {
+        if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, n_total / npg)))) return rc;
+        if (ensure_side2(s, w)) {
+            HIPCHK(hipStreamWaitEvent(w->side2, w->ev_fork, 0));
+            w->shift_pending = true;
+            tm.begin("lincomb_shift", w->side2); launch_lincomb_preshift_bytes(d_c, d_p, 48, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side2); tm.end(w->side2);
+            HIPCHK(hipEventRecord(w->ev_shift, w->side2));
+            shift_on_side2 = true;
+        }
+    }
+    HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+    w->side_pending = true;                                       // (from here on a failing call has to drain the side streams: quiesce())
+    if (pre) {
+        tm.begin("decompress_points", w->side); launch_decompress_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
+        HIPCHK(hipEventRecord(w->ev_pts, w->side));
+        w->pts_pending = true;
+        if (!shift_on_side2) { tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side); }
+        tm.begin("validate_points", w->side); launch_subgroup_points(d_pts, n_total, npg, d_err, w->side); tm.end(w->side);
+        w->shift_ready = true;
+    } else {
+        tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
+    }
+    HIPCHK(hipEventRecord(w->ev_join, w->side));
+    return KZG355_OK;
+}
+int join_points(Workspace *w) {       // the decoded points and their window shifts
+    if (w->shift_pending) { w->shift_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_shift, 0)); }
+    if (w->pts_pending) { w->pts_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_pts, 0)); }
+    else if (w->side_pending) { w->side_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0)); }
+    return KZG355_OK;
+}
+int join_side(Workspace *w) {         // everything the side streams were given, the validation verdicts included
+    int rc = join_points(w);
+    if (rc) return rc;
+    if (w->side_pending) { w->side_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0)); }
+    return KZG355_OK;
+}
 int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total,
-               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true) {
+               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true, HostFront *hf = nullptr) {
     int rc;
     w->shift_ready = false;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
@@ -288,33 +398,26 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         tm.begin("small_records"); launch_small_records(d_blobs, d_c, d_p, n_total, npg, s->t, w->z.as<Fr>(), d_records, d_err, w->stream); tm.end();
         return KZG355_OK;
     }
-    // Point validation depends on nothing but the inputs.  While the card is far from full (few batches) it runs on the side
-    // stream next to the challenge -> evaluation (-> r powers) chain and the main stream waits for it only where the points
-    // are first needed (join_side()).  With many batches in flight both kernels fill the card on their own and sharing the
-    // SIMDs only slows the challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together:
-    // one-wave workgroups of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
-    if (n_total <= 16384 && ensure_side(s, w)) {
-        HIPCHK(hipEventRecord(w->ev_fork, w->stream));
-        HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-        w->side_pending = true;                                   // (from here on a failing call has to drain the side stream: quiesce())
-        tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
-        if (allow_preshift && d_pts && !is_small(s) && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT) {
-            // the doubling chains of the linear combination depend on the points alone: walk them now, beside the hash
-            if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, n_total / npg)))) return rc;
-            tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side);
-            w->shift_ready = true;
-        }
-        HIPCHK(hipEventRecord(w->ev_join, w->side));
-        w->side_pending = true;
+    // While the card is far from full (few batches) the point work runs on the side streams next to the challenge -> evaluation
+    // (-> r powers) chain.  With many batches in flight every kernel fills the card on its own and sharing the SIMDs only slows the
+    // challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together: one-wave workgroups
+    // of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
+    if (n_total <= s->beside_max_blobs && ensure_side(s, w)) {
+        if ((rc = enqueue_points_beside(s, w, tm, d_c, d_p, n_total, npg, d_pts, d_err, allow_preshift))) return rc;
     } else {
         tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
     }
-    tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream, s->challenge_form); tm.end();
+    if (hf) {
+        // the blobs follow the point kernels into their queues (the copy from pageable memory holds the host thread for its duration);
+        // then the digests the host threads have been computing meanwhile: 32 bytes per blob instead of a 2050-compression chain
+        HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
+        hf->finish();
+        HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * (size_t)n_total, hipMemcpyHostToDevice, w->stream));
+        tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream); tm.end();
+    } else {
+        tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream, s->challenge_form); tm.end();
+    }
     tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
-    return KZG355_OK;
-}
-int join_side(Workspace *w) {
-    if (w->side_pending) { w->side_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0)); }
     return KZG355_OK;
 }
 int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_records, int npg, int groups, int check_zy, const G1Affine *d_pts,
@@ -331,7 +434,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     const int form = lincomb_form(s, npg, groups);
     const bool buckets = form == LC_FORM_BUCKET;
     if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
-    if ((rc = join_side(w))) return rc;                           // the validated points (and their shifts) are needed from here on
+    if ((rc = join_points(w))) return rc;                         // the decoded points (and their shifts) are needed from here on
     if (form == LC_FORM_PRESHIFT) {
         if (!shift_ready) {                                       // entry points without a stage 1 (single proofs, gathered records)
             if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, groups)))) return rc;
@@ -361,7 +464,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
 
 // Enqueue one launch set on w->stream (no host synchronisation) ...
 int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
-                   size_t res_off = 0, size_t res_cap = 0) {
+                   size_t res_off = 0, size_t res_cap = 0, HostFront *hf = nullptr) {
     // res_off / res_cap: several launch sets queued on one workspace (stream order keeps the device scratch safe) park their
     // verdicts at different offsets of the pinned result buffers, sized res_cap entries up front
     const int n_total = npg * G;
@@ -375,8 +478,9 @@ int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
     if ((rc = w->h_err.ensure(sizeof(int) * res_cap))) return rc;
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
-    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>()))) return rc;
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>(), true, hf))) return rc;
     if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if ((rc = join_side(w))) return rc;                           // the subgroup verdicts, before the error words go back
     HIPCHK(hipMemcpyAsync(w->h_ok.as<int>() + res_off, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.as<int>() + res_off, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     return KZG355_OK;
@@ -464,7 +568,7 @@ int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes)
 int stage_via_pinned(kzg355_settings *s, Workspace *w, PinBuf &pin, size_t pin_off, DevBuf &dst, const uint8_t *src, size_t bytes) {
     int rc;
     if ((rc = dst.ensure(bytes))) return rc;
-    if (s->copy_pool) s->copy_pool->copy(pin.as<uint8_t>() + pin_off, src, bytes);
+    if (s->host_pool) s->host_pool->copy(pin.as<uint8_t>() + pin_off, src, bytes);
     else memcpy(pin.as<uint8_t>() + pin_off, src, bytes);
     HIPCHK(hipMemcpyAsync(dst.p, pin.as<uint8_t>() + pin_off, bytes, hipMemcpyHostToDevice, w->stream));
     return KZG355_OK;
@@ -503,7 +607,7 @@ int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_b
 }
 
 // n commitments (d_c == null) or n blob proofs against the commitments d_c: enqueue on w->stream ...
-int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n) {
+int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, HostFront *hf = nullptr) {
     int rc;
     if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
@@ -525,14 +629,19 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
         // compute_challenge validates the commitment (kzg.rs:321-323); one "group" per blob so errors stay per blob
         // (the validation only feeds the error word: for few blobs it runs on the side stream, beside the hash chain -- 1.5 ms for one
         // point against 3.7 ms for one hash -- and is joined before the statuses are copied back)
-        if (n <= 16384 && ensure_side(s, w)) {
+        if (n <= (size_t)s->beside_max_blobs && ensure_side(s, w)) {
             HIPCHK(hipEventRecord(w->ev_fork, w->stream));       // after the memset of the error words
             HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+            w->side_pending = true;
             tm.begin("validate_points", w->side); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->side); tm.end(w->side);
             HIPCHK(hipEventRecord(w->ev_join, w->side));
-            w->side_pending = true;
         } else { tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end(); }
-        tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form); tm.end();
+        if (hf) {                                                 // challenges hashed on the host (see run_stage1)
+            HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
+            hf->finish();
+            HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * n, hipMemcpyHostToDevice, w->stream));
+            tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream); tm.end();
+        } else { tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form); tm.end(); }
         if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
         if ((rc = join_side(w))) return rc;
     }
@@ -583,6 +692,7 @@ struct HostCall {
     const uint8_t *blobs, *commitments, *proofs;
     size_t npg;                      // blobs per unit
     bool *ok; uint8_t *out48; int *status;
+    uint8_t *records_out = nullptr;  // verify, single-chunk calls only (kzg355_debug_verify_host_records): the stage-1 records, copied back after the chunk
 };
 int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
@@ -608,6 +718,10 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     // a call that fits one small chunk (a single 64-blob batch is 8 MiB) goes straight from caller memory: the runtime's own
     // staged copy moves it at link speed (measured 52 GB/s for 8 MiB), one pass over the bytes instead of two
     const bool direct = !s->pinned_ring || (nchunks == 1 && unit_bytes * units <= ((size_t)32 << 20));
+    // Fiat-Shamir challenges hashed on the host (host_sha256.h): single-chunk verify / blob-proof calls of the mainnet preset, up to the
+    // measured crossover (the device hash is a 3.7 ms chain for ANY call of up to 32,768 blobs; T host threads take ~35 us x blobs / T)
+    const bool host_hash = nchunks == 1 && (hc.kind == 0 || hc.kind == 2) && !is_small(cs) && s->host_pool &&
+                           (s->host_hash > 0 || (s->host_hash == 0 && units * hc.npg <= (size_t)s->host_hash_max));
     std::vector<WsGuard *> guards;
     struct Cleanup { std::vector<WsGuard *> &g; ~Cleanup() { for (size_t i = g.size(); i-- > 0;) delete g[i]; } } cleanup{guards};
     std::vector<Timed> tms;
@@ -626,6 +740,7 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         pend[slot].cnt = 0;
         int rc = hc.kind == 0 ? verify_collect(w, tms[slot], hc.ok + u0, hc.status ? hc.status + u0 : nullptr, (int)cnt)
                               : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt);
+        if (hc.records_out && hc.kind == 0 && hipMemcpy(hc.records_out + (size_t)RECORD_BYTES * hc.npg * u0, w->records.p, (size_t)RECORD_BYTES * hc.npg * cnt, hipMemcpyDeviceToHost) != hipSuccess) return KZG355_NO_DEVICE;
         if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return rc;
         if (rc != KZG355_OK && first == KZG355_OK) first = rc;
         return KZG355_OK;
@@ -646,7 +761,24 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         if ((rc = collect(slot))) return rc;                                       // frees this slot's pinned and device buffers
         t_wait += now() - t0; t0 = now();
         const size_t nb = cnt * hc.npg, off = u0 * hc.npg;
-        if (direct) {
+        HostFront hf;
+        if (direct && host_hash) {
+            // Small call whose challenges need a hash of every blob (verify, blob proof): the host threads hash while the copies and the
+            // point kernels are queued; the blobs themselves go to the device inside the enqueue below, behind the point kernels.
+            if ((rc = w->h_digests.ensure(32 * nb)) || (rc = w->digests.ensure(32 * nb)) || (rc = w->blobs.ensure(BB * nb))) return rc;
+            uint8_t *dig = w->h_digests.as<uint8_t>();
+            const uint8_t *hb = hc.blobs + BB * off, *hcm = hc.commitments + 48 * off;
+            const uint64_t n_fe = (uint64_t)s->t.n_fe; const int impl = s->sha_impl;
+            auto job = [=](size_t k) { kzg_host::challenge_digests(dig + 64 * k, hb + BB * 2 * k, BB, hcm + 96 * k, nb - 2 * k < 2 ? nb - 2 * k : 2, n_fe, impl); };
+            if (s->host_pool && s->host_pool->try_begin((nb + 1) / 2, job)) {
+                hf.pool = s->host_pool; hf.h_blobs = hb; hf.bytes = BB * nb; hf.running = true;
+                s->n_host_hashed++;
+            }
+        }
+        if (hf.running) {
+            if ((rc = stage_to_device(w, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
+            if (hc.proofs && (rc = stage_to_device(w, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
+        } else if (direct) {
             if ((rc = stage_to_device(w, w->blobs, hc.blobs + BB * off, BB * nb))) return rc;
             if (hc.commitments && (rc = stage_to_device(w, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
             if (hc.proofs && (rc = stage_to_device(w, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
@@ -662,8 +794,9 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
             if (hc.proofs && (rc = stage_via_pinned(s, w, w->h_stage_cp, 48 * nb, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
         }
         t_stage += now() - t0; t0 = now();
-        if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt);
-        else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt);
+        HostFront *hfp = hf.running ? &hf : nullptr;
+        if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt, 0, 0, hfp);
+        else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt, hfp);
         if (rc) return rc;
         if (dbg && !direct) (void)hipEventRecord(dev_ev[3 * k + 2], w->stream);
         t_enq += now() - t0;
@@ -700,6 +833,7 @@ extern "C" {
 const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montgomery, fixed-base Pippenger, precomputed-line pairing)"; }
 
 static int device_self_test(kzg355_settings *s);
+static std::vector<kzg355_settings *> replicas_of(kzg355_settings *s);
 static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, kzg355_settings **out) {
     if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
     // FIELD_ELEMENTS_PER_BLOB is a compile-time constant of the reference (consts.rs:13: 4096; its README's minimal preset: 4); here
@@ -762,10 +896,15 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     {
         cpu_set_t cpus; CPU_ZERO(&cpus);
         int workers = sched_getaffinity(0, sizeof cpus, &cpus) == 0 ? CPU_COUNT(&cpus) / 2 : 1;     // cores this process may run on
-        if (workers > 8) workers = 8;
-        if (const char *e = getenv("KZG355_COPY_THREADS")) workers = atoi(e);
+        if (workers > 16) workers = 16;
+        if (const char *e = getenv("KZG355_HOST_THREADS")) workers = atoi(e);
+        else if (const char *e = getenv("KZG355_COPY_THREADS")) workers = atoi(e);
         if (workers > 64) workers = 64;
-        if (workers > 1) s->copy_pool = new CopyPool(workers - 1);           // the calling thread is one of the copiers
+        if (workers < 1) workers = 1;
+        s->host_pool = new HostPool(workers - 1);                            // the calling thread is one of the workers
+        if (const char *e = getenv("KZG355_HOST_HASH")) s->host_hash = strcmp(e, "on") == 0 ? 1 : strcmp(e, "off") == 0 ? -1 : 0;
+        if (const char *e = getenv("KZG355_HOST_HASH_MAX")) { const int v = atoi(e); if (v >= 1) s->host_hash_max = v; }
+        if (const char *e = getenv("KZG355_HOST_SHA")) s->sha_impl = strcmp(e, "portable") == 0 ? 1 : strcmp(e, "shani") == 0 ? 2 : 0;
         if (const char *e = getenv("KZG355_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 16384) s->chunk_bytes = (size_t)v << 20; }
         if (const char *e = getenv("KZG355_STAGING")) s->pinned_ring = strcmp(e, "ring") == 0;
         if (const char *e = getenv("KZG355_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->chunks_in_flight = v; }
@@ -939,6 +1078,7 @@ struct MultiDev {
 };
 
 static void free_single(kzg355_settings *s);
+static std::vector<kzg355_settings *> replicas_of(kzg355_settings *s) { return s->multi ? s->multi->rep : std::vector<kzg355_settings *>{s}; }
 
 int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
                                       kzg355_settings **out) {
@@ -1062,7 +1202,8 @@ static void free_single(kzg355_settings *s) {
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
     if (s->side_stream) { (void)hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
-    delete s->copy_pool; s->copy_pool = nullptr;
+    if (s->side2_stream) { (void)hipStreamDestroy(s->side2_stream); s->side2_stream = nullptr; }
+    delete s->host_pool; s->host_pool = nullptr;
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
     delete s;
@@ -1086,6 +1227,22 @@ int kzg355_settings_msm_form(const kzg355_settings *s) {
     return s->wide_table_failed ? -8 : 8;
 }
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
+long kzg355_settings_host_hashed_calls(const kzg355_settings *s) { return s ? s->n_host_hashed.load() : 0L; }
+int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs) {
+    if (!s || mode < -1 || mode > 1 || max_blobs < 0) return KZG355_BADARGS;
+    for (kzg355_settings *r : s->multi ? replicas_of(s) : std::vector<kzg355_settings *>{s}) { r->host_hash = mode; if (max_blobs) r->host_hash_max = max_blobs; }
+    return KZG355_OK;
+}
+int kzg355_host_sha256(uint8_t out[32], const uint8_t *msg, size_t len, int impl) {
+    if (!out || (!msg && len) || impl < 0 || impl > 2) return KZG355_BADARGS;
+    return kzg_host::sha256(out, msg, len, impl) ? KZG355_OK : KZG355_INTERNAL;      // INTERNAL: SHA extensions asked for, CPU has none
+}
+int kzg355_host_challenge_digests(uint8_t *out, const uint8_t *blobs, size_t blob_bytes, const uint8_t *commitments, size_t n, int impl) {
+    if (!out || !blobs || !commitments || blob_bytes % 32 || blob_bytes == 0 || impl < 0 || impl > 2) return KZG355_BADARGS;
+    if (impl == 2 && !kzg_host::sha256_have_shani()) return KZG355_INTERNAL;
+    kzg_host::challenge_digests(out, blobs, blob_bytes, commitments, n, (uint64_t)(blob_bytes / 32), impl);
+    return KZG355_OK;
+}
 double kzg355_last_kernel_ms(const kzg355_settings *cs, const char *family) {
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
     if (!s || !family) return -1.0;
@@ -1433,6 +1590,15 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t
     if (n > (size_t)1 << 24) return KZG355_BADARGS;
     if (cs->multi) return multi_verify_many(ok, status, blobs, commitments, proofs, n_per_group, groups, cs);
     return single_verify_many(ok, status, blobs, commitments, proofs, n_per_group, groups, cs);
+}
+
+int kzg355_debug_verify_host_records(uint8_t *records_out, bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
+                                     size_t n_per_group, size_t groups, const kzg355_settings *cs) {
+    if (!cs || !ok || !records_out || !blobs || !commitments || !proofs || n_per_group == 0 || groups == 0 || cs->multi) return KZG355_BADARGS;
+    if (n_per_group * groups > (size_t)1 << 24 || blob_bytes_of(cs) * n_per_group * groups > ((size_t)64 << 20)) return KZG355_BADARGS;      // one chunk
+    HostCall hc{0, blobs, commitments, proofs, n_per_group, ok, nullptr, status};
+    hc.records_out = records_out;
+    return host_pipeline(hc, groups, cs);
 }
 
 int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,

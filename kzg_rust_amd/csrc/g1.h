@@ -471,25 +471,35 @@ KZG_HD void g1_compress_affine(uint8_t *out, const G1Affine &p) {
     out[0] |= (uint8_t)(0x80 | (fp_is_lex_largest(p.y) ? 0x20 : 0));
 }
 
-// Decode 48 compressed bytes.  Returns 0 ok, 1 bad encoding, 2 not on curve (blst_p1_uncompress rules:
-// compression bit required; infinity must be exactly 0xc0 00..00; x < p; x^3+4 must be a square).
-KZG_HD int g1_decompress(G1Affine &r, const uint8_t *in) {
+// Flags and x of a compressed encoding (blst_p1_uncompress rules: compression bit required; infinity must be exactly
+// 0xc0 00..00; x < p).  Returns 0 ok (x set, or inf), 1 bad encoding.
+KZG_HD int g1_parse_compressed(Fp &x, bool &inf, bool &y_large, const uint8_t *in) {
     const uint8_t b0 = in[0];
+    inf = false; y_large = (b0 & 0x20) != 0;
     if (!(b0 & 0x80)) return 1;
     if (b0 & 0x40) {
         uint32_t acc = b0 & 0x3f;
         for (int i = 1; i < 48; i++) acc |= in[i];
         if (acc) return 1;
-        r = g1a_inf();
+        inf = true;
         return 0;
     }
-    Fp x, y, y2;
-    if (!fp_from_be48(x, in, true)) return 1;
+    return fp_from_be48(x, in, true) ? 0 : 1;
+}
+// x^3 + 4
+KZG_HD void g1_curve_rhs(Fp &r, const Fp &x) {
     const uint32_t b4[NFP] = FP_B_INIT;
     Fp four; for (int i = 0; i < NFP; i++) four.l[i] = b4[i];
-    fp_sqr(y2, x); fp_mul(y2, y2, x); fp_add(y2, y2, four);
+    fp_sqr(r, x); fp_mul(r, r, x); fp_add(r, r, four);
+}
+// Decode 48 compressed bytes.  Returns 0 ok, 1 bad encoding, 2 not on curve (x^3 + 4 must be a square).
+KZG_HD int g1_decompress(G1Affine &r, const uint8_t *in) {
+    Fp x, y, y2;
+    bool inf, want_large;
+    if (g1_parse_compressed(x, inf, want_large, in)) return 1;
+    if (inf) { r = g1a_inf(); return 0; }
+    g1_curve_rhs(y2, x);
     if (!fp_sqrt(y, y2)) return 2;
-    bool want_large = (b0 & 0x20) != 0;
     if (fp_is_lex_largest(y) != want_large) fp_neg(y, y);
     r.x = x; r.y = y;
     return 0;

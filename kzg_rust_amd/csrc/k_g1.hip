@@ -451,19 +451,42 @@ __global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, Pa
 constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
 constexpr int PS_THREADS = 256, PS_LANES_PER_BUCKET = 64, PS_BUCKETS_PER_WG = PS_THREADS / PS_LANES_PER_BUCKET, PS_PARTS = LC_BUCKETS / PS_BUCKETS_PER_WG;     // 4 buckets per workgroup, 4 workgroups per (batch, class)
 __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
-// thread (g, pt): Q[w] = 32^w P for w = 0..25, canonical Jacobian.  Point 2n of every batch is -G (the term -[sum r^i y_i] G).
-__global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, int n, int groups, G1Jac *shifts) {
+// thread (g, pt): Q[w] = 32^w P for w = 0..25.  Point 2n of every batch is -G (the term -[sum r^i y_i] G).
+// The chain starts from x ALONE, so it does not wait for the square root of the decompression (a second 0.6 ms chain; with the
+// challenges hashed on the host nothing else hides it): with s = x^3 + 4 = y^2, the map (X, Y) -> (X / s, y Y / s^2) takes the curve
+// E'': Y^2 = X^3 + 4 s^3 to E, and (s x, s^2) on E'' is the image of P = (x, y).  The doubling formulas of a = 0 curves do not involve the
+// constant, so the chain runs on E'' from (s x, s^2, 1) unchanged, and a Jacobian point (X, Y, Z) of E'' IS the Jacobian point
+// (X, Y, y Z) of E:  x = X / (y Z)^2 = (X / Z^2) / s  and  y = Y / (y Z)^3 = y (Y / Z^3) / s^2.  The consumer (k_ps_buckets)
+// multiplies Z by y -- the sign of y included -- when it reads a shifted point; by then the decompression kernel has long finished.
+// Inputs: validated affine points (pts != null: entry points without a stage 1) or the compressed bytes themselves (a bad encoding
+// is treated as the point at infinity here; the decompression kernel raises the error).
+__global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n, int groups, G1Jac *shifts) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
     if (id >= np * groups) return;
     const int g = id / np, pt = id % np;
-    G1Affine p;
-    if (pt < 2 * n) p = pts[(size_t)g * 2 * n + pt];
-    else {
+    Fp x, s;
+    bool inf = false;
+    if (pt == 2 * n) {
         const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT;
-        for (int q = 0; q < NFP; q++) { p.x.l[q] = gx[q]; p.y.l[q] = gy[q]; }
-        fp_neg(p.y, p.y);
+        Fp y;
+        for (int q = 0; q < NFP; q++) { x.l[q] = gx[q]; y.l[q] = gy[q]; }
+        fp_sqr(s, y);
+    } else if (pts) {
+        const G1Affine p = pts[(size_t)g * 2 * n + pt];
+        inf = g1a_is_inf(p);
+        x = p.x; fp_sqr(s, p.y);
+    } else {
+        const uint8_t *src = pt < n ? cbytes + (size_t)stride * ((size_t)g * n + pt) : pbytes + (size_t)stride * ((size_t)g * n + (pt - n));
+        uint8_t b[48];
+        for (int k = 0; k < 48; k++) b[k] = src[k];
+        bool large;
+        x = fp_zero();
+        if (g1_parse_compressed(x, inf, large, b)) inf = true;
+        g1_curve_rhs(s, x);
     }
-    G1Jac acc; g1_from_affine(acc, p);
+    G1Jac acc;
+    fp_mul(acc.x, s, x); fp_sqr(acc.y, s); acc.z = fp_one();
+    if (inf) acc = g1_inf();
     G1Jac *out = shifts + (size_t)id * LC_WINDOWS;
     out[0] = acc;
 #pragma unroll 1
@@ -480,7 +503,7 @@ __device__ __forceinline__ int ps_point_of_item(int j, int n) {
 // One 256-thread workgroup per (batch, class, quarter of the buckets): 4 buckets x 64 lanes, one wave per SIMD of its CU.  (One
 // 512-thread workgroup per (batch, class) kept all 16 buckets on ONE CU: 8 waves sharing 4 SIMDs through ~26 dependent additions,
 // 0.88 ms for a lone batch; spread over four CUs the same sums take ~13 additions at one wave per SIMD.)  Writes the 16 bucket sums.
-__global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const int8_t *digits, int n, LcSlot *S) {
+__global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const G1Affine *pts, const int8_t *digits, int n, LcSlot *S) {
     __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15, grouped by bucket (this workgroup's buckets only)
     __shared__ int cnt[PS_BUCKETS_PER_WG + 1], start[PS_BUCKETS_PER_WG + 1], cursor[PS_BUCKETS_PER_WG + 1];
     const int part = blockIdx.x % PS_PARTS, gc = blockIdx.x / PS_PARTS, g = gc >> 1, cls = gc & 1, tid = threadIdx.x;
@@ -515,7 +538,14 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
     for (int q = sl; q < c; q += PS_LANES_PER_BUCKET) {
         const uint32_t v = list[s0 + q];
         const int j = lo + (int)(v & 0x3ff), w = (int)((v >> 10) & 31);
-        G1Jac p = sh[(size_t)ps_point_of_item(j, n) * LC_WINDOWS + w];
+        const int pt = ps_point_of_item(j, n);
+        G1Jac p = sh[(size_t)pt * LC_WINDOWS + w];
+        {   // the shift table holds points of E'' (k_ps_shift): Z picks up the y of the input point (zero for the point at infinity)
+            Fp y0;
+            if (pt < 2 * n) y0 = pts[(size_t)g * 2 * n + pt].y;
+            else { const uint32_t gy[NFP] = G1_GEN_Y_INIT; for (int q = 0; q < NFP; q++) y0.l[q] = gy[q]; fp_neg(y0, y0); }
+            Fp zz; fp_mul(zz, p.z, y0); p.z = zz;
+        }
         bool neg = (v & 0x8000) != 0;
         if (j & 1) { Fp bx; fp_mul(bx, p.x, beta); p.x = bx; neg = !neg; }       // the odd item of a term is -phi(P) = (beta x, -y)
         if (neg) fp_neg(p.y, p.y);
@@ -627,7 +657,12 @@ size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
     if (groups <= 0) return;
     const int total = ps_points(n_per_group) * groups;
-    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, d_pts, n_per_group, groups, d_shifts);
+    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, d_pts, (const uint8_t *)nullptr, (const uint8_t *)nullptr, 0, n_per_group, groups, d_shifts);
+}
+void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
+    if (groups <= 0) return;
+    const int total = ps_points(n_per_group) * groups;
+    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, (const G1Affine *)nullptr, d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
 }
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
                                int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st) {
@@ -638,7 +673,7 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
     hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * PS_PARTS), dim3(PS_THREADS), 0, st, d_shifts, digits, n_per_group, S);
+    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * PS_PARTS), dim3(PS_THREADS), 0, st, d_shifts, d_pts, digits, n_per_group, S);
     hipLaunchKernelGGL(k_ps_weights, dim3((2 * LC_BUCKETS * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {

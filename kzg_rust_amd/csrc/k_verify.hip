@@ -205,6 +205,18 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
     challenge_finish(hh, i, cm, proofs, z_out, records);
 }
 
+// Host-hashed form (host_sha256.h): the digests of the challenge transcripts arrive from the host (32 bytes each, big-endian as
+// SHA-256 emits them); what is left is hash_to_bls_field (utils.rs:250-258) and the record's C / z / proof fields.
+__global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *digests, const uint8_t *commitments, const uint8_t *proofs, int n_total,
+                                                              Fr *z_out, uint8_t *records) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t hh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) hh[k] = load_be32(digests + 32 * (size_t)i + 4 * k);
+    challenge_finish(hh, i, commitments + 48 * (size_t)i, proofs, z_out, records);
+}
+
 // ------------------------------------------------------------------------------------------------ evaluation
 // y = p(z) for a polynomial given by its 4096 evaluations at the (bit-reversed) roots of unity (kzg.rs:346-389).
 // The reference evaluates  y = (z^N - 1)/N * sum_i p_i w_i / (z - w_i)  with a 4096-long batch inversion and special-
@@ -510,6 +522,11 @@ void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, con
     const int wgs = (n_total + 63) / 64;
     if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
     else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+}
+void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
+                                    hipStream_t st) {
+    if (n_total <= 0) return;
+    hipLaunchKernelGGL(k_challenge_from_digest, dim3((n_total + 63) / 64), dim3(64), 0, st, d_digests, d_commitments, d_proofs, n_total, d_z, d_records);
 }
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {

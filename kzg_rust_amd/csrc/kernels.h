@@ -67,6 +67,9 @@ void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group,
 void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
+// the same records / z from digests hashed on the host (32 bytes per blob, host_sha256.h)
+void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
+                                    hipStream_t st);
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
                  uint8_t *d_records /* y written at +80; may be null */, int *d_err, hipStream_t st);
 // stage 2 (per group of n records): points from records, r-powers, lincomb, pairing
@@ -89,6 +92,8 @@ size_t lincomb_buckets_scratch_bytes(int n_per_group, int groups);
 bool lincomb_preshift_fits(int n_per_group, int groups);
 size_t lincomb_preshift_bytes(int n_per_group, int groups);
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
+// the same chains straight from the compressed inputs (x only: they do not wait for the square root of the decompression)
+void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                                int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st);
 void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)

@@ -57,6 +57,13 @@ class NoMemory(Error):
 
 
 _ERRORS = {c.code: c for c in (BadArgs, InternalError, InvalidBytesLength, InvalidHexFormat, InvalidTrustedSetup, NoDevice, NoMemory)}
+# statuses that can only describe the call as a whole (a device, allocation or library failure): a *_many call that returns one of
+# them may have left units untouched, so it is raised even when earlier units carry a per-unit status
+_WHOLE_CALL = (InternalError.code, NoDevice.code, NoMemory.code)
+
+
+def _whole_call_failed(rc, st, n):
+    return rc in _WHOLE_CALL or (rc != 0 and not any(st[i] for i in range(n)))
 
 
 def _check(rc, what):
@@ -201,6 +208,14 @@ class KzgSettings:
         could not be allocated."""
         return lib().kzg355_settings_msm_form(self.handle)
 
+    def set_host_hash(self, mode, max_blobs=0):
+        """Fiat-Shamir hashing of small host-buffer calls on host threads: mode 0 by size, 1 always, -1 never (kzg355.h)."""
+        _check(lib().kzg355_settings_set_host_hash(self.handle, mode, max_blobs), "set_host_hash")
+
+    @property
+    def host_hashed_calls(self):
+        return lib().kzg355_settings_host_hashed_calls(self.handle)
+
     def set_kernel_timing(self, enabled=True):
         lib().kzg355_set_kernel_timing(self.handle, 1 if enabled else 0)
 
@@ -293,7 +308,7 @@ class Kzg:
         out = C.create_string_buffer(48 * max(n, 1))
         st = (C.c_int * max(n, 1))()
         rc = lib().kzg355_blob_to_kzg_commitment_many(out, st, b"".join(bl), n, s.handle)
-        if rc != 0 and not any(st[i] for i in range(n)):          # the call failed as a whole (no device, out of memory, n too large)
+        if _whole_call_failed(rc, st, n):                         # no device, out of memory, n too large: nothing usable came back
             _check(rc, "blob_to_kzg_commitment_many")
         return [KzgCommitment(out.raw[48 * i:48 * i + 48]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("commit") for i in range(n)]
 
@@ -307,7 +322,7 @@ class Kzg:
         out = C.create_string_buffer(48 * max(n, 1))
         st = (C.c_int * max(n, 1))()
         rc = lib().kzg355_compute_blob_kzg_proof_many(out, st, b"".join(bl), b"".join(cs), n, s.handle)
-        if rc != 0 and not any(st[i] for i in range(n)):
+        if _whole_call_failed(rc, st, n):
             _check(rc, "compute_blob_kzg_proof_many")
         return [KzgProof(out.raw[48 * i:48 * i + 48]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("proof") for i in range(n)]
 
@@ -328,6 +343,6 @@ class Kzg:
         ok = (C.c_bool * G)()
         st = (C.c_int * G)()
         rc = lib().kzg355_verify_blob_kzg_proof_batch_many(ok, st, b"".join(flat_b), b"".join(flat_c), b"".join(flat_p), npg, G, s.handle)
-        if rc != 0 and not any(st[i] for i in range(G)):          # whole-call failure: no per-batch status was written
+        if _whole_call_failed(rc, st, G):                         # whole-call failure: the per-batch statuses are not to be trusted
             _check(rc, "verify_blob_kzg_proof_batch_many")
         return [bool(ok[i]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("verify") for i in range(G)]

@@ -163,6 +163,26 @@ int hd_w4_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be16) {
     g1_mul128_w4(r, pa, k, tab.data(), 5);
     g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
 }
+// [2^k]P computed as k_ps_shift does -- the doubling chain started from x ALONE on the curve Y^2 = X^3 + 4 s^3 (s = x^3 + 4), from
+// (s x, s^2, 1), with the y of the decompressed point multiplied into Z only at the end -- against the plain chain from (x, y, 1).
+// out = the first, ref = the second, both compressed.
+int hd_shift_from_x(uint8_t *out, uint8_t *ref, const uint8_t *p48, int k) {
+    Fp x, s; bool inf, large;
+    if (g1_parse_compressed(x, inf, large, p48)) return 1;
+    G1Affine pa; if (g1_decompress(pa, p48)) return 2;
+    G1Jac a;
+    g1_curve_rhs(s, x);
+    fp_mul(a.x, s, x); fp_sqr(a.y, s); a.z = fp_one();
+    if (inf) a = g1_inf();
+    for (int i = 0; i < k; i++) g1_dbl_lazy(a, a);
+    g1_canon_lazy(a, a);
+    Fp zz; fp_mul(zz, a.z, pa.y); a.z = zz;
+    G1Jac b; g1_from_affine(b, pa);
+    for (int i = 0; i < k; i++) g1_dbl(b, b);
+    G1Affine ra, rb; g1_to_affine(ra, a); g1_to_affine(rb, b);
+    g1_compress_affine(out, ra); g1_compress_affine(ref, rb);
+    return 0;
+}
 int hd_g2_decompress(const uint8_t *in) { G2Affine q; return g2_decompress(q, in); }
 // e(p1,q1) == e(p2,q2) via precomputed lines: ML(q1,-p1) * ML(q2,p2)
 int hd_pairings_verify(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {

@@ -334,3 +334,19 @@ def test_pairing_with_projective_arguments_and_split_miller_loops(hd, oracle, se
             got = C.c_int(-1)
             assert hd.hd_pairings_verify_coop_proj(C.byref(got), a, qa, b, qb, z) == 0
             assert got.value == want.value, (z, a.hex()[:8], b.hex()[:8])
+
+
+def test_window_shifts_started_from_x_alone(hd, setup_bytes):
+    """k_ps_shift walks its doubling chain on Y^2 = X^3 + 4 s^3 from (s x, s^2, 1) and lets the consumer multiply Z by y: same points
+    as the chain from (x, y, 1), for both signs of y, the generator, setup points and the point at infinity."""
+    import ctypes as C
+    g1, _ = setup_bytes
+    pts = [g1[48 * i:48 * i + 48] for i in (0, 1, 17, 4095)]
+    pts.append(bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"))
+    flipped = bytearray(pts[0]); flipped[0] ^= 0x20; pts.append(bytes(flipped))           # the other square root: -P
+    pts.append(bytes([0xc0]) + bytes(47))
+    for p in pts:
+        for k in (0, 1, 5, 125):
+            out, ref = C.create_string_buffer(48), C.create_string_buffer(48)
+            assert hd.hd_shift_from_x(out, ref, p, k) == 0
+            assert out.raw == ref.raw, (p.hex(), k)

@@ -1,0 +1,192 @@
+"""-m gpu: the host-buffer entry points with the Fiat-Shamir challenges hashed on the HOST (kzg_rust_amd/csrc/host_sha256.cpp,
+SURVEY 8f-4) and on the DEVICE (k_challenge*): every host-buffer parity check runs both ways.  The z_i (and y_i) of the stage-1
+records are compared byte for byte with the oracle's in both modes; the reference's vectors for the three functions that hash a
+blob (compute_blob_kzg_proof, verify_blob_kzg_proof, verify_blob_kzg_proof_batch; src/lib.rs:82-203) are replayed in both modes.
+Transcript: reference src/kzg.rs:298-339; call shape of the bench: benches/kzg_benches.rs:113-120."""
+import ctypes as C
+import os
+import threading
+
+import pytest
+
+from synth import random_blob
+from vector_harness import run_function
+
+pytestmark = pytest.mark.gpu
+
+HASHING_FUNCTIONS = {"compute_blob_kzg_proof": 14, "verify_blob_kzg_proof": 24, "verify_blob_kzg_proof_batch": 22}
+MODES = {"host": 1, "device": -1}
+
+
+@pytest.fixture(scope="module")
+def kz():
+    import kzg_rust_amd
+    return kzg_rust_amd
+
+
+@pytest.fixture(scope="module")
+def settings(kz, setup_bytes):
+    g1, g2 = setup_bytes
+    s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    yield s
+    s.free()
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from gpu_backend import ProductBackend
+    return ProductBackend()
+
+
+@pytest.fixture(scope="module")
+def batch(kz, settings):
+    blobs = [random_blob(7000 + i) for i in range(67)]
+    B = [kz.Blob(b) for b in blobs]
+    settings.set_host_hash(-1)
+    cs = kz.Kzg.blob_to_kzg_commitment_many(B, settings)
+    ps = kz.Kzg.compute_blob_kzg_proof_many(B, cs, settings)
+    settings.set_host_hash(0)
+    return blobs, [c.to_bytes() for c in cs], [p.to_bytes() for p in ps]
+
+
+def _records(kz, s, blobs, cs, ps, npg, groups):
+    L = kz.kzg.lib()
+    n = npg * groups
+    out = C.create_string_buffer(160 * n)
+    ok = (C.c_bool * groups)()
+    st = (C.c_int * groups)()
+    rc = L.kzg355_debug_verify_host_records(out, ok, st, b"".join(blobs[:n]), b"".join(cs[:n]), b"".join(ps[:n]), npg, groups, s.handle)
+    return rc, list(ok), list(st), out.raw
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("fn", list(HASHING_FUNCTIONS))
+def test_reference_vectors_both_hash_routes(mode, fn, golden_vectors, golden_blobs, backend, settings):
+    """The reference's test loop (src/lib.rs:82-203) for the functions that hash a blob, with the knob on and off."""
+    settings.set_host_hash(MODES[mode])
+    before = settings.host_hashed_calls
+    try:
+        n, failures = run_function(fn, golden_vectors, backend, settings, golden_blobs)
+    finally:
+        settings.set_host_hash(0)
+    assert n == HASHING_FUNCTIONS[fn]
+    assert not failures, "\n".join(failures)
+    took_host = settings.host_hashed_calls - before
+    assert (took_host > 0) == (mode == "host"), took_host
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_records_z_y_byte_exact_vs_oracle(mode, kz, settings, batch, oracle, oracle_settings):
+    """z_i = hash_to_bls_field(SHA-256(transcript_i)) and y_i = p_i(z_i) of every blob, byte for byte against the oracle, through the
+    host-buffer call; shapes: one batch of 64 (the bench call), 67 (a partial wave), 1 (the single-blob path), 4 batches of 16."""
+    blobs, cs, ps = batch
+    inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+    settings.set_host_hash(MODES[mode])
+    try:
+        for npg, groups in ((64, 1), (67, 1), (1, 1), (16, 4), (3, 5)):
+            before = settings.host_hashed_calls
+            rc, ok, st, rec = _records(kz, settings, blobs, cs, ps, npg, groups)
+            assert rc == 0 and ok == [True] * groups and st == [0] * groups, (npg, groups, rc, ok, st)
+            assert (settings.host_hashed_calls - before == 1) == (mode == "host")
+            for i in range(npg * groups):
+                r = rec[160 * i:160 * i + 160]
+                assert r[:48] == cs[i] and r[112:] == ps[i]
+                assert r[48:80] == inter["z"][i], f"z[{i}] ({mode}, {npg} x {groups})"
+                assert r[80:112] == inter["y"][i], f"y[{i}] ({mode}, {npg} x {groups})"
+    finally:
+        settings.set_host_hash(0)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_verdicts_and_errors_both_hash_routes(mode, kz, settings, batch, oracle, oracle_settings):
+    """Honest / swapped-proof / invalid-point / non-canonical-blob batches of odd sizes: same verdicts and same Errs either way
+    (the host route changes the order of the work -- window shifts from x alone, validation beside them -- not the answers)."""
+    blobs, cs, ps = batch
+    B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+    settings.set_host_hash(MODES[mode])
+    try:
+        for n in (2, 7, 33, 64, 65, 67):
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], Pr[:n], settings) is True
+            bad = list(Pr[:n]); bad[n - 1] = Pr[n - 2]
+            assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], bad, settings) is False
+        n = 9
+        assert oracle.verify_blob_kzg_proof_batch(blobs[:n], cs[:n], ps[:n], oracle_settings) is True
+        # a proof that is on the curve but not in the subgroup, an x that is not on the curve, a bad flag byte, the point at infinity
+        not_in_g1 = bytes.fromhex("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcde0")
+        not_on_curve = bytes.fromhex("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef")
+        for pos, badpt in ((0, not_in_g1), (n - 1, not_on_curve), (4, bytes(48)), (3, bytes([0x9a]) + b"\xff" * 47)):
+            for which in ("proof", "commitment"):
+                c2, p2 = list(Cm[:n]), list(Pr[:n])
+                if which == "proof":
+                    p2[pos] = kz.KzgProof(badpt)
+                else:
+                    c2[pos] = kz.KzgCommitment(badpt)
+                with pytest.raises(kz.BadArgs):
+                    kz.Kzg.verify_blob_kzg_proof_batch(B[:n], c2, p2, settings)
+        inf = bytes([0xc0]) + bytes(47)
+        p2 = list(Pr[:n]); p2[2] = kz.KzgProof(inf)
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], p2, settings) is False      # infinity is a valid point (utils.rs:298-301), wrong proof
+        noncanon = bytearray(blobs[1]); noncanon[32 * 77:32 * 78] = b"\xff" * 32
+        b2 = list(B[:n]); b2[1] = kz.Blob(bytes(noncanon))
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch(b2, Cm[:n], Pr[:n], settings)
+        # the all-zero blob: commitment and proof at infinity, verdict true (the reference's 0xc0.. vectors)
+        zero = kz.Blob(bytes(131072))
+        assert kz.Kzg.verify_blob_kzg_proof_batch([zero, B[0]], [kz.KzgCommitment(inf), Cm[0]], [kz.KzgProof(inf), Pr[0]], settings) is True
+        # blob proofs
+        for i in (0, 5):
+            assert kz.Kzg.compute_blob_kzg_proof(B[i], Cm[i], settings).to_bytes() == ps[i]
+        got = kz.Kzg.compute_blob_kzg_proof_many(B[:5], Cm[:5], settings)
+        assert [p.to_bytes() for p in got] == ps[:5]
+    finally:
+        settings.set_host_hash(0)
+
+
+def test_auto_mode_crossover_and_portable_sha(kz, setup_bytes, batch):
+    """mode 0 takes the host route up to the crossover only; KZG355_HOST_SHA=portable (CPUs without the SHA extensions) gives the same z."""
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    os.environ["KZG355_HOST_SHA"] = "portable"
+    os.environ["KZG355_HOST_HASH_MAX"] = "8"
+    try:
+        s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    finally:
+        del os.environ["KZG355_HOST_SHA"], os.environ["KZG355_HOST_HASH_MAX"]
+    try:
+        rc, ok, st, rec_host = _records(kz, s, blobs, cs, ps, 8, 1)
+        assert rc == 0 and ok == [True] and s.host_hashed_calls == 1
+        rc, ok, st, rec_dev = _records(kz, s, blobs, cs, ps, 9, 1)
+        assert rc == 0 and ok == [True] and s.host_hashed_calls == 1          # above the crossover: device hash
+        assert rec_host == rec_dev[:160 * 8]
+    finally:
+        s.free()
+
+
+def test_concurrent_host_hashed_calls(kz, settings, batch):
+    """Several threads on one handle: the host threads serve one call at a time, the others take the device route; verdicts hold."""
+    blobs, cs, ps = batch
+    B, Cm, Pr = [kz.Blob(b) for b in blobs], [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps]
+    settings.set_host_hash(1)
+    errors = []
+
+    def work(k):
+        try:
+            for r in range(6):
+                n = 5 + 7 * ((k + r) % 5)
+                if kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], Pr[:n], settings) is not True:
+                    errors.append((k, r, "true expected"))
+                bad = list(Pr[:n]); bad[0] = Pr[1]
+                if kz.Kzg.verify_blob_kzg_proof_batch(B[:n], Cm[:n], bad, settings) is not False:
+                    errors.append((k, r, "false expected"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        settings.set_host_hash(0)
+    assert not errors, errors
