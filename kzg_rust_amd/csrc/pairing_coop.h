@@ -47,25 +47,29 @@ constexpr uint32_t EVEN_MASK = 0x555u;
 constexpr uint32_t FULL_MASK = 0xfffu;
 
 constexpr int COOP_MAX_TERMS = 10;
-// Work schedule of one product type.  Phase 1: which limb products lane l accumulates (all for the same convolution index
-// s).  Phase 2: coefficient k = sum_j tc[k][j] * partial[tl[k][j]] + kp[k] * p  (the multiple of p keeps the value positive;
-// partials are < 1.04 p, so every coefficient stays below 32 p: the lazy bound of an Fp12W between operations).
-struct CoopSched {
-    uint8_t s[64];            // convolution index this lane works for (255: idle)
-    uint8_t np[64];           // number of (i, j) pairs, <= 3
-    uint8_t pi[64][3], pj[64][3];
-    uint8_t dbl[64];          // 1: the partial enters doubled (cross terms a_i a_j, i < j, of a square)
+constexpr int COOP_T_FULL = 9, COOP_T_SPARSE = 6;       // terms per coefficient the combination walks: product / square <= 9; line product, cyclotomic square <= 6
+// Phase 2 of a product type (the "combination"): coefficient k = sum_t coef[k][t] * partial[lane[k][t]] + kp[k] * p.  The multiple
+// of p keeps the value positive -- one more p than the negative terms need, so that the value is at least p and the top limb of the
+// limb-parallel form below can never go negative; partials are < 1.04 p, so every coefficient stays below 32 p: the lazy bound of an
+// Fp12W between operations.
+struct CoopComb {
+    uint32_t term[12][COOP_MAX_TERMS];   // (lane << 8) | (coef & 0xff); unused entries are 0 (coefficient 0 times the partial of lane 0)
     uint8_t nt[12], kp[12];
-    uint8_t tl[12][COOP_MAX_TERMS];
-    int8_t tc[12][COOP_MAX_TERMS];
+    uint32_t nmax;                       // the largest nt: the uniform trip count of the combination
+};
+// Work schedule of one product type.  Phase 1: which limb products lane l accumulates (all for the same convolution index s),
+// packed into one word: bits 0-1 the number of (i, j) pairs (<= 3; 0: idle), bit 2 "the partial enters doubled" (cross terms
+// a_i a_j, i < j, of a square), then i and j of pair k in bits 4 + 8k .. 7 + 8k and 8 + 8k .. 11 + 8k.
+struct CoopSched {
+    uint8_t s[64];            // convolution index this lane works for (255: idle); construction and tests only
+    uint32_t prog[64];
+    CoopComb comb;
 };
 // Granger-Scott squaring: lane l multiplies  (U[a0] + fa U[a1]) * (U[b0] + fb U[b1])  with fa, fb in {0, 1, 2} and
-// U = (a_0 .. a_11, 2, 0); phase 2 as above.
+// U = (a_0 .. a_11, 2, 0); prog[l]: bit 0 active, a0 bits 1-4, a1 5-8, fa 9-10, b0 11-14, b1 15-18, fb 19-20.
 struct CoopCycSched {
-    uint8_t act[64], a0[64], a1[64], fa[64], b0[64], b1[64], fb[64];
-    uint8_t nt[12], kp[12];
-    uint8_t tl[12][COOP_MAX_TERMS];
-    int8_t tc[12][COOP_MAX_TERMS];
+    uint32_t prog[64];
+    CoopComb comb;
 };
 struct CoopScheds { CoopSched mul, sqr, line; CoopCycSched cyc; };
 static_assert(sizeof(CoopScheds) % 4 == 0, "copied to LDS word by word");
@@ -75,15 +79,42 @@ struct CoopMem {
     Fp cyc_consts[2];         // 2 (Montgomery form) and 0: entries 12, 13 of the cyclotomic squaring's operand table; must follow line[]
     Fp red[64];               // the reduced partial of every lane (phase 1 -> phase 2)
     Fp px[2], py[2], pz[2];   // the two G1 arguments as (X Z, Y, Z^3) (g1.h: PairPt)
+    uint32_t pmod[16];        // the limbs of p (the combination indexes them by lane)
     CoopScheds sc;
     int flag;
 };
 
+inline void coop_comb_clear(CoopComb &cb) {
+    for (int k = 0; k < 12; k++) { cb.nt[k] = 0; cb.kp[k] = 0; for (int t = 0; t < COOP_MAX_TERMS; t++) cb.term[k][t] = 0; }
+    cb.nmax = 0;
+}
+inline bool coop_comb_term(CoopComb &cb, int k, int lane, int coef) {
+    const int n = cb.nt[k];
+    if (n >= COOP_MAX_TERMS) return false;
+    cb.term[k][n] = ((uint32_t)lane << 8) | ((uint32_t)coef & 0xffu);
+    cb.nt[k] = (uint8_t)(n + 1);
+    return true;
+}
+// multiples of p and the bound check: partials are < 1.04 p; coefficient < 31 p
+inline bool coop_comb_finish(CoopComb &cb) {
+    bool ok = true;
+    cb.nmax = 0;
+    for (int k = 0; k < 12; k++) {
+        int neg = 0, pos = 0;
+        for (int t = 0; t < cb.nt[k]; t++) { const int c = (int)(int8_t)(cb.term[k][t] & 0xffu); if (c < 0) neg -= c; else pos += c; }
+        const int K = (neg * 105 + 99) / 100 + 1;
+        cb.kp[k] = (uint8_t)K;
+        if (pos * 105 + K * 100 >= 3100) ok = false;
+        if (cb.nt[k] > cb.nmax) cb.nmax = cb.nt[k];
+    }
+    return ok;
+}
+
 // Phase-2 tables of a product schedule from its lane -> convolution index map, with the bound check.
 inline bool coop_finish_sched(CoopSched &sc) {
     bool ok = true;
+    coop_comb_clear(sc.comb);
     for (int k = 0; k < 12; k++) {
-        int n = 0, neg = 0, pos = 0;
         for (int l = 0; l < 64; l++) {
             const int s = sc.s[l];
             if (s == 255) continue;
@@ -92,16 +123,10 @@ inline bool coop_finish_sched(CoopSched &sc) {
             else if (k <= 5) coef = s == k + 12 ? -2 : s == k + 18 ? -4 : 0;
             else coef = (s == k + 12 || s == k + 6) ? 2 : 0;
             if (!coef) continue;
-            if (n == COOP_MAX_TERMS) { ok = false; break; }
-            sc.tl[k][n] = (uint8_t)l; sc.tc[k][n] = (int8_t)coef; n++;
-            if (coef < 0) neg -= coef; else pos += coef;
+            ok = coop_comb_term(sc.comb, k, l, coef) && ok;
         }
-        sc.nt[k] = (uint8_t)n;
-        const int K = (neg * 105 + 99) / 100;                    // partials are < 1.04 p
-        sc.kp[k] = (uint8_t)K;
-        if (pos * 105 + K * 100 >= 3100) ok = false;             // coefficient < 31 p
     }
-    return ok;
+    return coop_comb_finish(sc.comb) && ok;
 }
 // Schedules: convolution index s of a full product has c_s = min(s, 22 - s) + 1 limb products; it gets ceil(c_s / 3)
 // lanes (56 lanes in all).  A square has floor(c_s / 2) cross products (2 per lane, doubled) plus a_{s/2}^2 on a lane of
@@ -109,7 +134,12 @@ inline bool coop_finish_sched(CoopSched &sc) {
 inline bool build_coop_schedules(CoopScheds &out) {
     CoopSched &mul = out.mul, &sqr = out.sqr, &lin = out.line;
     for (CoopSched *sc : {&mul, &sqr, &lin})
-        for (int l = 0; l < 64; l++) { sc->s[l] = 255; sc->np[l] = 0; sc->dbl[l] = 0; for (int k = 0; k < 3; k++) sc->pi[l][k] = sc->pj[l][k] = 0; }
+        for (int l = 0; l < 64; l++) { sc->s[l] = 255; sc->prog[l] = 0; }
+    // pair k of lane l (k = the lane's current count)
+    auto add_pair = [](CoopSched &sc, int l, int i, int j, bool dbl) {
+        const int k = (int)(sc.prog[l] & 3u);
+        sc.prog[l] = (sc.prog[l] & ~3u) | (uint32_t)(k + 1) | (dbl ? 4u : 0u) | ((uint32_t)i << (4 + 8 * k)) | ((uint32_t)j << (8 + 8 * k));
+    };
     bool ok = true;
     int lane = 0;
     for (int s = 0; s < 23; s++) {
@@ -118,7 +148,8 @@ inline bool build_coop_schedules(CoopScheds &out) {
             const int j = s - i;
             if (j < 0 || j > 11) continue;
             if (k == 3) { lane++; k = 0; }
-            mul.s[lane] = (uint8_t)s; mul.pi[lane][k] = (uint8_t)i; mul.pj[lane][k] = (uint8_t)j; mul.np[lane] = (uint8_t)(++k);
+            if (lane < 64) { mul.s[lane] = (uint8_t)s; add_pair(mul, lane, i, j, false); }
+            k++;
         }
         lane++;
     }
@@ -130,12 +161,13 @@ inline bool build_coop_schedules(CoopScheds &out) {
             const int j = s - i;
             if (j <= i || j > 11) continue;
             if (k == 2) { lane++; k = 0; }
-            sqr.s[lane] = (uint8_t)s; sqr.pi[lane][k] = (uint8_t)i; sqr.pj[lane][k] = (uint8_t)j; sqr.np[lane] = (uint8_t)(++k); sqr.dbl[lane] = 1;
+            if (lane < 64) { sqr.s[lane] = (uint8_t)s; add_pair(sqr, lane, i, j, true); }
+            k++;
             any = true;
         }
         if (any) lane++;
         if (!(s & 1)) {
-            sqr.s[lane] = (uint8_t)s; sqr.pi[lane][0] = sqr.pj[lane][0] = (uint8_t)(s >> 1); sqr.np[lane] = 1; sqr.dbl[lane] = 0;
+            if (lane < 64) { sqr.s[lane] = (uint8_t)s; add_pair(sqr, lane, s >> 1, s >> 1, false); }
             lane++;
         }
     }
@@ -147,7 +179,8 @@ inline bool build_coop_schedules(CoopScheds &out) {
             const int j = s - i;
             if (j < 0 || j > 11 || !((LINE_MASK >> j) & 1u)) continue;
             if (k == 2) { lane++; k = 0; }
-            lin.s[lane] = (uint8_t)s; lin.pi[lane][k] = (uint8_t)i; lin.pj[lane][k] = (uint8_t)j; lin.np[lane] = (uint8_t)(++k);
+            if (lane < 64) { lin.s[lane] = (uint8_t)s; add_pair(lin, lane, i, j, false); }
+            k++;
             any = true;
         }
         if (any) lane++;
@@ -166,9 +199,9 @@ inline bool build_coop_schedules(CoopScheds &out) {
     //   t = 2:  a_4', a_10' as the first two rows;  a_1' = -12P7 - 12P8 + E1,  a_7' = 6P5 - 6P6 + 6P7 + 6P8 + E7
     // (checked against the generic square by tests/test_device_math_host.py).
     CoopCycSched &cy = out.cyc;
-    for (int l = 0; l < 64; l++) { cy.act[l] = 0; cy.a0[l] = cy.a1[l] = cy.b0[l] = cy.b1[l] = 13; cy.fa[l] = cy.fb[l] = 0; }
+    for (int l = 0; l < 64; l++) cy.prog[l] = 0;
     auto prod = [&](int l, int a0, int a1, int fa, int b0, int b1, int fb) {
-        cy.act[l] = 1; cy.a0[l] = (uint8_t)a0; cy.a1[l] = (uint8_t)a1; cy.fa[l] = (uint8_t)fa; cy.b0[l] = (uint8_t)b0; cy.b1[l] = (uint8_t)b1; cy.fb[l] = (uint8_t)fb;
+        cy.prog[l] = 1u | ((uint32_t)a0 << 1) | ((uint32_t)a1 << 5) | ((uint32_t)fa << 9) | ((uint32_t)b0 << 11) | ((uint32_t)b1 << 15) | ((uint32_t)fb << 19);
     };
     for (int t = 0; t < 3; t++) {
         const int a = t, b = t + 6, c = t + 3, d = t + 9, l = 8 * t;
@@ -182,8 +215,8 @@ inline bool build_coop_schedules(CoopScheds &out) {
         prod(l + 7, b, 13, 0, c, d, 1);     // P8
     }
     for (int k = 0; k < 12; k++) prod(24 + k, k, 13, 0, 12, 13, 0);       // E_k = 2 a_k
-    for (int k = 0; k < 12; k++) cy.nt[k] = 0;
-    auto term = [&](int k, int l, int coef) { const int n = cy.nt[k]; if (n < COOP_MAX_TERMS) { cy.tl[k][n] = (uint8_t)l; cy.tc[k][n] = (int8_t)coef; } else ok = false; cy.nt[k] = (uint8_t)(n + 1); };
+    coop_comb_clear(cy.comb);
+    auto term = [&](int k, int l, int coef) { ok = coop_comb_term(cy.comb, k, l, coef) && ok; };
     const int lo_of[3] = {0, 2, 4}, hi_of[3] = {6, 8, 10};
     for (int t = 0; t < 3; t++) {
         const int l = 8 * t, lo = lo_of[t], hi = hi_of[t];
@@ -197,13 +230,8 @@ inline bool build_coop_schedules(CoopScheds &out) {
     }
     term(1, 16 + 6, -12); term(1, 16 + 7, -12); term(1, 24 + 1, 1);
     term(7, 16 + 4, 6); term(7, 16 + 5, -6); term(7, 16 + 6, 6); term(7, 16 + 7, 6); term(7, 24 + 7, 1);
-    for (int k = 0; k < 12; k++) {
-        int neg = 0, pos = 0;
-        for (int j = 0; j < cy.nt[k] && j < COOP_MAX_TERMS; j++) { if (cy.tc[k][j] < 0) neg -= cy.tc[k][j]; else pos += cy.tc[k][j]; }
-        const int K = (neg * 105 + 99) / 100;
-        cy.kp[k] = (uint8_t)K;
-        if (pos * 105 + K * 100 >= 3100) ok = false;
-    }
+    ok = coop_comb_finish(cy.comb) && ok;
+    ok = ok && mul.comb.nmax <= (uint32_t)COOP_T_FULL && sqr.comb.nmax <= (uint32_t)COOP_T_FULL && lin.comb.nmax <= (uint32_t)COOP_T_SPARSE && cy.comb.nmax <= (uint32_t)COOP_T_SPARSE;
     return ok;
 }
 
@@ -252,49 +280,85 @@ KZG_HD void wide_reduce(Fp &r, uint64_t *acc) {
 }
 
 // ---------------------------------------------------------------------------------- cooperative Fp12 operations
-// phase 2 of every product: out = sum_j coef_j * red[lane_j] + K p, limb-wise in signed 64-bit columns, one carry sweep.
-// The value is in [0, 31 p) by construction of the schedules, so the top limb keeps a small non-negative excess.
-KZG_HD void coop_combine(Fp &out, const Fp *red, const uint8_t *lanes, const int8_t *coefs, int n, int K) {
-    const uint32_t m[NFP] = FP_MOD_INIT;
-    int64_t acc[NFP];
+// Phase 2 of every product, LIMB-parallel: lane (k, j) forms limb j of coefficient k,
+//     acc_j = bias_j + sum_t coef_t * red[lane_t].l[j]        (one v_mad_i64_i32 per term),
+// where the bias is K p written so that every limb below the top one is large -- K p_j + 2^35 at limb j < 13, the 2^35 taken back
+// as 2^6 from limb j + 1 -- which keeps acc_j >= 0 whatever the negative terms (< 26 * 2^29 in all).  One carry step to the
+// neighbouring lane (a DPP row shift on the device) then leaves limbs in [0, 2^29 + 2^7): "almost normalised", which is all the
+// 64-bit product columns of the next operation need (14 * (2^29 + 2^7)^2 < 2^62); the top limb keeps the excess, and is >= 12
+// because the value is >= p (CoopComb).  Rows of 16 lanes hold one coefficient (limbs 0..13, two idle lanes), four coefficients per
+// pass, three passes: ~4 instructions per term instead of a 14-limb sweep per term on 12 lanes.
+// T: compile-time number of terms walked (>= the schedule's nmax; unused entries have coefficient 0): a fixed-length, fully unrolled
+// body lets all table entries and then all partial limbs be fetched back to back -- a loop pays two dependent LDS round trips per term.
+template <int T> KZG_HD void coop_combine_all(CoopMem &m, const CoopComb &cb, Fp12W &dst) {
+    COOP_LANES(lane) {
+        const int kq = lane >> 4, jr = lane & 15, j = jr < NFP ? jr : NFP - 1;
+        uint32_t e[3][T];
+        int32_t v[3][T];
+        int32_t kp[3];
 #pragma unroll
-    for (int i = 0; i < NFP; i++) acc[i] = (int64_t)K * (int64_t)m[i];
-    for (int j = 0; j < n; j++) {
-        const Fp &v = red[lanes[j]];
-        const int32_t c = coefs[j];                               // 32 x 32 -> 64 signed products: one v_mad_i64_i32 per limb
+        for (int q = 0; q < 3; q++) {
+            kp[q] = (int32_t)cb.kp[4 * q + kq];
 #pragma unroll
-        for (int i = 0; i < NFP; i++) acc[i] += (int64_t)c * (int64_t)(int32_t)v.l[i];
+            for (int t = 0; t < T; t++) e[q][t] = cb.term[4 * q + kq][t];
+        }
+        const int64_t pj = (int64_t)m.pmod[j];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int t = 0; t < T; t++) v[q][t] = (int32_t)m.red[e[q][t] >> 8].l[j];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int k = 4 * q + kq;
+            int64_t acc = (int64_t)kp[q] * pj + (j < NFP - 1 ? ((int64_t)1 << 35) : 0) - (j > 0 ? 64 : 0);
+#pragma unroll
+            for (int t = 0; t < T; t++) acc += (int64_t)(int32_t)(int8_t)(e[q][t] & 0xffu) * (int64_t)v[q][t];       // 32 x 32 -> 64 signed: one v_mad_i64_i32
+            const uint32_t hi = (uint32_t)(acc >> LB);                                    // < 2^7 below the top limb
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+#else
+            uint32_t hp = 0;
+            if (jr > 0 && jr < NFP) {                                                     // the neighbouring lane's carry, recomputed
+                int64_t a2 = (int64_t)kp[q] * (int64_t)m.pmod[jr - 1] + ((int64_t)1 << 35) - (jr - 1 > 0 ? 64 : 0);
+                for (int t = 0; t < T; t++) a2 += (int64_t)(int32_t)(int8_t)(e[q][t] & 0xffu) * (int64_t)(int32_t)m.red[e[q][t] >> 8].l[jr - 1];
+                hp = (uint32_t)(a2 >> LB);
+            }
+#endif
+            const uint32_t out = (jr < NFP - 1 ? ((uint32_t)acc & LMASK) : (uint32_t)acc) + (jr > 0 ? hp : 0u);
+            if (jr < NFP) dst.c[k].l[jr] = out;
+        }
     }
-    int64_t cy = 0;
+    COOP_SYNC();
+}
+// limbs of a lazy coefficient -> normalised (below 2^29 except the top one); in front of routines that assume normalised limbs
+KZG_HD void fp_norm_lz(Fp &r, const Fp &a) {
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) {
-        const int64_t t = acc[i] + cy;
-        if (i < NFP - 1) { out.l[i] = (uint32_t)t & LMASK; cy = t >> LB; }
-        else out.l[i] = (uint32_t)t;
-    }
+    for (int i = 0; i < NFP; i++) { const uint32_t t = a.l[i] + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
 }
 
 // dst = a * b (sc = mul / line schedule; for the line schedule b has non-zero coefficients only at w^{0,2,3,6,8,9}) or, with
 // sc = the square schedule and b = a, dst = a^2.  bmask: coefficients of b known to be zero are skipped.  dst may alias a or b.
 KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
     COOP_LANES(lane) {
-        if (sc.s[lane] != 255) {
+        const uint32_t pg = sc.prog[lane];
+        const int np = (int)(pg & 3u);
+        if (np) {
             uint64_t acc[2 * NFP];
             wide_zero(acc);
-            const int np = sc.np[lane];
             for (int k = 0; k < np; k++) {
-                const int i = sc.pi[lane][k], j = sc.pj[lane][k];
+                const int i = (int)((pg >> (4 + 8 * k)) & 15u), j = (int)((pg >> (8 + 8 * k)) & 15u);
                 if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, b.c[j].l);
             }
             wide_carry(acc);
-            if (sc.dbl[lane]) wide_double(acc);                  // columns < 2^29 after the carry sweep
+            if (pg & 4u) wide_double(acc);                       // columns < 2^29 after the carry sweep
             Fp r; wide_reduce(r, acc);
             m.red[lane] = r;
         }
     }
     COOP_SYNC();
-    COOP_LANES(lane) { if (lane < 12) coop_combine(dst.c[lane], m.red, sc.tl[lane], sc.tc[lane], sc.nt[lane], sc.kp[lane]); }
-    COOP_SYNC();
+    if (&sc == &m.sc.line) coop_combine_all<COOP_T_SPARSE>(m, sc.comb, dst); else coop_combine_all<COOP_T_FULL>(m, sc.comb, dst);
 }
 KZG_HD void coop_mul(CoopMem &m, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) { coop_product(m, m.sc.mul, dst, a, b, bmask); }
 KZG_HD void coop_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) { coop_product(m, m.sc.sqr, dst, a, a, FULL_MASK); }
@@ -303,20 +367,24 @@ KZG_HD void coop_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) { coop_product(m, m
 KZG_HD void coop_cyc_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
     const CoopCycSched &sc = m.sc.cyc;
     COOP_LANES(lane) {
-        if (sc.act[lane]) {
+        const uint32_t pg = sc.prog[lane];
+        if (pg & 1u) {
             const Fp *U = a.c;                                   // entries 12, 13 come from m.cyc_consts
             auto get = [&](int idx) -> const Fp & { return idx < 12 ? U[idx] : m.cyc_consts[idx - 12]; };
-            auto operand = [&](Fp &o, int i0, int i1, int f) {
-                Fp t = get(i1), t2;
-                fp_add_lz(t2, t, t);
-                fp_select(t, f == 2, t, t2);
-                const Fp z = fp_zero();
-                fp_select(t, f == 0, t, z);
-                fp_add_lz(o, get(i0), t);
+            // o = U[i0] + f U[i1], f in {0, 1, 2}: limbs normalised below the top one
+            auto operand = [&](Fp &o, int i0, int i1, uint32_t f) {
+                const Fp &x = get(i0), &y = get(i1);
+                const uint32_t sh = f >> 1, keep = f ? 0xffffffffu : 0u;
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < NFP; i++) {
+                    const uint32_t t = x.l[i] + ((y.l[i] << sh) & keep) + c;
+                    if (i < NFP - 1) { c = t >> LB; o.l[i] = t & LMASK; } else o.l[i] = t;
+                }
             };
             Fp x, y;
-            operand(x, sc.a0[lane], sc.a1[lane], sc.fa[lane]);
-            operand(y, sc.b0[lane], sc.b1[lane], sc.fb[lane]);
+            operand(x, (int)((pg >> 1) & 15u), (int)((pg >> 5) & 15u), (pg >> 9) & 3u);
+            operand(y, (int)((pg >> 11) & 15u), (int)((pg >> 15) & 15u), (pg >> 19) & 3u);
             uint64_t acc[2 * NFP];
             wide_zero(acc);
             wide_mac(acc, x.l, y.l);
@@ -326,8 +394,7 @@ KZG_HD void coop_cyc_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
         }
     }
     COOP_SYNC();
-    COOP_LANES(lane) { if (lane < 12) coop_combine(dst.c[lane], m.red, sc.tl[lane], sc.tc[lane], sc.nt[lane], sc.kp[lane]); }
-    COOP_SYNC();
+    coop_combine_all<COOP_T_SPARSE>(m, sc.comb, dst);
 }
 
 KZG_HD void coop_copy(Fp12W &dst, const Fp12W &a) {
@@ -374,7 +441,7 @@ KZG_HD bool coop_is_one(CoopMem &m, const Fp12W &a) {
     COOP_LANES(lane) {
         if (lane < 12) {
             const Fp want = lane == 0 ? fp_one() : fp_zero();
-            Fp c; fp_canon64(c, a.c[lane]);
+            Fp c; fp_norm_lz(c, a.c[lane]); fp_canon64(c, c);
             if (!fp_eq(c, want)) m.flag = 0;
         }
     }
@@ -389,7 +456,7 @@ KZG_HD void coop_fp6_inv(Fp12W &x) {
             Fp6 n, ni;
             Fp2 *nc[3] = {&n.c0, &n.c1, &n.c2};
             for (int j = 0; j < 3; j++) {              // (x0 + x1 u) v^j  <-  w^(2j): x0 - x1, w^(2j+6): x1   (lazy -> canonical first)
-                Fp lo, hi; fp_canon64(lo, x.c[2 * j]); fp_canon64(hi, x.c[2 * j + 6]);
+                Fp lo, hi; fp_norm_lz(lo, x.c[2 * j]); fp_canon64(lo, lo); fp_norm_lz(hi, x.c[2 * j + 6]); fp_canon64(hi, hi);
                 nc[j]->c1 = hi;
                 fp_add(nc[j]->c0, lo, hi);
             }
@@ -488,6 +555,7 @@ KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const PairPt &p1, co
             m.cyc_consts[0] = two; m.cyc_consts[1] = fp_zero();
         }
         if (lane < 24) { m.line[lane / 12].c[lane % 12] = fp_zero(); }
+        if (lane < 16) { const uint32_t pm[NFP] = FP_MOD_INIT; uint32_t v = 0; for (int i = 0; i < NFP; i++) if (i == lane) v = pm[i]; m.pmod[lane] = v; }
     }
     COOP_SYNC();
 }
