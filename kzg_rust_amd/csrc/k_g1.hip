@@ -460,9 +460,59 @@ __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }           
 // multiplies Z by y -- the sign of y included -- when it reads a shifted point; by then the decompression kernel has long finished.
 // Inputs: validated affine points (pts != null: entry points without a stage 1) or the compressed bytes themselves (a bad encoding
 // is treated as the point at infinity here; the decompression kernel raises the error).
-__global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n, int groups, G1Jac *shifts) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
-    if (id >= np * groups) return;
+// The chain itself is walked by FOUR lanes per point (a DPP quad).  A lone wave issues one instruction per ~5 cycles whatever it is,
+// so a doubling costs its instruction count: 5 squarings + 2 products in a row on one lane (dbl-2009-l).  Its products come in three
+// dependent stages, and within a stage they are independent:
+//     stage 1:  A = X^2,  B = Y^2,  S = (Y + Z)^2,  ZZ = Z^2          (four lanes, one squaring each;  Z3 = S - B - ZZ = 2 Y Z)
+//     stage 2:  F = (3A)^2,  C = B^2,  G = (X + B)^2                   (three lanes;  D = 2 (G - A - C),  X3 = F - 2D)
+//     stage 3:  E (D - X3)                                             (every lane for itself;  Y3 = E (D - X3) - 8C)
+// so the quad runs ONE squaring body per stage, each lane on its own operand (picked by v_cndmask), and the results are broadcast with
+// quad_perm DPP moves: 2 squarings + 1 product deep instead of 5 + 2.  All four lanes carry the same (X, Y, Z) and do the cheap linear
+// steps redundantly.  Lazy bounds as in g1_dbl_lazy (g1.h): in X, Y, Z < 32p, out X < 26p, Y < 18p, Z < 6p.
+template <int K> __device__ __forceinline__ Fp fp_quad_bcast(const Fp &v) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55 /* quad_perm: [K, K, K, K] */, 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ void fp_mul3_lz(Fp &r, const Fp &a) {        // 3a, limbs normalised
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { const uint32_t t = 3u * a.l[i] + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
+}
+__device__ __forceinline__ void fp_mul8_lz(Fp &r, const Fp &a) {        // 8a, limbs normalised (a's limbs below the top one < 2^29)
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) { const uint32_t t = (a.l[i] << 3) + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
+}
+__device__ __forceinline__ void g1_dbl_quad(G1Jac &p, int role) {
+    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT, m16[NFP] = FP_MOD16_INIT, m32[NFP] = FP_MOD32_INIT;
+    Fp u, r, t, v;
+    fp_add_lz(t, p.y, p.z);                                       // Y + Z                           < 64p
+    fp_select(u, role == 1, p.x, p.y); fp_select(u, role == 2, u, t); fp_select(u, role == 3, u, p.z);
+    fp_sqr_lz(r, u);
+    const Fp A = fp_quad_bcast<0>(r), B = fp_quad_bcast<1>(r), S = fp_quad_bcast<2>(r), ZZ = fp_quad_bcast<3>(r);
+    Fp Z3; fp_sub_lz(t, S, B, m2); fp_sub_lz(Z3, t, ZZ, m2);     // S - B - ZZ + 4p                 in (0, 6p)
+    Fp E; fp_mul3_lz(E, A);                                       // E = 3A                          < 4p
+    fp_add_lz(t, p.x, B);                                         // X + B                           < 34p
+    fp_select(u, role == 1, E, B); fp_select(u, role == 2, u, t);
+    fp_sqr_lz(r, u);
+    const Fp F = fp_quad_bcast<0>(r), C = fp_quad_bcast<1>(r), G = fp_quad_bcast<2>(r);
+    fp_sub_lz(t, G, A, m2); fp_sub_lz(v, t, C, m2);               // G - A - C + 4p                  in (0, 6p)
+    Fp D; fp_add_lz(D, v, v);                                     // D                               < 12p
+    Fp X3; fp_sub_lz(t, F, D, m16); fp_sub_lz(X3, t, D, m8);      // F - 2D + 24p                    in (0, 26p)
+    fp_sub_lz(t, D, X3, m32);                                     // D - X3 + 32p                    in (6p, 44p)
+    Fp Y3; fp_mul_lz(Y3, E, t);
+    fp_mul8_lz(v, C);                                             // 8C                              < 9p
+    fp_sub_lz(p.y, Y3, v, m16);                                   //                                 in (0, 18p)
+    p.x = X3; p.z = Z3;
+}
+constexpr int PS_SHIFT_THREADS = 256;
+__global__ void __launch_bounds__(PS_SHIFT_THREADS) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n, int groups, G1Jac *shifts) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
+    const int role = tid & 3;
+    const bool live = (tid >> 2) < np * groups;
+    const int id = live ? (tid >> 2) : np * groups - 1;           // idle quads redo the last point (every lane takes part in the DPP moves)
     const int g = id / np, pt = id % np;
     Fp x, s;
     bool inf = false;
@@ -488,11 +538,16 @@ __global__ void __launch_bounds__(64) k_ps_shift(const G1Affine *pts, const uint
     fp_mul(acc.x, s, x); fp_sqr(acc.y, s); acc.z = fp_one();
     if (inf) acc = g1_inf();
     G1Jac *out = shifts + (size_t)id * LC_WINDOWS;
-    out[0] = acc;
+    if (live && role == 0) out[0] = acc;
 #pragma unroll 1
     for (int k = 1; k <= LC_BITS * (LC_WINDOWS - 1); k++) {
-        g1_dbl_lazy(acc, acc);
-        if (k % LC_BITS == 0) { G1Jac c; g1_canon_lazy(c, acc); out[k / LC_BITS] = c; acc = c; }
+        g1_dbl_quad(acc, role);
+        if (k % LC_BITS == 0) {                                   // window boundary: lane r of the quad makes coordinate r canonical and stores it
+            Fp c; fp_select(c, role == 1, acc.x, acc.y); fp_select(c, role == 2, c, acc.z);
+            fp_canon64(c, c);
+            Fp *dst = &out[k / LC_BITS].x + (role < 3 ? role : 0);
+            if (live && role < 3) *dst = c;
+        }
     }
 }
 // item j of a batch -> index of its point in the shift table (items 2t, 2t+1 belong to term t; see k_lc_prep)
@@ -657,12 +712,12 @@ size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
     if (groups <= 0) return;
     const int total = ps_points(n_per_group) * groups;
-    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, d_pts, (const uint8_t *)nullptr, (const uint8_t *)nullptr, 0, n_per_group, groups, d_shifts);
+    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, d_pts, (const uint8_t *)nullptr, (const uint8_t *)nullptr, 0, n_per_group, groups, d_shifts);
 }
 void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
     if (groups <= 0) return;
     const int total = ps_points(n_per_group) * groups;
-    hipLaunchKernelGGL(k_ps_shift, dim3((total + 63) / 64), dim3(64), 0, st, (const G1Affine *)nullptr, d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
+    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, (const G1Affine *)nullptr, d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
 }
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
                                int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st) {

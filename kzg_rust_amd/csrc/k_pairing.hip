@@ -36,13 +36,17 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairP
 __global__ void __launch_bounds__(128) k_pairing_coop2(const PairPt *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
                                                        const FrobTables *frob, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
     __shared__ CoopMem mems[2];
+    __shared__ Fp pre[2 * N_LINES * 6];                           // every line of both pairs evaluated at its point, ahead of the loops
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x;
     CoopMem &m = mems[wid];
     const PairPt p1 = pair_pts[2 * (size_t)g], p2 = pair_pts[2 * (size_t)g + 1];
     const bool use1 = !fp_is_zero(p1.az) && !lines_inf[2], use2 = !fp_is_zero(p2.az) && !lines_inf[0];      // e(P, infinity) = e(infinity, Q) = 1
     const LineW *lines1 = lines_w + 2 * N_LINES, *lines2 = lines_w;      // lines_w[2] = setup g2[1] = [tau]G2 ; lines_w[0] = G2 generator
     coop_init(m, scheds, p1, p2);
-    coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && use1, wid == 1 && use2, *frob);
+#pragma unroll 1
+    for (int item = threadIdx.x; item < 2 * N_LINES * 6; item += 128) coop_eval_lines_item(pre, item, lines1, lines2, p1, p2);
+    __syncthreads();
+    coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && use1, wid == 1 && use2, *frob, pre);
     __syncthreads();                                              // both waves reach this; wave 1 is done afterwards
     if (wid == 1) return;
     if (lane < 12) m.t0.c[lane] = mems[1].f.c[lane];

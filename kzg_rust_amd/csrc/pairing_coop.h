@@ -351,8 +351,9 @@ KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12
                 const int i = (int)((pg >> (4 + 8 * k)) & 15u), j = (int)((pg >> (8 + 8 * k)) & 15u);
                 if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, b.c[j].l);
             }
-            wide_carry(acc);
-            if (pg & 4u) wide_double(acc);                       // columns < 2^29 after the carry sweep
+            // no carry sweep in front of the reduction: with limbs < 2^29 + 2^7 three products leave every column below 42 * 2^58, a doubled
+            // pair of cross products below 56 * 2^58, and the reduction adds at most 14 * 2^58 + 2^35: < 2^64 either way
+            if (pg & 4u) wide_double(acc);
             Fp r; wide_reduce(r, acc);
             m.red[lane] = r;
         }
@@ -388,7 +389,6 @@ KZG_HD void coop_cyc_sqr(CoopMem &m, Fp12W &dst, const Fp12W &a) {
             uint64_t acc[2 * NFP];
             wide_zero(acc);
             wide_mac(acc, x.l, y.l);
-            wide_carry(acc);
             Fp r; wide_reduce(r, acc);
             m.red[lane] = r;
         }
@@ -559,7 +559,9 @@ KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const PairPt &p1, co
     }
     COOP_SYNC();
 }
-KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const LineW *lines1, const LineW *lines2, bool use1, bool use2, const FrobTables &ft) {
+// pre (or null): the line evaluations of both pairs made ahead of the loop, [pair][line][l0, l6, l2, l8, l3, l9 at the point] (coop_eval_lines)
+KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const LineW *lines1, const LineW *lines2, bool use1, bool use2, const FrobTables &ft,
+                     const Fp *pre = nullptr) {
     if (pc1 <= pc0) return;
     CoopInsn nxt = prog[pc0];
     for (int pc = pc0; pc < pc1; pc++) {
@@ -579,6 +581,17 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             case OP_CYC_SQR: coop_cyc_sqr(m, dst, a); break;
             case OP_LINE_EVAL: {
                 const int n = in.a;
+                if (pre) {                                  // evaluated ahead of the loop: fetch
+                    COOP_LANES(lane) {
+                        if (lane < 12) {
+                            const int q = lane / 6, e = lane % 6;
+                            const int dst_k = e == 0 ? 0 : e == 1 ? 6 : e == 2 ? 2 : e == 3 ? 8 : e == 4 ? 3 : 9;
+                            m.line[q].c[dst_k] = pre[(q * N_LINES + n) * 6 + e];
+                        }
+                    }
+                    COOP_SYNC();
+                    break;
+                }
                 COOP_LANES(lane) {                          // evaluate both lines at their points, scaled by Z^3: 12 products on 12 lanes,
                     if (lane < 12) {                        // ONE product body for all of them (operands picked per lane, no divergent arms)
                         const int q = lane / 6, e = lane % 6;
@@ -600,6 +613,18 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             default: coop_copy(dst, a); break;
         }
     }
+}
+// All 2 x 68 line evaluations at once, ahead of the Miller loop (they depend on the points only; inside the loop each one is a
+// dependent ~650-instruction step): item (q, n, e) = coefficient e of line n of pair q times its argument, items dealt to `nthreads`
+// threads.  out: [2][N_LINES][6].
+KZG_HD void coop_eval_lines_item(Fp *out, int item, const LineW *lines1, const LineW *lines2, const PairPt &p1, const PairPt &p2) {
+    const int q = item / (N_LINES * 6), n = (item / 6) % N_LINES, e = item % 6;
+    const LineW &L = q == 0 ? lines1[n] : lines2[n];
+    const PairPt &P = q == 0 ? p1 : p2;
+    const Fp *coef = &L.l0 + e;                                         // l0, l6, l2, l8, l3, l9
+    const Fp *arg = e < 2 ? &P.az : e < 4 ? &P.ax : &P.ay;              // * Z^3, Z^3, X Z, X Z, Y, Y
+    Fp v; fp_mul(v, *coef, *arg);
+    out[item] = v;
 }
 // p1 / p2 = (0,0) (infinity) makes that pair contribute 1.
 KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,

@@ -251,8 +251,12 @@ int hd_pairings_verify_coop_proj(int *ok, const uint8_t *p1, const uint8_t *q1, 
     static CoopScheds sc;
     if (!build_coop_schedules(sc)) return 3;
     coop_init(*m0, &sc, pa, pb); coop_init(*m1, &sc, pa, pb);
-    coop_run(*m0, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), use1, false, ft);
-    coop_run(*m1, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), false, use2, ft);
+    // the line evaluations made ahead of the loops, as k_pairing_coop2 does (odd zsel: inside the loop, the single-wave kernel's way)
+    std::vector<Fp> pre(2 * N_LINES * 6);
+    for (int item = 0; item < 2 * N_LINES * 6; item++) coop_eval_lines_item(pre.data(), item, w1.data(), w2.data(), pa, pb);
+    const Fp *prep = (zsel & 1) ? nullptr : pre.data();
+    coop_run(*m0, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), use1, false, ft, prep);
+    coop_run(*m1, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), false, use2, ft, prep);
     for (int k = 0; k < 12; k++) m0->t0.c[k] = m1->f.c[k];
     coop_product(*m0, m0->sc.mul, m0->f, m0->f, m0->t0, FULL_MASK);
     coop_run(*m0, prog, COOP_MILLER_INSNS, n_insn, w1.data(), w2.data(), false, false, ft);
