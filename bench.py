@@ -191,6 +191,8 @@ def main():
     engine = HipEngine(s)
     out48 = C.create_string_buffer(48 * n_blobs)
 
+    exchange_acc = {}                              # stage / exchange wall times of the sharded path, accumulated over the timed steps (this rank)
+
     def run_steps(g):
         """one launch set over g independent 64-blob batches; returns when the results are on the host."""
         nb = g * n_local
@@ -210,7 +212,7 @@ def main():
             assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         else:
             # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
-            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine)
+            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, timings=exchange_acc)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
     def barrier():
@@ -231,6 +233,7 @@ def main():
     for _ in range(W):
         run_steps(Cc)
     L.kzg355_reset_kernel_stats(s.handle)
+    exchange_acc.clear()
     s.set_kernel_timing(not args.no_kernel_timing)     # HIP events around every kernel, on its launch stream; the schedule is unchanged
     step_ms = []
     barrier()
@@ -246,6 +249,21 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # N > 1 (or --sharded-path): where a step's time goes on every rank -- stage 1, the exchange (collective + permute), stage 2, the
+    # verdict merge -- so that a sub-linear scaling curve can be attributed
+    exchange_stats = None
+    if exchange_acc:
+        mine = {k: round(v / K, 3) for k, v in exchange_acc.items()}
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        exchange_stats = {"mode": os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall"), "per_rank_ms_per_step": per_rank,
+                          "exchange_ms": max(r.get("exchange_ms", 0.0) for r in per_rank), "stage1_ms": max(r.get("stage1_ms", 0.0) for r in per_rank),
+                          "stage2_ms": max(r.get("stage2_ms", 0.0) for r in per_rank), "merge_ms": max(r.get("merge_ms", 0.0) for r in per_rank),
+                          "note": "wall ms per step, max over ranks; alltoall: records + decoded points of each rank's share of the batches, then an all-reduce of "
+                                  "the verdict words (merge_ms); allgather (BASELINE north_star): one all-gather, stage 2 replicated on every rank"}
 
     blobs_total = K * Cc * n_local * world
     value = blobs_total / dt
@@ -307,6 +325,14 @@ def main():
                        "host_inputs": host_inputs},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if host_inputs:
+            # the call at the drop-in boundary includes the H2D of the blobs.  `value` is the device-resident rate the task
+            # statement asks for; these two are the H2D-inclusive rates of the same build, same run (details in config.host_inputs)
+            line["value_host_single_call"] = host_inputs["single_call_blobs_per_s"]      # one verify_blob_kzg_proof_batch(n = 64) on host slices (benches/kzg_benches.rs:113-120)
+            line["single_call_ms"] = host_inputs["single_call_ms"]
+            line["value_host_stream"] = host_inputs["stream_blobs_per_s"]               # many batches streamed from pageable host memory by one *_many call
+        if exchange_stats:
+            line["config"]["exchange"] = exchange_stats
         print(json.dumps(line), flush=True)
     s.free()
     if world > 1:
@@ -401,8 +427,8 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
     """The bound that binds: VALU issue.  Wave-instructions per blob of every kernel family come from the committed SQ counter
     pass (profiles/rNN/sq_*_vK.json, tools/sq_summary.py: SQ_INSTS_VALU at the bench's launch size); the durations are this
     run's live HIP-event averages.  Fractions are quoted against the NOMINAL issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per
-    wave64 instruction) and against the MEASURED ceiling of this instruction mix (profiles/rNN/valu_ceiling.json, from
-    tools/ubench/valu_rates.hip: most integer VOP3 / 64-bit instructions issue at half rate)."""
+    wave64 instruction); the measured issue rates of the instruction classes involved (profiles/rNN/valu_ceiling.json, from
+    tools/ubench/valu_rates.hip: most integer VOP3 / 64-bit instructions issue at half rate) ride along as context."""
     out = {"nominal_peak_wave_insts_per_s": NOMINAL_WAVE_INSTS_PER_S, "per_kernel": {}, "source": None}
     ceil_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_ceiling.json")))
     ceiling = json.load(open(ceil_files[-1])) if ceil_files else None
@@ -423,10 +449,6 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
         total_insts += insts
         out["per_kernel"][fam] = {"valu_wave_insts_per_blob": round(insts, 1), "achieved_wave_insts_per_s": rate,
                                   "frac_of_nominal": round(rate / NOMINAL_WAVE_INSTS_PER_S, 4), "wait_inst_any_frac": wait}
-        if ceiling:      # SHA-256 kernels against the measured SHA body rate, field-arithmetic kernels against the Fp-product body rate
-            mix = ceiling.get("sha256_mix_wave_insts_per_s" if fam in ("challenge", "rpowers") else "field_mix_wave_insts_per_s")
-            if mix:
-                out["per_kernel"][fam]["frac_of_measured_ceiling"] = round(rate / mix, 4)
         out["source"] = os.path.relpath(f, ROOT)
     if total_insts:
         out["path_valu_wave_insts_per_blob"] = round(total_insts, 1)
@@ -434,9 +456,10 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
         out["path_frac_of_nominal"] = round(total_insts * blobs_per_s_per_gpu / NOMINAL_WAVE_INSTS_PER_S, 4)
         out["nominal_ceiling_blobs_per_s"] = round(NOMINAL_WAVE_INSTS_PER_S / total_insts, 1)
     if ceiling:
-        out["measured_ceiling"] = ceiling
-        if total_insts and ceiling.get("path_mix_wave_insts_per_s"):
-            out["path_frac_of_measured_ceiling"] = round(total_insts * blobs_per_s_per_gpu / ceiling["path_mix_wave_insts_per_s"], 4)
+        # context only, not a bound: measured issue rates of the instruction classes this path is made of (tools/ubench/valu_rates.hip).  Round 2
+        # quoted kernel rates against "ceilings" derived from these and got fractions above 1: the ubench bodies are two loop bodies of this
+        # code, not a limit of the hardware.  The roofline figure is frac_of_nominal.
+        out["measured_issue_rates"] = {k: ceiling[k] for k in ("source", "note", "ns_per_wave_inst_per_simd") if k in ceiling}
     return out
 
 

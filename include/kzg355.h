@@ -47,8 +47,9 @@ enum {
     KZG355_INVALID_BYTES_LENGTH = 3,  /* Error::InvalidBytesLength kzg.rs:17 */
     KZG355_INVALID_HEX = 4,           /* Error::InvalidHexFormat   kzg.rs:19 */
     KZG355_INVALID_TRUSTED_SETUP = 5, /* Error::InvalidTrustedSetup kzg.rs:21 */
-    KZG355_NO_DEVICE = 6,             /* no usable HIP device / HIP runtime error (no reference counterpart) */
-    KZG355_NO_MEMORY = 7              /* a device or pinned-host allocation failed (no reference counterpart) */
+    KZG355_NO_DEVICE = 6,             /* no usable HIP device (no reference counterpart; there is no CPU fallback) */
+    KZG355_NO_MEMORY = 7,             /* a device or pinned-host allocation failed (no reference counterpart) */
+    KZG355_DEVICE_ERROR = 8           /* a HIP runtime / RCCL call failed on a device that exists: a launch, copy, stream or collective error (no reference counterpart) */
 };
 
 typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings` (kzg.rs:28-40) */

@@ -29,7 +29,7 @@ constexpr size_t BYTES_PER_BLOB = KZG355_BYTES_PER_BLOB;                     // 
 
 // enum Error (kzg.rs:10-22)
 struct Error {
-    enum Kind { BadArgs = 1, InternalError = 2, InvalidBytesLength = 3, InvalidHexFormat = 4, InvalidTrustedSetup = 5, NoDevice = 6 } kind;
+    enum Kind { BadArgs = 1, InternalError = 2, InvalidBytesLength = 3, InvalidHexFormat = 4, InvalidTrustedSetup = 5, NoDevice = 6, NoMemory = 7, DeviceError = 8 } kind;
     std::string message;
 };
 
@@ -49,7 +49,7 @@ public:
 };
 
 inline Error from_status(int rc, const char *what) {
-    Error::Kind k = (rc >= 1 && rc <= 6) ? (Error::Kind)rc : Error::InternalError;
+    Error::Kind k = (rc >= 1 && rc <= 8) ? (Error::Kind)rc : Error::InternalError;
     return Error{k, std::string(what) + ": status " + std::to_string(rc)};
 }
 

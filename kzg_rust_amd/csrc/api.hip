@@ -1,7 +1,8 @@
 // api.hip -- host side of libkzg355.so: the C ABI of include/kzg355.h on top of the HIP kernels.
 // Mirrors the control flow of the reference's `impl Kzg` forwards and the functions behind them
 // (src/kzg.rs:401-693, 833-979): argument checks and early exits happen here, all arithmetic on the device.
-// There is no CPU fallback: without a usable HIP device every entry point returns KZG355_NO_DEVICE.
+// There is no CPU fallback: without a usable HIP device every entry point returns KZG355_NO_DEVICE (a HIP call that fails on a
+// device that exists: KZG355_DEVICE_ERROR).
 #include "../../include/kzg355.h"
 #include "kernels.h"
 #include "host_sha256.h"
@@ -30,7 +31,7 @@ using namespace kzg;
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) {                                                                        \
             if (getenv("KZG355_DEBUG")) fprintf(stderr, "kzg355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            return _e == hipErrorOutOfMemory ? KZG355_NO_MEMORY : KZG355_NO_DEVICE;                      \
+            return _e == hipErrorOutOfMemory ? KZG355_NO_MEMORY : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? KZG355_NO_DEVICE : KZG355_DEVICE_ERROR; \
         }                                                                                              \
     } while (0)
 
@@ -346,7 +347,7 @@ struct HostFront {
 // The main stream waits where the results are first needed: join_points() in front of the linear combination, join_side() in front of
 // the copy of the error words.
 int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_c, const uint8_t *d_p, int n_total, int npg, G1Affine *d_pts,
-                          int *d_err, bool allow_preshift) {
+                          int *d_err, bool allow_preshift, int stride = 48 /* bytes between consecutive inputs: 48 packed, 160 inside records */) {
     int rc;
     HIPCHK(hipEventRecord(w->ev_fork, w->stream));
     const bool pre = allow_preshift && d_pts && d_p && lincomb_form(s, npg, n_total / npg) == LC_FORM_PRESHIFT;
@@ -356,7 +357,7 @@ int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uin
         if (ensure_side2(s, w)) {
             HIPCHK(hipStreamWaitEvent(w->side2, w->ev_fork, 0));
             w->shift_pending = true;
-            tm.begin("lincomb_shift", w->side2); launch_lincomb_preshift_bytes(d_c, d_p, 48, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side2); tm.end(w->side2);
+            tm.begin("lincomb_shift", w->side2); launch_lincomb_preshift_bytes(d_c, d_p, stride, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side2); tm.end(w->side2);
             HIPCHK(hipEventRecord(w->ev_shift, w->side2));
             shift_on_side2 = true;
         }
@@ -364,14 +365,14 @@ int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uin
     HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
     w->side_pending = true;                                       // (from here on a failing call has to drain the side streams: quiesce())
     if (pre) {
-        tm.begin("decompress_points", w->side); launch_decompress_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
+        tm.begin("decompress_points", w->side); launch_decompress_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side, stride); tm.end(w->side);
         HIPCHK(hipEventRecord(w->ev_pts, w->side));
         w->pts_pending = true;
         if (!shift_on_side2) { tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side); }
         tm.begin("validate_points", w->side); launch_subgroup_points(d_pts, n_total, npg, d_err, w->side); tm.end(w->side);
         w->shift_ready = true;
     } else {
-        tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side); tm.end(w->side);
+        tm.begin("validate_points", w->side); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side, stride); tm.end(w->side);
     }
     HIPCHK(hipEventRecord(w->ev_join, w->side));
     return KZG355_OK;
@@ -551,7 +552,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
     for (size_t k = 0; k < parts; k++) {          // a lane's stream is synchronised once; its sets are then read back in order
         const size_t l = k % lanes, cnt = g0[k + 1] - g0[k];
         const int rc = verify_collect(gs[l]->w, tms[l], ok + g0[k], status ? status + g0[k] : nullptr, (int)cnt, res_off[k]);
-        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return rc;
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return rc;
         if (rc != KZG355_OK && first == KZG355_OK) first = rc;
     }
     return first;
@@ -740,8 +741,8 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         pend[slot].cnt = 0;
         int rc = hc.kind == 0 ? verify_collect(w, tms[slot], hc.ok + u0, hc.status ? hc.status + u0 : nullptr, (int)cnt)
                               : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt);
-        if (hc.records_out && hc.kind == 0 && hipMemcpy(hc.records_out + (size_t)RECORD_BYTES * hc.npg * u0, w->records.p, (size_t)RECORD_BYTES * hc.npg * cnt, hipMemcpyDeviceToHost) != hipSuccess) return KZG355_NO_DEVICE;
-        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return rc;
+        if (hc.records_out && hc.kind == 0 && hipMemcpy(hc.records_out + (size_t)RECORD_BYTES * hc.npg * u0, w->records.p, (size_t)RECORD_BYTES * hc.npg * cnt, hipMemcpyDeviceToHost) != hipSuccess) return KZG355_DEVICE_ERROR;
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return rc;
         if (rc != KZG355_OK && first == KZG355_OK) first = rc;
         return KZG355_OK;
     };
@@ -878,19 +879,19 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
         FrobTables ft;
         for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
-        if (hipMemcpy(s->frob.p, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+        if (hipMemcpy(s->frob.p, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     }
     {
         static CoopInsn prog[COOP_PROGRAM_MAX];
         const int n = build_pairing_program(prog);
         if (n > COOP_PROGRAM_MAX || s->prog.ensure(sizeof(CoopInsn) * n)) return fail(KZG355_INTERNAL);
-        if (hipMemcpy(s->prog.p, prog, sizeof(CoopInsn) * n, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+        if (hipMemcpy(s->prog.p, prog, sizeof(CoopInsn) * n, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
         s->t.pairing_prog = s->prog.as<CoopInsn>();
         s->t.pairing_prog_len = n;
         static CoopScheds sc;
         if (!build_coop_schedules(sc)) return fail(KZG355_INTERNAL);
-        if (s->scheds.ensure(sizeof sc)) return fail(KZG355_NO_DEVICE);
-        if (hipMemcpy(s->scheds.p, &sc, sizeof sc, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
+        if (s->scheds.ensure(sizeof sc)) return fail(KZG355_NO_MEMORY);
+        if (hipMemcpy(s->scheds.p, &sc, sizeof sc, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
         s->t.coop_scheds = s->scheds.as<CoopScheds>();
     }
     {
@@ -920,15 +921,15 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (const char *e = getenv("KZG355_RHASH_LANES_FROM")) { const int v = atoi(e); if (v >= 1) s->rhash_lanes_from = v; }
     if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
-    if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
-    if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_NO_DEVICE);
-    if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
+    if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
+    if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (small) launch_setup_small(g1b.as<uint8_t>(), (int)n1, s->t, err.as<int>(), nullptr);
-    if (launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr)) return fail(KZG355_NO_DEVICE);
+    if (launch_setup(g1b.as<uint8_t>(), g2b.as<uint8_t>(), s->t, err.as<int>(), nullptr)) return fail(KZG355_DEVICE_ERROR);
     launch_lines_to_w(s->t, nullptr);
-    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     int herr = 0;
-    if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_NO_DEVICE);
+    if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
     g1b.release(); g2b.release(); err.release();
     {   // the 23.6 GB wide-window MSM table (KZG355_MSM=bucket keeps the 15 MB 8-bit form only; so does a failed allocation)
@@ -939,7 +940,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
             s->t.wide = wide_shape(bits);
             if (s->wide.ensure(wide_table_bytes(s->t.wide)) == KZG355_OK) {
                 s->t.wide_table = s->wide.as<WideRow>();
-                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_DEVICE; } }
+                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_DEVICE_ERROR; } }
             } else { s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_MEMORY; } }
             if (s->wide_table_failed) fprintf(stderr, "kzg355: the %.1f GB wide-window MSM table could not be allocated; commitments / proofs take the 8-bit bucket form (about 3x slower, same results)\n", wide_table_bytes(s->t.wide) / 1e9);
             (void)hipGetLastError();
@@ -978,12 +979,12 @@ static int device_self_test(kzg355_settings *s) {
     };
     std::vector<uint8_t> ones(BB, 0);
     for (size_t i = 0; i < n; i++) ones[32 * i + 31] = 1;
-    if (hipMemcpy(blobs.p, ones.data(), BB, hipMemcpyHostToDevice) != hipSuccess) { blobs.release(); return KZG355_NO_DEVICE; }
+    if (hipMemcpy(blobs.p, ones.data(), BB, hipMemcpyHostToDevice) != hipSuccess) { blobs.release(); return KZG355_DEVICE_ERROR; }
     launch_fr_to_bytes(s->t.roots, (int)n, blobs.as<uint8_t>() + BB, nullptr);            // the blob (w_0, .., w_{N-1}), big-endian canonical
-    if (hipDeviceSynchronize() != hipSuccess) { blobs.release(); return KZG355_NO_DEVICE; }
+    if (hipDeviceSynchronize() != hipSuccess) { blobs.release(); return KZG355_DEVICE_ERROR; }
     uint8_t c[96]; int st[2] = {0, 0};
     rc = msm_op_many_device_impl(c, st, blobs.as<uint8_t>(), nullptr, 2, s);
-    if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) { blobs.release(); return rc; }
+    if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) { blobs.release(); return rc; }
     if (rc != KZG355_OK) return fail("commitment kernels report an error on canonical blobs");
     if (memcmp(c, G1_GEN, 48) != 0) {
         // Either the arithmetic is wrong or the caller's points are not a Lagrange basis of this domain (the reference loads any
@@ -1020,13 +1021,13 @@ static int device_self_test(kzg355_settings *s) {
         memcpy(&hp[48 * (n * G - 1)], c + 48, 48);
         bool copy_ok = hipMemcpy(cc.p, hc.data(), hc.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pp.p, hp.data(), hp.size(), hipMemcpyHostToDevice) == hipSuccess;
         for (size_t i = 0; i < n * G && copy_ok; i++) copy_ok = hipMemcpy(bb.as<uint8_t>() + BB * i, blobs.as<uint8_t>() + BB, BB, hipMemcpyDeviceToDevice) == hipSuccess;
-        if (!copy_ok) return done(KZG355_NO_DEVICE);
+        if (!copy_ok) return done(KZG355_DEVICE_ERROR);
         const int keep_mode = s->lincomb_mode, keep_chain = s->lc_chain_from, keep_lanes = s->rhash_lanes_from;
         s->lincomb_mode = LC_FORM_BUCKET; s->lc_chain_from = 1; s->rhash_lanes_from = 1;
         bool oks[2] = {false, true}; int sts[2] = {0, 0};
         rc = verify_many_device_impl(oks, sts, bb.as<uint8_t>(), cc.as<uint8_t>(), pp.as<uint8_t>(), n, G, s);
         s->lincomb_mode = keep_mode; s->lc_chain_from = keep_chain; s->rhash_lanes_from = keep_lanes;
-        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY) return done(rc);
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return done(rc);
         bb.release(); cc.release(); pp.release();
         if (rc != KZG355_OK || !oks[0] || oks[1]) return fail("verify_blob_kzg_proof_batch through the many-batch kernels: expected (true, false)");
     }
@@ -1083,6 +1084,7 @@ static std::vector<kzg355_settings *> replicas_of(kzg355_settings *s) { return s
 int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
                                       kzg355_settings **out) {
     if (!out || !devices || n_devices == 0 || n_devices > 64) return KZG355_BADARGS;
+    DeviceScope keep; keep.hold();               // the peer-access loop and the communicator set-up visit every device: the caller's current device comes back
     std::vector<kzg355_settings *> rep;
     auto fail = [&](int code) { for (auto *r : rep) free_single(r); return code; };
     for (size_t i = 0; i < n_devices; i++) {
@@ -1186,12 +1188,12 @@ int kzg355_lagrange_setup_from_monomial(uint8_t *out, const uint8_t *monomial_g1
     int rc = KZG355_OK;
     auto done = [&](int code) { in.release(); res.release(); err.release(); return code; };
     if ((rc = in.ensure(48 * n)) || (rc = res.ensure(48 * n)) || (rc = err.ensure(sizeof(int)))) return done(rc);
-    if (hipMemcpy(in.p, monomial_g1, 48 * n, hipMemcpyHostToDevice) != hipSuccess || hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return done(KZG355_NO_DEVICE);
+    if (hipMemcpy(in.p, monomial_g1, 48 * n, hipMemcpyHostToDevice) != hipSuccess || hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return done(KZG355_DEVICE_ERROR);
     launch_lagrange_from_monomial(in.as<uint8_t>(), (int)n, res.as<uint8_t>(), err.as<int>(), nullptr);
     int herr = 0;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_NO_DEVICE);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_DEVICE_ERROR);
     if (herr) return done(KZG355_BADARGS);
-    if (hipMemcpy(out, res.p, 48 * n, hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_NO_DEVICE);
+    if (hipMemcpy(out, res.p, 48 * n, hipMemcpyDeviceToHost) != hipSuccess) return done(KZG355_DEVICE_ERROR);
     return done(KZG355_OK);
 }
 
@@ -1284,8 +1286,11 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     if (!cs || !status) return KZG355_BADARGS;
     for (size_t i = 0; i < groups; i++) status[i] = KZG355_OK;
     if (n_local == 0 || groups == 0) return KZG355_OK;
-    if (n_local * groups > (size_t)1 << 24) return KZG355_BADARGS;
-    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || !d_blobs || ((uintptr_t)d_blobs & 15) || !d_commitments || !d_proofs) return KZG355_BADARGS;
+    // a refusal of the call as a whole writes nothing to d_records / d_points: every batch carries the status, so that a caller that
+    // reads per-batch statuses cannot mistake it for success
+    auto refuse = [&](int code) { for (size_t i = 0; i < groups; i++) status[i] = code; return code; };
+    if (n_local * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
+    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || !d_blobs || ((uintptr_t)d_blobs & 15) || !d_commitments || !d_proofs) return refuse(KZG355_BADARGS);
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
@@ -1328,9 +1333,10 @@ int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_r
                         const uint8_t *d_points = nullptr) {
     if (!cs || !ok) return KZG355_BADARGS;
     if (groups == 0) return KZG355_OK;
-    if (n == 0) return KZG355_BADARGS;                           // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
-    if (n * groups > (size_t)1 << 24) return KZG355_BADARGS;
-    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3)) return KZG355_BADARGS;      // the kernels read the records 16 bytes at a time
+    auto refuse = [&](int code) { if (status) for (size_t i = 0; i < groups; i++) status[i] = code; return code; };      // whole-call refusals mark every batch
+    if (n == 0) return refuse(KZG355_BADARGS);                   // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
+    if (n * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
+    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3)) return refuse(KZG355_BADARGS);      // the kernels read the records 16 bytes at a time
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
@@ -1475,12 +1481,13 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
             if (rc) return rc;
         }
         std::lock_guard<std::mutex> lk(m->ex_mu);
-        m->rccl.GroupStart();
-        for (size_t d = 0; d < D; d++) {
-            (void)hipSetDevice(gs[d]->s->device);
-            m->rccl.AllGather(gs[d]->w->records.p, gs[d]->w->small.p, shard_bytes, /* ncclUint8 */ 1, m->comms[d], gs[d]->w->stream);
+        for (size_t d = 0; d < D; d++) gs[d]->w->in_flight = true;     // every replica's stream carries the collective: quiesce() drains them on any exit
+        int bad = m->rccl.GroupStart();
+        for (size_t d = 0; d < D && !bad; d++) {
+            if (hipSetDevice(gs[d]->s->device) != hipSuccess) { bad = 1; break; }
+            bad = m->rccl.AllGather(gs[d]->w->records.p, gs[d]->w->small.p, shard_bytes, /* ncclUint8 */ 1, m->comms[d], gs[d]->w->stream);
         }
-        if (m->rccl.GroupEnd() != 0) return KZG355_NO_DEVICE;
+        if (m->rccl.GroupEnd() != 0 || bad) return KZG355_DEVICE_ERROR;
         m->n_allgathers++;
     } else m->n_peer_exchanges++;
     // stage 2: batch g on device g mod D, over the records of all blocks in transcript order
@@ -1632,24 +1639,23 @@ int kzg355_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_
     if ((rc = w->ok.ensure(sizeof(int)))) return rc;
     if ((rc = w->h_ok.ensure(sizeof(int)))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int)))) return rc;
+    w->in_flight = true;                                          // (before the first copy from caller memory: a failure below drains the streams)
     HIPCHK(hipMemcpyAsync(w->records.p, rec, RECORD_BYTES, hipMemcpyHostToDevice, w->stream));
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
     Timed tm(s, w);
     const uint8_t *d_rec = w->records.as<uint8_t>();
-    // bytes_to_kzg_commitment / bytes_to_kzg_proof (kzg.rs:436, 439): full validation incl. subgroup.  Decoding first; the subgroup
-    // test only feeds the error word, so it runs on the side stream beside the r powers, the linear combination and most of the pairing
-    tm.begin("decompress_points"); launch_decompress_points(d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream, 48); tm.end();
-    w->in_flight = true;
-    const bool sub_on_side = ensure_side(s, w);
-    if (sub_on_side) {
-        HIPCHK(hipEventRecord(w->ev_fork, w->stream));
-        HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-        tm.begin("validate_points", w->side); launch_subgroup_points(w->pts.as<G1Affine>(), 1, 1, w->err.as<int>(), w->side); tm.end(w->side);
-        HIPCHK(hipEventRecord(w->ev_join, w->side));
-    } else { tm.begin("validate_points"); launch_subgroup_points(w->pts.as<G1Affine>(), 1, 1, w->err.as<int>(), w->stream); tm.end(); }
-    // z, y canonical checks (kzg.rs:437-438) happen in k_rpowers (check_zy = 1)
+    // bytes_to_kzg_commitment / bytes_to_kzg_proof (kzg.rs:436, 439): full validation incl. subgroup.  The decoding, the subgroup test (it
+    // only feeds the error word) and the window shifts of the linear combination (from x alone) run beside each other on the side streams;
+    // the main stream has the canonical checks of z and y (kzg.rs:437-438: k_rpowers with check_zy = 1; with one record r^0 = 1 and there is
+    // no transcript to hash), then the linear combination C + [z] proof - [y] G and the pairing.
+    w->shift_ready = false;
+    if (ensure_side(s, w)) {
+        if ((rc = enqueue_points_beside(s, w, tm, d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), true, RECORD_BYTES))) return rc;
+    } else {
+        tm.begin("validate_points"); launch_validate_points(d_rec, d_rec + 112, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->stream, RECORD_BYTES); tm.end();
+    }
     if ((rc = run_stage2(s, w, tm, d_rec, 1, 1, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
-    if (sub_on_side) HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0));       // the subgroup verdict, before the error word goes back
+    if ((rc = join_side(w))) return rc;                           // the subgroup verdict, before the error word goes back
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int), hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
@@ -1716,14 +1722,14 @@ int kzg355_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uin
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
     int rc;
-    if ((rc = stage_to_device(w, w->blobs, blob, blob_bytes_of(cs)))) return rc;
-    if ((rc = stage_to_device(w, w->small, z_bytes, 32))) return rc;
     if ((rc = w->err.ensure(sizeof(int)))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int)))) return rc;
     if ((rc = w->z.ensure(sizeof(Fr)))) return rc;
     if ((rc = w->records.ensure(64))) return rc;
     if ((rc = w->h_ok.ensure(64))) return rc;
-    w->in_flight = true;
+    w->in_flight = true;                                          // (before the first copy from caller memory: a failure below drains the stream)
+    if ((rc = stage_to_device(w, w->blobs, blob, blob_bytes_of(cs)))) return rc;
+    if ((rc = stage_to_device(w, w->small, z_bytes, 32))) return rc;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int), w->stream));
     Timed tm(s, w);
     launch_fr_from_bytes(w->small.as<uint8_t>(), 1, w->z.as<Fr>(), w->err.as<int>(), w->stream);       // kzg.rs:452

@@ -47,7 +47,7 @@ class InvalidTrustedSetup(Error):
 
 
 class NoDevice(Error):
-    """No usable HIP device / HIP runtime failure (no reference counterpart; there is no CPU fallback)."""
+    """No usable HIP device (no reference counterpart; there is no CPU fallback)."""
     code = 6
 
 
@@ -56,10 +56,15 @@ class NoMemory(Error):
     code = 7
 
 
-_ERRORS = {c.code: c for c in (BadArgs, InternalError, InvalidBytesLength, InvalidHexFormat, InvalidTrustedSetup, NoDevice, NoMemory)}
+class DeviceError(Error):
+    """A HIP runtime / RCCL call failed on a device that exists (no reference counterpart)."""
+    code = 8
+
+
+_ERRORS = {c.code: c for c in (BadArgs, InternalError, InvalidBytesLength, InvalidHexFormat, InvalidTrustedSetup, NoDevice, NoMemory, DeviceError)}
 # statuses that can only describe the call as a whole (a device, allocation or library failure): a *_many call that returns one of
 # them may have left units untouched, so it is raised even when earlier units carry a per-unit status
-_WHOLE_CALL = (InternalError.code, NoDevice.code, NoMemory.code)
+_WHOLE_CALL = (InternalError.code, NoDevice.code, NoMemory.code, DeviceError.code)
 
 
 def _whole_call_failed(rc, st, n):

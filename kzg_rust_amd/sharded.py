@@ -17,6 +17,9 @@ combination challenge r, a hash over ALL (C_i, z_i, y_i, proof_i) (utils.rs:454-
   ONE all-reduce(MAX) of the per-batch verdict / status words, so every rank returns every verdict and an Err on any rank
                                          is an Err everywhere (the `?` semantics)
 
+BASELINE.json's north_star names the other form -- a single all-gather of the records with stage 2 replicated on every rank; it is
+here as exchange="allgather" (KZG355_BENCH_EXCHANGE=allgather for bench.py), so that an 8-GPU run can compare the two.
+
 The compute stages are delegated to an `engine` with two methods, so that the orchestration (partitioning, gather
 order, status merging) is testable on CPU with gloo; the product engine is HipEngine (C ABI of libkzg355.so).
 """
@@ -40,14 +43,18 @@ class HipEngine:
 
     def shard_records(self, blobs, commitments, proofs, n_local, groups):
         import torch
-        rec = torch.empty(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
-        pts = torch.empty(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
+        rec = torch.zeros(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
+        pts = torch.zeros(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
         st = (C.c_int * max(groups, 1))()
         rc = self.L.kzg355_verify_shard_records_points_device(rec.data_ptr(), pts.data_ptr(), st, blobs.data_ptr(), commitments.data_ptr(), proofs.data_ptr(),
                                                               n_local, groups, self.s.handle)
-        if rc not in (0, 1):
+        st = _ints(st, groups)
+        # rc == 1 (BADARGS) is a per-batch status when some batch carries it.  A whole-call refusal (misaligned pointer, too many blobs:
+        # nothing was written to rec / pts) marks EVERY batch, so no batch of such a call is ever read as verified; a
+        # non-zero rc with every batch OK cannot come from this library and is raised
+        if rc not in (0, 1) or (rc != 0 and not st.any()):
             raise RuntimeError(f"kzg355_verify_shard_records_points_device: status {rc}")
-        return rec, pts, _ints(st, groups)
+        return rec, pts, st
 
     def verify_records(self, records, points, n, groups):
         ok = (C.c_bool * max(groups, 1))()
@@ -56,9 +63,10 @@ class HipEngine:
             rc = self.L.kzg355_verify_records_device(ok, st, records.data_ptr(), n, groups, self.s.handle)
         else:
             rc = self.L.kzg355_verify_records_points_device(ok, st, records.data_ptr(), points.data_ptr(), n, groups, self.s.handle)
-        if rc not in (0, 1):
+        st = _ints(st, groups)
+        if rc not in (0, 1) or (rc != 0 and not st.any()):
             raise RuntimeError(f"kzg355_verify_records_device: status {rc}")
-        return _bools(ok, groups), _ints(st, groups)
+        return _bools(ok, groups), st
 
 
 def _ints(c_array, n):
@@ -87,34 +95,94 @@ def _on_host(group):
     return dist.get_backend(group) == "gloo"
 
 
-def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group=None, force_exchange=False):
+def _tick(timings, key, t0, device=None):
+    """accumulate the wall time since t0 under `key` (the engine calls are synchronous; torch work is synchronised first)"""
+    import time
+    if timings is None:
+        return time.perf_counter()
+    if device is not None and device.type == "cuda":
+        import torch
+        torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    timings[key] = timings.get(key, 0.0) + (t1 - t0) * 1e3
+    return t1
+
+
+def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group=None, force_exchange=False,
+                                        exchange=None, timings=None):
     """`groups` independent batches; this rank holds n_local blobs of each (group-major uint8 tensors).
-    Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err."""
+    Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err.
+
+    exchange (default: $KZG355_BENCH_EXCHANGE or "alltoall"):
+      "alltoall"   stage 2 split by batch: ONE all-to-all brings every rank the records (+ decoded points) of its share of the batches,
+                   one small all-reduce(MAX) spreads the verdicts and merges the statuses;
+      "allgather"  BASELINE.json's north_star form: ONE all-gather of every rank's records (+ points + stage-1 statuses), then EVERY rank
+                   runs stage 2 on all batches (replicated: no second collective, world x the stage-2 work).
+    timings (dict or None): accumulates stage1_ms / exchange_ms / stage2_ms / merge_ms of this rank, so that a scaling curve can be
+    attributed (bench.py reports them per rank in config.exchange)."""
+    import os
+    import time
     import numpy as np
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if n_local == 0:
         return [True] * groups, [0] * groups                       # kzg.rs:653-655
+    mode = exchange or os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall")
+    if mode not in ("alltoall", "allgather"):
+        raise ValueError(f"exchange must be alltoall or allgather, not {mode!r}")
+    dev = local_blobs.device
+    t0 = time.perf_counter()
     rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
+    t0 = _tick(timings, "stage1_ms", t0)
     if world == 1 and not (force_exchange and dist.is_initialized()):      # (force_exchange: run the collectives of a one-rank group too -- test hook)
         ok, st2 = engine.verify_records(rec, pts, n_local, groups)
+        _tick(timings, "stage2_ms", t0)
         st1, st2, ok = np.asarray(st_local, dtype=np.int64), np.asarray(st2, dtype=np.int64), np.asarray(ok, dtype=bool)
         status = np.where(st1 != 0, st1, st2)
+        return (ok & (status == 0)).tolist(), status.tolist()
+    rank = dist.get_rank(group)
+    rec_b = n_local * RECORD                                    # bytes per batch: records, points
+    pts_b = 0 if pts is None else 2 * n_local * POINT
+    rec2 = rec.view(groups, rec_b)
+    pts2 = None if pts is None else pts.view(groups, pts_b)
+    on_host = _on_host(group) and rec.is_cuda
+    if mode == "allgather":
+        # ONE all-gather: [records | points | stage-1 statuses (int32 per batch)] of every rank to every rank
+        st_bytes = torch.from_numpy(np.asarray(st_local, dtype=np.int32).view(np.uint8).copy())
+        parts = [rec.reshape(-1)] + ([pts.reshape(-1)] if pts is not None else [])
+        send = torch.cat(parts + [st_bytes.to(dev)])
+        per = send.numel()
+        if on_host:
+            host = torch.empty(world * per, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, send.cpu(), group=group)
+            got = host.to(dev)
+        else:
+            got = torch.empty(world * per, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(got, send, group=group)
+        per_src = got.view(world, per)
+        # [rank][batch][n_local*160] -> [batch][rank][n_local*160]: transcript order (contiguous blocks of blobs per rank)
+        recs = per_src[:, :groups * rec_b].reshape(world, groups, rec_b).permute(1, 0, 2).contiguous().view(-1)
+        points = None
+        if pts is not None:     # [rank][batch][C | proofs][n_local] -> [batch][C | proofs][rank][n_local]
+            points = per_src[:, groups * rec_b:groups * (rec_b + pts_b)].reshape(world, groups, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
+        st_all = per_src[:, groups * (rec_b + pts_b):].contiguous().cpu().numpy().view(np.int32).reshape(world, groups).astype(np.int64)     # (also orders the stream: the permutes are done)
+        t0 = _tick(timings, "exchange_ms", t0, dev)
+        ok, st2 = engine.verify_records(recs, points, n_local * world, groups)           # every rank: all the batches
+        t0 = _tick(timings, "stage2_ms", t0)
+        st1 = st_all.max(axis=0)                                    # an Err on any rank's shard is an Err of the batch (the `?`s of kzg.rs:673-682)
+        st2, ok = np.asarray(st2, dtype=np.int64), np.asarray(ok, dtype=bool)
+        status = np.where(st1 != 0, st1, st2)
+        _tick(timings, "merge_ms", t0)
         return (ok & (status == 0)).tolist(), status.tolist()
     # The ONE data-path collective: an all-to-all.  Stage 2 is split by batch, so rank j needs the records (and decoded points) of
     # the batches in ITS share only, from every rank: rank i sends rank j the slice [g_lo_j, g_hi_j) of its records | points.  An
     # all-gather would deliver every rank's whole shard to everybody -- world x the bytes, over a ring; here every pair of ranks
     # exchanges 1 / world of a shard over its own xGMI link (at 8 ranks and 8192 batches per step: 25 MB per link instead of
     # 1.4 GB around the ring).
-    rank = dist.get_rank(group)
     shares = [((groups * r) // world, (groups * (r + 1)) // world) for r in range(world)]
     g_lo, g_hi = shares[rank]
     mine = g_hi - g_lo
-    rec_b = n_local * RECORD                                    # bytes per batch: records, points
-    pts_b = 0 if pts is None else 2 * n_local * POINT
-    rec2 = rec.view(groups, rec_b)
-    pts2 = None if pts is None else pts.view(groups, pts_b)
     parts = []
     for lo, hi in shares:
         parts.append(rec2[lo:hi].reshape(-1))
@@ -123,15 +191,16 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     send = torch.cat(parts)
     in_splits = [(hi - lo) * (rec_b + pts_b) for lo, hi in shares]
     out_splits = [mine * (rec_b + pts_b)] * world
-    if _on_host(group) and send.is_cuda:
+    if on_host:
         host = torch.empty(sum(out_splits), dtype=torch.uint8)
         dist.all_to_all_single(host, send.cpu(), out_splits, in_splits, group=group)
-        got = host.to(send.device)
+        got = host.to(dev)
     else:
-        got = torch.empty(sum(out_splits), dtype=torch.uint8, device=send.device)
+        got = torch.empty(sum(out_splits), dtype=torch.uint8, device=dev)
         dist.all_to_all_single(got, send, out_splits, in_splits, group=group)
-    code = torch.zeros(2 * groups, dtype=torch.int32, device=rec.device)      # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status
-    code[:groups] = torch.from_numpy(np.asarray(st_local, dtype=np.int32)).to(rec.device)
+    # [0:G] stage-1 status, [G:2G] 1 + ok + 256 * stage-2 status of this rank's share: assembled on the host, ONE upload
+    code_h = np.zeros(2 * groups, dtype=np.int32)
+    code_h[:groups] = np.asarray(st_local, dtype=np.int32)
     if mine > 0:
         per_src = got.view(world, mine * (rec_b + pts_b))          # from rank i: [records of my batches | points of my batches]
         # [rank][batch][n_local*160] -> [batch][rank][n_local*160]: transcript order (contiguous blocks of blobs per rank)
@@ -140,14 +209,19 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         if pts is not None:     # [rank][batch][C | proofs][n_local] -> [batch][C | proofs][rank][n_local]
             points = per_src[:, mine * rec_b:].reshape(world, mine, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
         if rec.is_cuda:
-            torch.cuda.synchronize(rec.device)
+            torch.cuda.synchronize(dev)                            # the permutes ran on torch's stream, the engine has its own
+        t0 = _tick(timings, "exchange_ms", t0)
         ok, st2 = engine.verify_records(recs, points, n_local * world, mine)
-        enc = 1 + np.asarray(ok, dtype=np.int32) + 256 * np.asarray(st2, dtype=np.int32)
-        code[groups + g_lo:groups + g_hi] = torch.from_numpy(enc.astype(np.int32)).to(rec.device)
-    if _on_host(group) and code.is_cuda:
-        code = code.cpu()
+        t0 = _tick(timings, "stage2_ms", t0)
+        code_h[groups + g_lo:groups + g_hi] = 1 + np.asarray(ok, dtype=np.int32) + 256 * np.asarray(st2, dtype=np.int32)
+    else:
+        t0 = _tick(timings, "exchange_ms", t0, dev)
+    code = torch.from_numpy(code_h)
+    if not on_host and rec.is_cuda:
+        code = code.to(dev)
     dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)        # verdicts of every share + status merge, one small collective
-    code = code.cpu().numpy().astype(np.int64)
+    code = code.cpu().numpy().astype(np.int64)                      # the one read-back
     st1, enc = code[:groups], code[groups:]
     status = np.where(st1 != 0, st1, enc >> 8)
+    _tick(timings, "merge_ms", t0)
     return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()

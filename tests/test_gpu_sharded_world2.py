@@ -43,9 +43,12 @@ def _worker(rank, world, port, blobs, cs, ps, q):
     tp = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[2])), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
     eng = HipEngine(s)
-    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng)
-    ok1, st1 = verify_blob_kzg_proof_batch_sharded(tb[:n_local * 131072], tc[:n_local * 48], tp[:n_local * 48], n_local, 1, eng)    # one batch: rank 0's share is empty
-    q.put((rank, ok, st, ok1, st1))
+    res = []
+    for exchange in ("alltoall", "allgather"):             # stage 2 split by batch / BASELINE.json's single all-gather with stage 2 replicated
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange)
+        ok1, st1 = verify_blob_kzg_proof_batch_sharded(tb[:n_local * 131072], tc[:n_local * 48], tp[:n_local * 48], n_local, 1, eng, exchange=exchange)    # one batch: rank 0's share is empty
+        res.append((exchange, ok, st, ok1, st1))
+    q.put((rank, res))
     s.free()
     dist.destroy_process_group()
 
@@ -81,7 +84,8 @@ def test_sharded_driver_two_ranks_on_the_hip_engine():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, ok, st, ok1, st1 in res:
-        assert ok == [True, False, False], (rank, ok)
-        assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, st)
-        assert (ok1, st1) == ([True], [0]), (rank, ok1, st1)
+    for rank, per_exchange in res:
+        for exchange, ok, st, ok1, st1 in per_exchange:
+            assert ok == [True, False, False], (rank, exchange, ok)
+            assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, exchange, st)
+            assert (ok1, st1) == ([True], [0]), (rank, exchange, ok1, st1)

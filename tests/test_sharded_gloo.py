@@ -65,7 +65,7 @@ def _inputs():
     return blobs, cs, ps
 
 
-def _worker(rank, world, port, blobs, cs, ps, q):
+def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,32 +85,36 @@ def _worker(rank, world, port, blobs, cs, ps, q):
     tc = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[1])), dtype=torch.uint8)
     tp = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[2])), dtype=torch.uint8)
     eng = OracleEngine()
-    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng)
+    timings = {}
+    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange, timings=timings)
+    assert timings.get("stage1_ms", 0) > 0 and "exchange_ms" in timings and "merge_ms" in timings, timings
     # ONE batch over two ranks: rank 0's share of the batches is EMPTY (groups * 0 // 2 == groups * 1 // 2), rank 1 runs stage 2
     # alone, and the all-reduce still has to hand rank 0 the verdict -- honest first, then with rank 0's proofs swapped, then with
     # an invalid proof on rank 0 (Err raised by a rank that verifies nothing itself)
     one = lambda t, per: t[:n_local * per].clone()
-    ok1, st1 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), one(tp, 48), n_local, 1, eng)
+    ok1, st1 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), one(tp, 48), n_local, 1, eng, exchange=exchange)
     sw = one(tp, 48)
     if rank == 0:
         tmp = sw[:48].clone(); sw[:48] = sw[48:96]; sw[48:96] = tmp
-    ok2, st2 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), sw, n_local, 1, eng)
+    ok2, st2 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), sw, n_local, 1, eng, exchange=exchange)
     bad = one(tp, 48)
     if rank == 0:
         bad[:48] = torch.frombuffer(bytearray(bytes([0x9A]) + b"\xff" * 47), dtype=torch.uint8)
-    ok3, st3 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), bad, n_local, 1, eng)
+    ok3, st3 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), bad, n_local, 1, eng, exchange=exchange)
     q.put((rank, ok, st, (ok1, st1, ok2, st2, ok3, st3)))
     dist.destroy_process_group()
 
 
-def test_sharded_verify_world2_gloo():
+@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
+def test_sharded_verify_world2_gloo(exchange):
+    """both exchanges: the all-to-all with stage 2 split by batch, and BASELINE.json's single all-gather with stage 2 replicated"""
     blobs, cs, ps = _inputs()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, blobs, cs, ps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, blobs, cs, ps, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)

@@ -15,8 +15,8 @@ echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc
 echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/write.err; echo rc=$?
 echo "== SQ"; rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $BENCH > /dev/null 2> $OUT/sq.err; echo rc=$?
 cd $ROOT
-python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 524288 $OUT/pmc_traffic_$V.json > /dev/null
-python tools/sq_summary.py $OUT/pmc_sq 524288 $OUT/sq_$V.json > /dev/null
+python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_$V.json > /dev/null
+python tools/sq_summary.py $OUT/pmc_sq $OUT/sq_$V.json > /dev/null
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_default_$V.csv \;
 for op in commit proof; do
   echo "== $op"

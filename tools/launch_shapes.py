@@ -1,0 +1,29 @@
+"""Blobs processed by one launch of each kernel, from the launch's total work-item count (rocprofv3 `Grid_Size`).
+
+The counter summaries (pmc_summary.py, sq_summary.py) normalise every kernel by the blobs of ITS OWN largest launch: in one bench run
+the verify kernels see 524,288 blobs per launch while the commit / proof kernels of the untimed setup see 65,536 -- one global
+constant misreports the latter 8x (round-2 verdict).  The table restates the launchers (kzg_rust_amd/csrc/k_*.hip) for the
+many-unit (throughput) launch shapes; per-batch kernels are scaled by the batch size (64 blobs in bench.py)."""
+import math
+
+
+def blobs_of_launch(kernel, grid, npg=64):
+    """kernel: name without `kzg::` / argument list (templates kept, e.g. `k_msm_wide<false>`); grid: total work-items; npg: blobs per batch."""
+    per_blob = {                         # work-items per blob (grids are rounded up to the workgroup size: exact for the bench's sizes)
+        "k_eval": 64, "k_challenge_1w": 1, "k_challenge": 2, "k_challenge_from_digest": 1,
+        "k_validate_points": 2, "k_decompress_points": 2, "k_subgroup_points": 2, "k_points_from_records": 2,
+        "k_msm_wide<false>": 256, "k_msm_wide<true>": 256, "k_msm_finalize": 64, "k_quotient": 1024,
+        "k_digits_from_blobs": 4096, "k_digits_from_fr": 4096, "k_msm_bucket<4>": 512, "k_msm_bucket<1>": 4096,
+        "k_small_records": 1, "k_small_commit": 1, "k_small_proof": 1,
+    }
+    per_batch = {                        # work-items per batch of npg blobs
+        "k_rhash_lanes": 1, "k_rpowers": 64, "k_lc_prep": 64 * math.ceil((3 * npg + 1) / 64), "k_lc_buckets": 256, "k_lc_horner": 32,
+        "k_lc_wsum": 52, "k_lc_hchain": 2, "k_ps_shift": 4 * (2 * npg + 1), "k_ps_buckets": 2 * 4 * 256, "k_ps_weights": 32,
+        "k_lincomb_terms": 64 * math.ceil(2 * (3 * npg + 1) / 64), "k_lincomb_finish": 64, "k_pairing_coop": 64, "k_pairing_coop2": 128,
+        "k_pairing": 1, "k_dump_intermediates": 2,
+    }
+    if kernel in per_blob:
+        return grid / per_blob[kernel]
+    if kernel in per_batch:
+        return grid / per_batch[kernel] * npg
+    return None

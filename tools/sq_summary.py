@@ -3,9 +3,10 @@
 
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \\
               --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py ...
-    python tools/sq_summary.py gpurun_out/pmc_sq BLOBS_PER_LAUNCH out.json
+    python tools/sq_summary.py gpurun_out/pmc_sq out.json
 
-Per kernel (largest-grid launches only, i.e. the launches that processed BLOBS_PER_LAUNCH blobs): wave-instructions per blob
+Per kernel (largest-grid launches only, normalised by the blobs of THAT launch -- Grid_Size -> blobs: tools/launch_shapes.py; the
+verify kernels of the bench see 524,288 blobs per launch, the commit / proof kernels of its untimed setup 65,536): wave-instructions per blob
 (SQ_INSTS_VALU is counted per wave-instruction), waves per launch, and the share of the wave-cycles spent waiting to issue
 (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES) or parked in s_waitcnt / barriers (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  bench.py's
 roofline.alu combines the per-blob instruction counts with its live HIP-event kernel durations."""
@@ -16,9 +17,12 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from launch_shapes import blobs_of_launch
+
 
 def main():
-    directory, blobs, dst = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    directory, dst = sys.argv[1], sys.argv[-1]
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     assert files, f"no counter_collection.csv under {directory}"
     agg = defaultdict(lambda: defaultdict(list))
@@ -30,11 +34,15 @@ def main():
     res = {}
     for name, counters in sorted(agg.items()):
         v = {}
+        gmax = 0
         for cname, vals in counters.items():
             gmax = max(g for g, _ in vals)
             big = [c for g, c in vals if g == gmax]
             v[cname] = sum(big) / len(big)
             v["_launches"] = len(big)
+        blobs = blobs_of_launch(name, gmax)
+        if not blobs:
+            continue
         wc = v.get("SQ_WAVE_CYCLES", 0.0)
         res[name] = {"valu_wave_insts_per_blob": round(v.get("SQ_INSTS_VALU", 0.0) / blobs, 2),
                      "salu_insts_per_blob": round(v.get("SQ_INSTS_SALU", 0.0) / blobs, 2),
@@ -42,11 +50,11 @@ def main():
                      "waves_per_launch": round(v.get("SQ_WAVES", 0.0)),
                      "wait_inst_any_frac": round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4) if wc else None,
                      "wait_any_frac": round(v.get("SQ_WAIT_ANY", 0.0) / wc, 4) if wc else None,
-                     "launches": v.get("_launches", 0)}
-    json.dump({"note": f"rocprofv3 --pmc SQ_* over bench.py, {blobs} blobs per launch (largest-grid launches only); SQ_INSTS_VALU counts "
+                     "launches": v.get("_launches", 0), "grid_size": gmax, "blobs_per_launch": round(blobs)}
+    json.dump({"note": "rocprofv3 --pmc SQ_* over bench.py; per kernel the largest-grid launches only, normalised by the blobs of that launch; SQ_INSTS_VALU counts "
                        "wave-instructions (summed over the chip); SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md), only "
                        "their ratio is used",
-               "blobs_per_launch": blobs, "per_kernel": res}, open(dst, "w"), indent=1)
+               "per_kernel": res}, open(dst, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
