@@ -60,7 +60,8 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
  * Builds the device-resident tables (roots of unity, bit-reversed G1 table and its per-window multiples,
  * Miller-loop line tables of the two G2 points the verify path uses) -- including the 23.6 GB wide-window MSM table
  * (every multiple 1..2048 of 2^(12w) * g1[i]); if that allocation fails, or with KZG355_MSM=bucket in the environment,
- * only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results). */
+ * only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results).  Takes the defaults of
+ * kzg355_options below with the KZG355_* environment overrides applied; kzg355_load_trusted_setup_ex is the explicit form. */
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
 /* The same over several GPUs of one node: a full replica of the tables per device, and the host-buffer entry points below spread
  * their work over the devices INSIDE the call, invisibly to the caller (the reference has no notion of devices): independent
@@ -72,6 +73,44 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
  * kzg355_settings_device refer to the first device of the list. */
 int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
                                       kzg355_settings **out);
+/* Everything a deployment may want to pin when a handle is created.  kzg355_options_default fills in the defaults (and struct_size, which
+ * lets a library newer than the caller's header keep its own defaults for fields the caller does not know); 0 means "default" for every
+ * numeric field unless stated otherwise.  The dispatch thresholds default to multiples of the device's compute-unit count -- the
+ * measured crossovers of the 256-CU MI355X scaled to the device at hand.  The KZG355_* environment variables named
+ * below are TEST / EXPERIMENT overrides: only kzg355_load_trusted_setup, _devices and _file read them (through
+ * kzg355_options_from_env); kzg355_load_trusted_setup_ex takes what it is given and reads no environment. */
+typedef struct kzg355_options {
+    size_t struct_size;        /* sizeof(kzg355_options) as the caller compiled it */
+    int device;                /* device ordinal; -1: the calling thread's current device                                   KZG355_DEVICE */
+    int msm_bits;              /* fixed-base MSM table: 0 = 12-bit windows (23.6 GB); 13 / 14 / 15 = 42.9 / 81.6 / 154.6 GB (5 / 15 / 21 % more
+                                  commitments per second); 8 = the 15 MB 8-bit bucket form only                  KZG355_MSM_BITS, KZG355_MSM=bucket */
+    int msm_require_wide;      /* 1: failing to allocate / build the wide table fails the load (else: bucket form, noted on stderr)  KZG355_MSM=wide */
+    int self_test;             /* 1 (default): known-answer self-test of the new handle (~10 ms); 0: skip                   KZG355_SELFTEST */
+    int host_threads;          /* host worker threads of the handle (Fiat-Shamir hashing of small host-buffer calls, staging copies);
+                                  0 = min(16, cpus the process may run on / 2)                                             KZG355_HOST_THREADS */
+    int host_hash;             /* challenges of host-buffer verify / blob-proof calls hashed on the host: 0 by size, 1 always, -1 never  KZG355_HOST_HASH=auto|on|off */
+    int host_hash_max_blobs;   /* ... up to this many blobs per call (0 = 4096: measured crossover, profiles/r03/host_hash_crossover_v3.txt)          KZG355_HOST_HASH_MAX */
+    int host_sha;              /* host SHA-256 form: 0 SHA extensions when the CPU has them, 1 portable C, 2 SHA extensions      KZG355_HOST_SHA=portable|shani */
+    int challenge_form;        /* device Fiat-Shamir kernel: 0 by size (two-wave form up to 2 workgroups per CU), 1 one wave, 2 two waves   KZG355_CHALLENGE=1w|2w */
+    int lincomb_form;          /* batch linear combination: 0 by size, 1 per-term windows, 2 buckets, 3 pre-shifted        KZG355_LINCOMB=window|bucket|preshift */
+    int pairing_lane;          /* 1: one-lane pairing kernel (A/B and tests)                                               KZG355_PAIRING=lane */
+    int pairing_two_wave_upto; /* batches per launch set up to which a pairing runs its two Miller loops on two waves; 0 = 1 per CU; -1 never  KZG355_PAIRING_2W_UPTO */
+    int lc_chain_from;         /* batches from which the bucket form ends in one Horner chain per class; 0 = 24 per CU      KZG355_LC_CHAIN_FROM */
+    int rhash_lanes_from;      /* batches from which the r-transcripts are hashed one lane per batch; 0 = 4 per CU          KZG355_RHASH_LANES_FROM */
+    int beside_max_blobs;      /* blobs per launch set up to which the point kernels run on side streams; 0 = 64 per CU */
+    int split_parts;           /* device-resident verify calls as this many overlapped launch sets (0 / 1: one set)         KZG355_SPLIT=parts[,streams] */
+    int split_streams;         /* ... over this many streams (0 = 2) */
+    int chunk_mb;              /* MiB of blobs per chunk of a streamed host-buffer call (0 = 1024)                          KZG355_CHUNK_MB */
+    int chunks_in_flight;      /* workspaces such a call rotates over (0 = 3)                                               KZG355_CHUNKS_IN_FLIGHT */
+    int staging_ring;          /* 1: stage caller memory through pinned slots instead of letting the runtime DMA from it    KZG355_STAGING=ring */
+    int exchange;              /* handles over several devices: 0 RCCL all-gather when available, 1 peer copies, 2 RCCL or fail   KZG355_EXCHANGE=peer|rccl */
+} kzg355_options;
+void kzg355_options_default(kzg355_options *options);
+void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */
+/* kzg355_load_trusted_setup with explicit options, on options->device or -- devices != NULL -- over the listed devices (as
+ * kzg355_load_trusted_setup_devices).  options == NULL: all defaults.  Reads no environment variable. */
+int kzg355_load_trusted_setup_ex(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
+                                 const kzg355_options *options, kzg355_settings **out);
 /* Kzg::load_trusted_setup_file (kzg.rs:995 -> 906-979): "4096\n65\n" + hex lines. */
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out);
 /* Minimal preset helper: n compressed MONOMIAL points [tau^k]G1 (n a power of two in [4, 64], e.g. the first four `setup_G1`
@@ -192,7 +231,7 @@ const char *kzg355_version(void);
  * host core with the SHA extensions ~60 us.  Host-buffer verify / blob-proof calls of at most `max_blobs` blobs (one chunk) therefore
  * hash their transcripts on the handle's host threads WHILE the H2D copy and the point kernels run and upload 32-byte digests; larger
  * and device-resident calls keep the device kernels.  mode: 0 by size (default), 1 always, -1 never; max_blobs 0 keeps the current
- * crossover (default 1024; KZG355_HOST_HASH=auto|on|off and KZG355_HOST_HASH_MAX in the environment set the same at load). */
+ * crossover (default 4096; KZG355_HOST_HASH=auto|on|off and KZG355_HOST_HASH_MAX in the environment set the same at load). */
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs);
 /* How many host-buffer calls on this handle had their challenges hashed on the host so far. */
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s);

@@ -12,6 +12,14 @@ class KzgLibraryMissing(ImportError):
     pass
 
 
+class Options(C.Structure):
+    """struct kzg355_options (include/kzg355.h): the same fields in the same order."""
+    _fields_ = [("struct_size", C.c_size_t)] + [(name, C.c_int) for name in (
+        "device", "msm_bits", "msm_require_wide", "self_test", "host_threads", "host_hash", "host_hash_max_blobs", "host_sha", "challenge_form",
+        "lincomb_form", "pairing_lane", "pairing_two_wave_upto", "lc_chain_from", "rhash_lanes_from", "beside_max_blobs", "split_parts",
+        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange")]
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise KzgLibraryMissing(
@@ -79,6 +87,11 @@ def load():
     lib.kzg355_last_kernel_ms.argtypes = [vp, u8p]
     lib.kzg355_last_kernel_ms.restype = C.c_double
     lib.kzg355_version.restype = C.c_char_p
+    lib.kzg355_load_trusted_setup_ex.argtypes = [u8p, sz, u8p, sz, C.POINTER(C.c_int), sz, C.POINTER(Options), C.POINTER(vp)]
+    lib.kzg355_load_trusted_setup_ex.restype = C.c_int
+    for name in ("kzg355_options_default", "kzg355_options_from_env"):
+        getattr(lib, name).argtypes = [C.POINTER(Options)]
+        getattr(lib, name).restype = None
     lib.kzg355_settings_host_hashed_calls.argtypes = [vp]
     lib.kzg355_settings_host_hashed_calls.restype = C.c_long
     return lib
@@ -95,4 +108,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
     "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_verify_shard_records_points_device", "kzg355_verify_records_points_device", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
     "kzg355_settings_set_host_hash", "kzg355_settings_host_hashed_calls", "kzg355_host_sha256", "kzg355_host_challenge_digests", "kzg355_debug_verify_host_records",
+    "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex",
 ]

@@ -197,10 +197,13 @@ struct kzg355_settings {
     int rhash_lanes_from = 1024;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM); measured: 1024 batches of 512 records 6.75 -> 3.47 ms, 8192 of 64: 2.44 -> 0.57 ms
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
     int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
+    int cu_count = 256;            // compute units of the device: the thresholds above and below are multiples of it (load_on_device)
+    int pairing_two_wave_upto = 256;     // batches per launch set up to which a pairing runs its two Miller loops on two waves (1 per CU)
+    int challenge_two_wave_upto = 32768; // blobs per launch set up to which the Fiat-Shamir hash runs as producer / consumer wave pairs (2 workgroups per CU)
     std::mutex mu;
     hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
-    int host_hash_max = 1024;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX); crossover measured in profiles/r03/host_hash_crossover.txt
+    int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v3.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
     int sha_impl = 0;                // host SHA-256 form: 0 auto (SHA extensions when the CPU has them), 1 portable, 2 SHA extensions (KZG355_HOST_SHA=portable|shani)
     std::atomic<long> n_host_hashed{0};   // introspection: host-buffer calls whose challenges were hashed on the host
     std::vector<Workspace *> pool;
@@ -416,7 +419,7 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * (size_t)n_total, hipMemcpyHostToDevice, w->stream));
         tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream); tm.end();
     } else {
-        tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream, s->challenge_form); tm.end();
+        tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream, s->challenge_form ? s->challenge_form : n_total <= s->challenge_two_wave_upto ? 2 : 1); tm.end();
     }
     tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
     return KZG355_OK;
@@ -458,7 +461,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
-    else launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
+    else launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream, s->pairing_two_wave_upto);
     tm.end();
     return KZG355_OK;
 }
@@ -642,7 +645,7 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
             hf->finish();
             HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * n, hipMemcpyHostToDevice, w->stream));
             tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream); tm.end();
-        } else { tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form); tm.end(); }
+        } else { tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form ? s->challenge_form : (int)n <= s->challenge_two_wave_upto ? 2 : 1); tm.end(); }
         if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
         if ((rc = join_side(w))) return rc;
     }
@@ -835,7 +838,62 @@ const char *kzg355_version(void) { return "kzg355 0.1 (gfx950, 29-bit-limb Montg
 
 static int device_self_test(kzg355_settings *s);
 static std::vector<kzg355_settings *> replicas_of(kzg355_settings *s);
-static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, kzg355_settings **out) {
+
+// ---- options ---------------------------------------------------------------------------------------------------------------------
+// Everything a deployment may want to pin is a field of kzg355_options (include/kzg355.h) passed to kzg355_load_trusted_setup_ex; the
+// dispatch thresholds default to multiples of the device's CU count (0 = auto).  The KZG355_* environment variables are what the tests
+// and experiments use to override them: kzg355_options_from_env folds them into a struct, and the plain load functions use that.
+void kzg355_options_default(kzg355_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = sizeof *o;
+    o->device = -1;
+    o->self_test = 1;
+}
+void kzg355_options_from_env(kzg355_options *o) {
+    if (!o) return;
+    kzg355_options_default(o);
+    auto num = [](const char *name, long lo, long hi, int *dst) { if (const char *e = getenv(name)) { const long v = atol(e); if (v >= lo && v <= hi) *dst = (int)v; } };
+    num("KZG355_DEVICE", 0, 1023, &o->device);
+    if (const char *e = getenv("KZG355_MSM")) { if (strcmp(e, "bucket") == 0) o->msm_bits = 8; else if (strcmp(e, "wide") == 0) o->msm_require_wide = 1; }
+    if (o->msm_bits != 8) num("KZG355_MSM_BITS", 10, 15, &o->msm_bits);
+    num("KZG355_SELFTEST", 0, 1, &o->self_test);
+    num("KZG355_COPY_THREADS", 1, 64, &o->host_threads);
+    num("KZG355_HOST_THREADS", 1, 64, &o->host_threads);
+    if (const char *e = getenv("KZG355_HOST_HASH")) o->host_hash = strcmp(e, "on") == 0 ? 1 : strcmp(e, "off") == 0 ? -1 : 0;
+    num("KZG355_HOST_HASH_MAX", 1, 1 << 24, &o->host_hash_max_blobs);
+    if (const char *e = getenv("KZG355_HOST_SHA")) o->host_sha = strcmp(e, "portable") == 0 ? 1 : strcmp(e, "shani") == 0 ? 2 : 0;
+    num("KZG355_CHUNK_MB", 1, 16384, &o->chunk_mb);
+    if (const char *e = getenv("KZG355_STAGING")) o->staging_ring = strcmp(e, "ring") == 0;
+    num("KZG355_CHUNKS_IN_FLIGHT", 1, 8, &o->chunks_in_flight);
+    if (const char *e = getenv("KZG355_PAIRING")) o->pairing_lane = strcmp(e, "lane") == 0;
+    num("KZG355_PAIRING_2W_UPTO", 0, 1 << 24, &o->pairing_two_wave_upto);
+    if (getenv("KZG355_PAIRING_2W_UPTO") && o->pairing_two_wave_upto == 0) o->pairing_two_wave_upto = -1;      // "0": never
+    if (const char *e = getenv("KZG355_SPLIT")) {
+        int a = 1, b = 2;
+        const int got = sscanf(e, "%d,%d", &a, &b);
+        if (got >= 1 && a >= 1 && a <= 64) o->split_parts = a;
+        if (got >= 2 && b >= 1 && b <= 8) o->split_streams = b;
+    }
+    num("KZG355_LC_CHAIN_FROM", 1, 1 << 24, &o->lc_chain_from);
+    num("KZG355_RHASH_LANES_FROM", 1, 1 << 24, &o->rhash_lanes_from);
+    if (const char *e = getenv("KZG355_CHALLENGE")) o->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
+    if (const char *e = getenv("KZG355_LINCOMB")) o->lincomb_form = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
+    if (const char *e = getenv("KZG355_EXCHANGE")) o->exchange = strcmp(e, "peer") == 0 ? 1 : strcmp(e, "rccl") == 0 ? 2 : 0;
+}
+// the caller's struct may be older (smaller) than this library's: fields beyond its struct_size keep their defaults
+static kzg355_options options_of(const kzg355_options *opt) {
+    kzg355_options o;
+    kzg355_options_default(&o);
+    if (opt && opt->struct_size >= sizeof(size_t)) {
+        const size_t n = opt->struct_size < sizeof o ? opt->struct_size : sizeof o;
+        memcpy(&o, opt, n);
+        o.struct_size = sizeof o;
+    }
+    return o;
+}
+
+static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, const kzg355_options &opt, kzg355_settings **out) {
     if (!out || !g1_bytes || !g2_bytes) return KZG355_BADARGS;
     // FIELD_ELEMENTS_PER_BLOB is a compile-time constant of the reference (consts.rs:13: 4096; its README's minimal preset: 4); here
     // it is a property of the handle, taken from the number of G1 points: 4096, or a power of two in [4, 64] for the small path
@@ -845,7 +903,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KZG355_NO_DEVICE;
     int dev = 0;
     if (dev_or_minus1 >= 0) dev = dev_or_minus1;
-    else if (const char *e = getenv("KZG355_DEVICE")) dev = atoi(e);
+    else if (opt.device >= 0) dev = opt.device;
     else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev < 0 || dev >= ndev) return KZG355_NO_DEVICE;
     DeviceScope scope;
@@ -898,29 +956,33 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         cpu_set_t cpus; CPU_ZERO(&cpus);
         int workers = sched_getaffinity(0, sizeof cpus, &cpus) == 0 ? CPU_COUNT(&cpus) / 2 : 1;     // cores this process may run on
         if (workers > 16) workers = 16;
-        if (const char *e = getenv("KZG355_HOST_THREADS")) workers = atoi(e);
-        else if (const char *e = getenv("KZG355_COPY_THREADS")) workers = atoi(e);
+        if (opt.host_threads > 0) workers = opt.host_threads;
         if (workers > 64) workers = 64;
         if (workers < 1) workers = 1;
         s->host_pool = new HostPool(workers - 1);                            // the calling thread is one of the workers
-        if (const char *e = getenv("KZG355_HOST_HASH")) s->host_hash = strcmp(e, "on") == 0 ? 1 : strcmp(e, "off") == 0 ? -1 : 0;
-        if (const char *e = getenv("KZG355_HOST_HASH_MAX")) { const int v = atoi(e); if (v >= 1) s->host_hash_max = v; }
-        if (const char *e = getenv("KZG355_HOST_SHA")) s->sha_impl = strcmp(e, "portable") == 0 ? 1 : strcmp(e, "shani") == 0 ? 2 : 0;
-        if (const char *e = getenv("KZG355_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 16384) s->chunk_bytes = (size_t)v << 20; }
-        if (const char *e = getenv("KZG355_STAGING")) s->pinned_ring = strcmp(e, "ring") == 0;
-        if (const char *e = getenv("KZG355_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->chunks_in_flight = v; }
+        s->host_hash = opt.host_hash;
+        if (opt.host_hash_max_blobs > 0) s->host_hash_max = opt.host_hash_max_blobs;
+        s->sha_impl = opt.host_sha;
+        if (opt.chunk_mb > 0) s->chunk_bytes = (size_t)opt.chunk_mb << 20;
+        s->pinned_ring = opt.staging_ring != 0;
+        if (opt.chunks_in_flight >= 1 && opt.chunks_in_flight <= 8) s->chunks_in_flight = opt.chunks_in_flight;
     }
-    if (const char *e = getenv("KZG355_PAIRING")) s->lane_pairing = strcmp(e, "lane") == 0;
-    if (const char *e = getenv("KZG355_SPLIT")) {
-        int a = 1, b = 2;
-        const int got = sscanf(e, "%d,%d", &a, &b);
-        if (got >= 1 && a >= 1 && a <= 64) s->split_parts = a;
-        if (got >= 2 && b >= 1 && b <= 8) s->split_streams = b;
+    {   // dispatch thresholds: measured on the 256-CU MI355X and kept as multiples of the CU count of the device at hand
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        s->cu_count = cus;
+        s->lc_chain_from = opt.lc_chain_from > 0 ? opt.lc_chain_from : 24 * cus;             // one Horner chain per class from 6144 batches on
+        s->rhash_lanes_from = opt.rhash_lanes_from > 0 ? opt.rhash_lanes_from : 4 * cus;     // transcript hash with a lane per batch from one wave per SIMD on (1024)
+        s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
+        s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;     // two waves per pairing up to 256 batches
+        s->challenge_two_wave_upto = 2 * cus * 64;                                           // two-wave hash while every wave has a SIMD to itself (512 workgroups of 64 blobs)
     }
-    if (const char *e = getenv("KZG355_LC_CHAIN_FROM")) { const int v = atoi(e); if (v >= 1) s->lc_chain_from = v; }
-    if (const char *e = getenv("KZG355_RHASH_LANES_FROM")) { const int v = atoi(e); if (v >= 1) s->rhash_lanes_from = v; }
-    if (const char *e = getenv("KZG355_CHALLENGE")) s->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
-    if (const char *e = getenv("KZG355_LINCOMB")) s->lincomb_mode = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
+    s->lane_pairing = opt.pairing_lane != 0;
+    if (opt.split_parts >= 1 && opt.split_parts <= 64) s->split_parts = opt.split_parts;
+    if (opt.split_streams >= 1 && opt.split_streams <= 8) s->split_streams = opt.split_streams;
+    s->challenge_form = opt.challenge_form;
+    s->lincomb_mode = opt.lincomb_form;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
@@ -932,26 +994,22 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
     g1b.release(); g2b.release(); err.release();
-    {   // the 23.6 GB wide-window MSM table (KZG355_MSM=bucket keeps the 15 MB 8-bit form only; so does a failed allocation)
-        const char *e = getenv("KZG355_MSM");
-        if (!small && !(e && strcmp(e, "bucket") == 0)) {
-            int bits = 12;
-            if (const char *b = getenv("KZG355_MSM_BITS")) { const int v = atoi(b); if (v >= 10 && v <= 14) bits = v; }
+    {   // the 23.6 GB wide-window MSM table (msm_bits = 8 keeps the 15 MB 8-bit form only; so does a failed allocation)
+        if (!small && opt.msm_bits != 8) {
+            const int bits = opt.msm_bits >= 10 && opt.msm_bits <= 15 ? opt.msm_bits : 12;
+            const bool required = opt.msm_require_wide != 0;
             s->t.wide = wide_shape(bits);
             if (s->wide.ensure(wide_table_bytes(s->t.wide)) == KZG355_OK) {
                 s->t.wide_table = s->wide.as<WideRow>();
-                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_DEVICE_ERROR; } }
-            } else { s->wide_table_failed = true; if (e && strcmp(e, "wide") == 0) { kzg355_free_trusted_setup(s); return KZG355_NO_MEMORY; } }
+                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (required) { kzg355_free_trusted_setup(s); return KZG355_DEVICE_ERROR; } }
+            } else { s->wide_table_failed = true; if (required) { kzg355_free_trusted_setup(s); return KZG355_NO_MEMORY; } }
             if (s->wide_table_failed) fprintf(stderr, "kzg355: the %.1f GB wide-window MSM table could not be allocated; commitments / proofs take the 8-bit bucket form (about 3x slower, same results)\n", wide_table_bytes(s->t.wide) / 1e9);
             (void)hipGetLastError();
         }
     }
-    {   // known-answer self-test of the freshly built handle (KZG355_SELFTEST=0 skips it)
-        const char *e = getenv("KZG355_SELFTEST");
-        if (!(e && atoi(e) == 0)) {
-            const int rc = device_self_test(s);
-            if (rc != KZG355_OK) { kzg355_free_trusted_setup(s); return rc; }
-        }
+    if (opt.self_test) {   // known-answer self-test of the freshly built handle
+        const int rc = device_self_test(s);
+        if (rc != KZG355_OK) { kzg355_free_trusted_setup(s); return rc; }
     }
     *out = s;
     return KZG355_OK;
@@ -1081,15 +1139,15 @@ struct MultiDev {
 static void free_single(kzg355_settings *s);
 static std::vector<kzg355_settings *> replicas_of(kzg355_settings *s) { return s->multi ? s->multi->rep : std::vector<kzg355_settings *>{s}; }
 
-int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
-                                      kzg355_settings **out) {
+static int load_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices, const kzg355_options &opt,
+                        kzg355_settings **out) {
     if (!out || !devices || n_devices == 0 || n_devices > 64) return KZG355_BADARGS;
     DeviceScope keep; keep.hold();               // the peer-access loop and the communicator set-up visit every device: the caller's current device comes back
     std::vector<kzg355_settings *> rep;
     auto fail = [&](int code) { for (auto *r : rep) free_single(r); return code; };
     for (size_t i = 0; i < n_devices; i++) {
         kzg355_settings *r = nullptr;
-        int rc = load_on_device(g1_bytes, n1, g2_bytes, n2, devices[i], &r);
+        int rc = load_on_device(g1_bytes, n1, g2_bytes, n2, devices[i], opt, &r);
         if (rc) return fail(rc);
         rep.push_back(r);
     }
@@ -1101,20 +1159,34 @@ int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const 
     for (size_t i = 0; i < n_devices; i++)                       // peer access speeds up the record copies; not required
         for (size_t j = 0; j < n_devices; j++)
             if (devices[i] != devices[j] && hipSetDevice(devices[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
-    const char *ex = getenv("KZG355_EXCHANGE");
-    const bool want_rccl = !(ex && strcmp(ex, "peer") == 0);
+    const bool want_rccl = opt.exchange != 1;
     if (want_rccl && distinct && m->rccl.load()) {
         m->comms.assign(n_devices, nullptr);
         if (m->rccl.CommInitAll(m->comms.data(), (int)n_devices, devices) == 0) m->exchange = 1;
         else m->comms.clear();
     }
-    if (ex && strcmp(ex, "rccl") == 0 && m->exchange != 1) { delete m; return fail(KZG355_NO_DEVICE); }
+    if (opt.exchange == 2 && m->exchange != 1) { delete m; return fail(KZG355_DEVICE_ERROR); }
     rep[0]->multi = m;
     *out = rep[0];
     return KZG355_OK;
 }
 
+int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
+                                      kzg355_settings **out) {
+    kzg355_options o;
+    kzg355_options_from_env(&o);
+    return load_devices(g1_bytes, n1, g2_bytes, n2, devices, n_devices, o, out);
+}
+int kzg355_load_trusted_setup_ex(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices, size_t n_devices,
+                                 const kzg355_options *options, kzg355_settings **out) {
+    const kzg355_options o = options_of(options);
+    if (devices && n_devices) return load_devices(g1_bytes, n1, g2_bytes, n2, devices, n_devices, o, out);
+    return load_on_device(g1_bytes, n1, g2_bytes, n2, -1, o, out);
+}
+
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out) {
+    kzg355_options o;
+    kzg355_options_from_env(&o);
     // KZG355_DEVICES=0,1,...: the handle spans those devices; otherwise KZG355_DEVICE / the current device
     if (const char *e = getenv("KZG355_DEVICES")) {
         std::vector<int> devs;
@@ -1125,9 +1197,9 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
             devs.push_back((int)v);
             p = *end == ',' ? end + 1 : end;
         }
-        if (!devs.empty()) return kzg355_load_trusted_setup_devices(g1_bytes, n1, g2_bytes, n2, devs.data(), devs.size(), out);
+        if (!devs.empty()) return load_devices(g1_bytes, n1, g2_bytes, n2, devs.data(), devs.size(), o, out);
     }
-    return load_on_device(g1_bytes, n1, g2_bytes, n2, -1, out);
+    return load_on_device(g1_bytes, n1, g2_bytes, n2, -1, o, out);
 }
 int kzg355_settings_device_count(const kzg355_settings *s) { return !s ? 0 : s->multi ? (int)s->multi->rep.size() : 1; }
 int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, long *peer_exchanges) {

@@ -64,9 +64,8 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
     lines_w[i] = o;
 }
 
-void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st, int two_wave_upto) {
     if (groups <= 0) return;
-    static const int two_wave_upto = [] { const char *e = getenv("KZG355_PAIRING_2W_UPTO"); return e ? atoi(e) : 256; }();
     if (groups <= two_wave_upto) {          // two waves per batch while that still leaves most SIMDs a single wave
         hipLaunchKernelGGL(k_pairing_coop2, dim3(groups), dim3(128), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog,
                            t.pairing_prog_len, t.coop_scheds, d_ok);

@@ -96,7 +96,8 @@ void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups,
 void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                                int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st);
-void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);        // wave-cooperative (default)
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st,
+                    int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */);        // wave-cooperative (default)
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 
 // ---- k_pairing.hip

@@ -182,6 +182,26 @@ class KzgSettings:
         return KzgSettings(h)
 
     @staticmethod
+    def load_trusted_setup_ex(g1_bytes, g2_bytes, devices=None, **options):
+        """kzg355_load_trusted_setup_ex: explicit options (field names of struct kzg355_options, e.g. msm_bits=14, host_hash=-1); reads no
+        KZG355_* environment variable."""
+        g1_bytes, g2_bytes = list(g1_bytes), list(g2_bytes)
+        if any(len(x) != BYTES_PER_G1 for x in g1_bytes) or any(len(x) != BYTES_PER_G2 for x in g2_bytes):
+            raise InvalidBytesLength("trusted setup point length")
+        o = _lib.Options()
+        lib().kzg355_options_default(C.byref(o))
+        for k, v in options.items():
+            if k == "struct_size" or not hasattr(o, k):
+                raise BadArgs(f"unknown option {k}")
+            setattr(o, k, v)
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        h = C.c_void_p()
+        rc = lib().kzg355_load_trusted_setup_ex(b"".join(g1_bytes), len(g1_bytes), b"".join(g2_bytes), len(g2_bytes), devs, len(devices) if devices else 0,
+                                                C.byref(o), C.byref(h))
+        _check(rc, "load_trusted_setup_ex")
+        return KzgSettings(h)
+
+    @staticmethod
     def load_trusted_setup_file(path):
         h = C.c_void_p()
         rc = lib().kzg355_load_trusted_setup_file(os.fsencode(path), C.byref(h))

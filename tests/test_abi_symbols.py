@@ -85,3 +85,35 @@ def test_trusted_setup_json_helper(setup_bytes):
         kz.TrustedSetup.from_json(json.dumps({"setup_G1_lagrange": ["0x00"], "setup_G2": []}))
     with pytest.raises(kz.InvalidHexFormat):
         kz.TrustedSetup.from_json(json.dumps({"setup_G1_lagrange": ["0xzz"], "setup_G2": []}))
+
+
+def test_options_struct_defaults_env_overrides_and_layout(lib, monkeypatch):
+    """kzg355_options (include/kzg355.h): defaults, the KZG355_* overrides folded in by kzg355_options_from_env only, and the ctypes
+    mirror's layout (struct_size is sizeof as the C side sees it)."""
+    from kzg_rust_amd import _lib
+    o = _lib.Options()
+    lib.kzg355_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(_lib.Options)
+    assert (o.device, o.self_test, o.msm_bits, o.host_hash, o.host_hash_max_blobs, o.lc_chain_from) == (-1, 1, 0, 0, 0, 0)
+    for k, v in {"KZG355_MSM_BITS": "14", "KZG355_HOST_HASH": "off", "KZG355_HOST_HASH_MAX": "77", "KZG355_LINCOMB": "bucket", "KZG355_SPLIT": "4,3",
+                 "KZG355_SELFTEST": "0", "KZG355_DEVICE": "2", "KZG355_EXCHANGE": "peer", "KZG355_PAIRING_2W_UPTO": "0"}.items():
+        monkeypatch.setenv(k, v)
+    lib.kzg355_options_from_env(C.byref(o))
+    assert (o.msm_bits, o.host_hash, o.host_hash_max_blobs, o.lincomb_form, o.split_parts, o.split_streams, o.self_test, o.device, o.exchange,
+            o.pairing_two_wave_upto) == (14, -1, 77, 2, 4, 3, 0, 2, 1, -1)
+    monkeypatch.setenv("KZG355_MSM", "bucket")
+    lib.kzg355_options_from_env(C.byref(o))
+    assert o.msm_bits == 8
+    lib.kzg355_options_default(C.byref(o))                       # the explicit form never reads the environment
+    assert (o.msm_bits, o.host_hash, o.self_test) == (0, 0, 1)
+
+
+def test_load_ex_checks_counts_before_any_device_work(lib):
+    import torch
+    from kzg_rust_amd import _lib
+    h = C.c_void_p()
+    o = _lib.Options()
+    lib.kzg355_options_default(C.byref(o))
+    assert lib.kzg355_load_trusted_setup_ex(bytes(48 * 4095), 4095, bytes(96 * 65), 65, None, 0, C.byref(o), C.byref(h)) == 5
+    if not torch.cuda.is_available():
+        assert lib.kzg355_load_trusted_setup_ex(bytes(48 * 4096), 4096, bytes(96 * 65), 65, None, 0, None, C.byref(h)) == 6

@@ -190,3 +190,29 @@ def test_concurrent_host_hashed_calls(kz, settings, batch):
     finally:
         settings.set_host_hash(0)
     assert not errors, errors
+
+
+def test_explicit_options_ignore_the_environment(kz, setup_bytes, batch, monkeypatch):
+    """kzg355_load_trusted_setup_ex takes its knobs from the struct it is given: the KZG355_* variables (test overrides of the plain
+    load functions) do not reach it.  Checked on two knobs with visible effects: the MSM form and the host hashing."""
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    monkeypatch.setenv("KZG355_HOST_HASH", "on")
+    monkeypatch.setenv("KZG355_MSM_BITS", "13")
+    s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)],
+                                             msm_bits=8, host_hash=-1)
+    try:
+        assert s.msm_form == 8
+        B, Cm, Pr = [kz.Blob(b) for b in blobs[:5]], [kz.KzgCommitment(c) for c in cs[:5]], [kz.KzgProof(p) for p in ps[:5]]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, s) is True and s.host_hashed_calls == 0
+        assert kz.Kzg.blob_to_kzg_commitment(B[0], s).to_bytes() == cs[0]
+    finally:
+        s.free()
+    s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)],
+                                             host_hash=1, host_threads=3, lincomb_form=1, self_test=0)
+    try:
+        assert s.msm_form == 12
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, s) is True and s.host_hashed_calls == 1
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, [Pr[1]] + Pr[1:], s) is False
+    finally:
+        s.free()

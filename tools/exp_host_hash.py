@@ -46,7 +46,7 @@ def timed(npg, groups, mode, reps=9):
 
 
 print("call shape            blobs   host hash (median / min ms)   device hash (median / min ms)")
-for npg, groups in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (128, 1), (64, 4), (64, 8), (64, 16), (64, 32), (64, 48)):
+for npg, groups in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (128, 1), (64, 4), (64, 8), (64, 16), (64, 32), (64, 48), (64, 64), (64, 128)):
     h = timed(npg, groups, 1); d = timed(npg, groups, -1)
     print(f"{groups:3d} x {npg:3d}            {npg * groups:6d}   {h[0]:8.3f} / {h[1]:8.3f}            {d[0]:8.3f} / {d[1]:8.3f}")
 
