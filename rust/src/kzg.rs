@@ -4,7 +4,7 @@
 use crate::consts::*;
 use crate::ffi;
 use std::ffi::CString;
-use std::ops::Deref;
+use std::ops::{Deref, DerefMut};
 use std::path::Path;
 
 #[derive(Debug)]
@@ -28,7 +28,7 @@ fn check(rc: i32, what: &str) -> Result<(), Error> {
         ffi::KZG355_INVALID_BYTES_LENGTH => Err(Error::InvalidBytesLength(what.into())),
         ffi::KZG355_INVALID_HEX => Err(Error::InvalidHexFormat(what.into())),
         ffi::KZG355_INVALID_TRUSTED_SETUP => Err(Error::InvalidTrustedSetup(what.into())),
-        _ => Err(Error::InternalError), // INTERNAL, NO_DEVICE, NO_MEMORY
+        _ => Err(Error::InternalError), // INTERNAL, NO_DEVICE, NO_MEMORY, DEVICE_ERROR: no reference counterpart (there is no CPU fallback)
     }
 }
 
@@ -71,6 +71,38 @@ impl KzgSettings {
             "load_trusted_setup_on_devices",
         )?;
         Ok(Self { raw })
+    }
+
+    /// Extension: explicit engine options (`ffi::kzg355_options`, filled from `KzgSettings::default_options()`); no environment
+    /// variable is read on this path.
+    pub fn load_trusted_setup_with_options(
+        g1_bytes: Vec<[u8; BYTES_PER_G1]>,
+        g2_bytes: Vec<[u8; BYTES_PER_G2]>,
+        devices: &[i32],
+        options: &ffi::kzg355_options,
+    ) -> Result<Self, Error> {
+        let g1: Vec<u8> = g1_bytes.iter().flatten().copied().collect();
+        let g2: Vec<u8> = g2_bytes.iter().flatten().copied().collect();
+        let mut raw = std::ptr::null_mut();
+        let devs = if devices.is_empty() { std::ptr::null() } else { devices.as_ptr() };
+        check(
+            unsafe { ffi::kzg355_load_trusted_setup_ex(g1.as_ptr(), g1_bytes.len(), g2.as_ptr(), g2_bytes.len(), devs, devices.len(), options, &mut raw) },
+            "load_trusted_setup_with_options",
+        )?;
+        Ok(Self { raw })
+    }
+
+    pub fn default_options() -> ffi::kzg355_options {
+        let mut o = std::mem::MaybeUninit::<ffi::kzg355_options>::zeroed();
+        unsafe {
+            ffi::kzg355_options_default(o.as_mut_ptr());
+            o.assume_init()
+        }
+    }
+
+    /// FIELD_ELEMENTS_PER_BLOB of this handle (4096, or 4 for a minimal-preset setup).
+    pub fn field_elements_per_blob(&self) -> usize {
+        unsafe { ffi::kzg355_settings_field_elements_per_blob(self.raw) as usize }
     }
 
     pub fn load_trusted_setup_file<P: AsRef<Path>>(trusted_setup_file: P) -> Result<Self, Error> {
@@ -151,6 +183,17 @@ impl Deref for Blob {
         &self.bytes
     }
 }
+// the reference lets callers build and edit blobs in place (kzg.rs:222-228, 262-266: the bench fills arrays and converts them)
+impl DerefMut for Blob {
+    fn deref_mut(&mut self) -> &mut Self::Target {
+        &mut self.bytes
+    }
+}
+impl From<[u8; BYTES_PER_BLOB]> for Blob {
+    fn from(value: [u8; BYTES_PER_BLOB]) -> Self {
+        Self { bytes: Box::new(value) }
+    }
+}
 
 macro_rules! g1_newtype {
     ($name:ident, $n:expr) => {
@@ -162,6 +205,11 @@ macro_rules! g1_newtype {
             }
             pub fn to_bytes(self) -> [u8; $n] {
                 self.0.bytes
+            }
+        }
+        impl From<Bytes48> for $name {
+            fn from(b: Bytes48) -> Self {
+                Self(b)
             }
         }
         impl From<[u8; $n]> for $name {
@@ -240,11 +288,7 @@ impl Kzg {
     }
 
     pub fn verify_blob_kzg_proof_batch(blobs: &[Blob], commitment_bytes: &[KzgCommitment], proof_bytes: &[KzgProof], s: &KzgSettings) -> Result<bool, Error> {
-        // `&[Blob]` is a slice of boxes: the blobs are not contiguous in memory, the ABI wants one buffer
-        let mut staged = Vec::with_capacity(blobs.len() * BYTES_PER_BLOB);
-        for b in blobs {
-            staged.extend_from_slice(&b[..]);
-        }
+        let staged = stage_blobs(blobs);
         let c: Vec<u8> = commitment_bytes.iter().flat_map(|x| x.to_bytes()).collect();
         let p: Vec<u8> = proof_bytes.iter().flat_map(|x| x.to_bytes()).collect();
         let mut ok = false;
@@ -257,4 +301,79 @@ impl Kzg {
         )?;
         Ok(ok)
     }
+
+    // ---- throughput extensions (no reference counterpart): many independent units per call, one set of kernel launches ----
+
+    /// `blobs.len()` independent `blob_to_kzg_commitment` calls; one `Result` per blob.
+    pub fn blob_to_kzg_commitment_many(blobs: &[Blob], s: &KzgSettings) -> Result<Vec<Result<KzgCommitment, Error>>, Error> {
+        let n = blobs.len();
+        let staged = stage_blobs(blobs);
+        let mut out = vec![0u8; BYTES_PER_COMMITMENT * n.max(1)];
+        let mut st = vec![0i32; n.max(1)];
+        let rc = unsafe { ffi::kzg355_blob_to_kzg_commitment_many(out.as_mut_ptr(), st.as_mut_ptr(), staged.as_ptr(), n, s.raw) };
+        whole_call(rc, &st[..n], "blob_to_kzg_commitment_many")?;
+        Ok((0..n)
+            .map(|i| check(st[i], "commit").map(|_| KzgCommitment::from(<[u8; BYTES_PER_COMMITMENT]>::try_from(&out[48 * i..48 * i + 48]).unwrap())))
+            .collect())
+    }
+
+    /// `blobs.len()` independent `compute_blob_kzg_proof` calls.
+    pub fn compute_blob_kzg_proof_many(blobs: &[Blob], commitments: &[KzgCommitment], s: &KzgSettings) -> Result<Vec<Result<KzgProof, Error>>, Error> {
+        if blobs.len() != commitments.len() {
+            return Err(Error::BadArgs("length mismatch".into()));
+        }
+        let n = blobs.len();
+        let staged = stage_blobs(blobs);
+        let c: Vec<u8> = commitments.iter().flat_map(|x| x.to_bytes()).collect();
+        let mut out = vec![0u8; BYTES_PER_PROOF * n.max(1)];
+        let mut st = vec![0i32; n.max(1)];
+        let rc = unsafe { ffi::kzg355_compute_blob_kzg_proof_many(out.as_mut_ptr(), st.as_mut_ptr(), staged.as_ptr(), c.as_ptr(), n, s.raw) };
+        whole_call(rc, &st[..n], "compute_blob_kzg_proof_many")?;
+        Ok((0..n)
+            .map(|i| check(st[i], "proof").map(|_| KzgProof::from(<[u8; BYTES_PER_PROOF]>::try_from(&out[48 * i..48 * i + 48]).unwrap())))
+            .collect())
+    }
+
+    /// `groups` independent `verify_blob_kzg_proof_batch` calls of `n_per_group` blobs each (inputs group-major).
+    pub fn verify_blob_kzg_proof_batch_many(
+        blobs: &[Blob],
+        commitments: &[KzgCommitment],
+        proofs: &[KzgProof],
+        n_per_group: usize,
+        s: &KzgSettings,
+    ) -> Result<Vec<Result<bool, Error>>, Error> {
+        if blobs.len() != commitments.len() || blobs.len() != proofs.len() || n_per_group == 0 || blobs.len() % n_per_group != 0 {
+            return Err(Error::BadArgs("length mismatch".into()));
+        }
+        let groups = blobs.len() / n_per_group;
+        let staged = stage_blobs(blobs);
+        let c: Vec<u8> = commitments.iter().flat_map(|x| x.to_bytes()).collect();
+        let p: Vec<u8> = proofs.iter().flat_map(|x| x.to_bytes()).collect();
+        let mut ok = vec![false; groups.max(1)];
+        let mut st = vec![0i32; groups.max(1)];
+        let rc = unsafe {
+            ffi::kzg355_verify_blob_kzg_proof_batch_many(ok.as_mut_ptr(), st.as_mut_ptr(), staged.as_ptr(), c.as_ptr(), p.as_ptr(), n_per_group, groups, s.raw)
+        };
+        whole_call(rc, &st[..groups], "verify_blob_kzg_proof_batch_many")?;
+        Ok((0..groups).map(|g| check(st[g], "verify").map(|_| ok[g])).collect())
+    }
+}
+
+/// `&[Blob]` is a slice of boxes: the blobs are not contiguous in memory, the ABI wants one buffer.
+fn stage_blobs(blobs: &[Blob]) -> Vec<u8> {
+    let mut staged = Vec::with_capacity(blobs.len() * BYTES_PER_BLOB);
+    for b in blobs {
+        staged.extend_from_slice(&b[..]);
+    }
+    staged
+}
+
+/// A `*_many` call that failed as a whole (device, allocation or library failure -- or a non-zero return with no unit carrying a
+/// status) is an `Err` of the call; per-unit statuses are then not to be trusted.
+fn whole_call(rc: i32, st: &[i32], what: &str) -> Result<(), Error> {
+    let whole = matches!(rc, ffi::KZG355_INTERNAL | ffi::KZG355_NO_DEVICE | ffi::KZG355_NO_MEMORY | ffi::KZG355_DEVICE_ERROR);
+    if whole || (rc != ffi::KZG355_OK && st.iter().all(|&x| x == 0)) {
+        return check(rc, what);
+    }
+    Ok(())
 }

@@ -1,6 +1,6 @@
 //! kzg_rust with the MI355X engine behind `Kzg` (see README.md in this directory).
 mod consts;
-mod ffi;
+pub mod ffi; // public: `KzgSettings::load_trusted_setup_with_options` takes `ffi::kzg355_options`
 mod kzg;
 mod trusted_setup;
 
