@@ -91,6 +91,9 @@ typedef struct kzg355_options {
     int host_hash;             /* challenges of host-buffer verify / blob-proof calls hashed on the host: 0 by size, 1 always, -1 never  KZG355_HOST_HASH=auto|on|off */
     int host_hash_max_blobs;   /* ... up to this many blobs per call (0 = 4096: measured crossover, profiles/r03/host_hash_crossover_v3.txt)          KZG355_HOST_HASH_MAX */
     int host_sha;              /* host SHA-256 form: 0 SHA extensions when the CPU has them, 1 portable C, 2 SHA extensions      KZG355_HOST_SHA=portable|shani */
+    int host_rhash;            /* batch challenge r of lone small calls hashed on the host (records copied back, ~60 us instead of a 0.33 ms
+                                  device chain): 0 by size, -1 never                                                       KZG355_HOST_RHASH=off */
+    int host_rhash_max_records;/* ... up to this many records per call (0 = 256)                                           KZG355_HOST_RHASH_MAX */
     int challenge_form;        /* device Fiat-Shamir kernel: 0 by size (two-wave form up to 2 workgroups per CU), 1 one wave, 2 two waves   KZG355_CHALLENGE=1w|2w */
     int lincomb_form;          /* batch linear combination: 0 by size, 1 per-term windows, 2 buckets, 3 pre-shifted        KZG355_LINCOMB=window|bucket|preshift */
     int pairing_lane;          /* 1: one-lane pairing kernel (A/B and tests)                                               KZG355_PAIRING=lane */

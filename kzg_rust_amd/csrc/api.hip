@@ -76,7 +76,7 @@ struct Workspace {
     bool side_pending = false, pts_pending = false, shift_pending = false;
     DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests;
     bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
-    PinBuf h_ok, h_err, h_out, h_digests;
+    PinBuf h_ok, h_err, h_out, h_digests, h_records, h_rdig;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
     hipEvent_t ev[32];
     bool ev_ok = false;
@@ -92,7 +92,7 @@ struct Workspace {
     }
     ~Workspace() {
         for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests}) b->release();
-        h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release();
+        h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift}) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
@@ -204,6 +204,8 @@ struct kzg355_settings {
     hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
     int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v3.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
+    int host_rhash = 0;              // batch challenge r of lone small calls hashed on the host (records copied back): 0 by size, -1 never (KZG355_HOST_RHASH=off)
+    int host_rhash_max_records = 256;    // records per call up to which that is done
     int sha_impl = 0;                // host SHA-256 form: 0 auto (SHA extensions when the CPU has them), 1 portable, 2 SHA extensions (KZG355_HOST_SHA=portable|shani)
     std::atomic<long> n_host_hashed{0};   // introspection: host-buffer calls whose challenges were hashed on the host
     std::vector<Workspace *> pool;
@@ -434,7 +436,28 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if ((rc = w->scal_b.ensure(32 * n_total))) return rc;
     if ((rc = w->scal_c.ensure(32 * (size_t)groups))) return rc;
     if ((rc = w->pair_pts.ensure(sizeof(PairPt) * 2 * (size_t)groups))) return rc;
-    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe, s->rhash_lanes_from); tm.end();
+    // The batch challenge r hashes every record of the batch (utils.rs:439-473): one serial SHA-256 chain per batch -- 161 compressions
+    // for 64 records, 0.33 ms on a lone GPU lane whatever else the card does.  For a lone small call the records go to the host instead
+    // (10 KB for 64), a host core hashes them in microseconds (host_sha256.h) and 32 bytes per batch come back: ~60 us of round trip
+    // in place of the chain.  Large or many-batch calls keep the device forms (k_rpowers / k_rhash_lanes).
+    bool host_rhash = s->host_rhash >= 0 && npg > 1 && n_total <= (size_t)s->host_rhash_max_records && !is_small(s);
+    if (host_rhash && ((rc = w->h_records.ensure((size_t)RECORD_BYTES * n_total)) || (rc = w->h_rdig.ensure(32 * (size_t)groups)))) return rc;
+    if (host_rhash) {
+        HIPCHK(hipMemcpyAsync(w->h_records.p, d_records, (size_t)RECORD_BYTES * n_total, hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(hipStreamSynchronize(w->stream));
+        std::vector<uint8_t> msg(32 + (size_t)RECORD_BYTES * npg);
+        memcpy(msg.data(), "RCKZGBATCH___V1_", 16);                            // RANDOM_CHALLENGE_KZG_BATCH_DOMAIN (consts.rs:25)
+        for (int k = 0; k < 8; k++) { msg[16 + k] = (uint8_t)((uint64_t)s->t.n_fe >> (56 - 8 * k)); msg[24 + k] = (uint8_t)((uint64_t)npg >> (56 - 8 * k)); }
+        for (int g = 0; g < groups; g++) {
+            memcpy(msg.data() + 32, w->h_records.as<uint8_t>() + (size_t)RECORD_BYTES * npg * g, (size_t)RECORD_BYTES * npg);
+            uint8_t dg[32];
+            kzg_host::sha256(dg, msg.data(), msg.size(), s->sha_impl);
+            uint32_t *dst = w->h_rdig.as<uint32_t>() + 8 * (size_t)g;            // the digest as an integer: 8 little-endian 32-bit words (what k_rhash_lanes leaves)
+            for (int k = 0; k < 8; k++) dst[k] = ((uint32_t)dg[28 - 4 * k] << 24) | ((uint32_t)dg[29 - 4 * k] << 16) | ((uint32_t)dg[30 - 4 * k] << 8) | dg[31 - 4 * k];
+        }
+        HIPCHK(hipMemcpyAsync(w->scal_c.p, w->h_rdig.p, 32 * (size_t)groups, hipMemcpyHostToDevice, w->stream));
+    }
+    tm.begin("rpowers"); launch_rpowers(d_records, npg, groups, check_zy, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), d_err, w->stream, s->t.n_fe, s->rhash_lanes_from, host_rhash ? 1 : 0); tm.end();
     const int form = lincomb_form(s, npg, groups);
     const bool buckets = form == LC_FORM_BUCKET;
     if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
@@ -863,6 +886,8 @@ void kzg355_options_from_env(kzg355_options *o) {
     if (const char *e = getenv("KZG355_HOST_HASH")) o->host_hash = strcmp(e, "on") == 0 ? 1 : strcmp(e, "off") == 0 ? -1 : 0;
     num("KZG355_HOST_HASH_MAX", 1, 1 << 24, &o->host_hash_max_blobs);
     if (const char *e = getenv("KZG355_HOST_SHA")) o->host_sha = strcmp(e, "portable") == 0 ? 1 : strcmp(e, "shani") == 0 ? 2 : 0;
+    if (const char *e = getenv("KZG355_HOST_RHASH")) o->host_rhash = strcmp(e, "off") == 0 ? -1 : 0;
+    num("KZG355_HOST_RHASH_MAX", 1, 1 << 20, &o->host_rhash_max_records);
     num("KZG355_CHUNK_MB", 1, 16384, &o->chunk_mb);
     if (const char *e = getenv("KZG355_STAGING")) o->staging_ring = strcmp(e, "ring") == 0;
     num("KZG355_CHUNKS_IN_FLIGHT", 1, 8, &o->chunks_in_flight);
@@ -963,6 +988,8 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         s->host_hash = opt.host_hash;
         if (opt.host_hash_max_blobs > 0) s->host_hash_max = opt.host_hash_max_blobs;
         s->sha_impl = opt.host_sha;
+        s->host_rhash = opt.host_rhash;
+        if (opt.host_rhash_max_records > 0) s->host_rhash_max_records = opt.host_rhash_max_records;
         if (opt.chunk_mb > 0) s->chunk_bytes = (size_t)opt.chunk_mb << 20;
         s->pinned_ring = opt.staging_ring != 0;
         if (opt.chunks_in_flight >= 1 && opt.chunks_in_flight <= 8) s->chunks_in_flight = opt.chunks_in_flight;

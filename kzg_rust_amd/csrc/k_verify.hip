@@ -534,15 +534,15 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
     hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, t.eval_tab, n_per_group, d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
-                    uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe, int lanes_from) {
+                    uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe, int lanes_from, int have_digest) {
     if (groups <= 0) return;
     // four waves per workgroup once there are more batches than CUs can take one each (even placement); below that one wave per
     // workgroup: four of these LDS-latency-bound single-lane chains on one CU slow each other down (512-blob batches: 3x)
     const int wpw = groups > 512 ? 4 : 1;
     // from one wave per SIMD on (lanes_from, default 1024 batches), hash with a lane per batch first (k_rhash_lanes)
-    const int lanes = (n_per_group > 1 && groups >= lanes_from) ? 1 : 0;
+    const int lanes = (!have_digest && n_per_group > 1 && groups >= lanes_from) ? 1 : 0;
     if (lanes) hipLaunchKernelGGL(k_rhash_lanes, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, d_scal_c, n_fe);
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes);
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes || have_digest);
 }
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;

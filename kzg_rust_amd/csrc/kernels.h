@@ -76,7 +76,8 @@ void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_to
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st);
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe = N_FE /* the u64be(FIELD_ELEMENTS_PER_BLOB) field of the transcript */,
-                    int lanes_from = 1024 /* batches from which the hash runs one lane per batch (k_rhash_lanes) */);
+                    int lanes_from = 1024 /* batches from which the hash runs one lane per batch (k_rhash_lanes) */,
+                    int have_digest = 0 /* 1: the transcript digests are already in d_scal_c (8 little-endian words per batch: hashed on the host) */);
 void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                     int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, PairPt *d_pair_pts /* [group][2]: -proof_lincomb, rhs */,
                     hipStream_t st);

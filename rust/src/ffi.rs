@@ -31,6 +31,8 @@ pub struct kzg355_options {
     pub host_hash: c_int,
     pub host_hash_max_blobs: c_int,
     pub host_sha: c_int,
+    pub host_rhash: c_int,
+    pub host_rhash_max_records: c_int,
     pub challenge_form: c_int,
     pub lincomb_form: c_int,
     pub pairing_lane: c_int,
