@@ -121,9 +121,10 @@ def main():
         else:
             dist.init_process_group(backend)
     if args.op != "verify":
-        # commit / proof are bound by the fixed-base MSM: 14-bit windows (19 windows, 81.6 GB table) instead of the handle's default 12-bit
-        # (22 windows, 23.6 GB) -- a deployment that serves commitments sets the same knob; the verify path never reads the table
-        os.environ.setdefault("KZG355_MSM_BITS", "14")
+        # commit / proof are bound by the fixed-base MSM: 15-bit windows (17 full windows + a carry window, 154.6 GB table) instead of the handle's
+        # default 12-bit (22 windows, 23.6 GB) -- a deployment that serves commitments sets the same knob (kzg355_options.msm_bits); the
+        # verify path never reads the table.  Measured: 12 / 13 / 14 / 15 bits -> 75 / 79 / 88 / 92 k commitments per second.
+        os.environ.setdefault("KZG355_MSM_BITS", "15")
     import kzg_rust_amd as kz
     from synth import random_blob
     L = kz.kzg.lib()
@@ -288,7 +289,7 @@ def main():
             return blobs_events / stats[fam][1] if fam in PER_BATCH_FAMILIES else blobs_events / world / stats[fam][1]
         blobs_per_launch = blobs_per_launch_of(dom)
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(dom, blobs_per_launch)
+        traffic, traffic_src = pmc_traffic(dom, blobs_per_launch, None if args.op == "verify" else args.op)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch,
@@ -300,6 +301,16 @@ def main():
                     "measured_stream_copy_gbps": stream_copy_peak(torch, dev) if rank == 0 else None,
                     "alu": alu_roofline(stats, blobs_per_launch_of, value / world) if args.op == "verify" else None,      # (the committed SQ pass is over the verify bench)
                     "note": "integer-issue-bound path (~1e3 integer ops per byte): the HBM fraction is small by construction; roofline.alu is the bound that binds"}
+        if args.op != "verify" and s.msm_form >= 10:
+            # the memory-side bound of the fixed-base MSM is not streaming bandwidth but RANDOM 128-byte row gathers: one table row per (window, scalar).
+            # Measured ceiling of that access pattern on MI355X: tools/ubench/gather_rate.hip, profiles/r03/gather_rate_random_128B.txt
+            bits = s.msm_form
+            windows = (256 + bits - 1) // bits
+            rows_per_blob = 4096 * (windows if bits != 15 else 17.45)      # 15 bits: 17 full windows and a carry window hit by 45 % of the scalars
+            rows_per_s = rows_per_blob * value / world
+            roofline["gather"] = {"rows_per_blob": round(rows_per_blob), "achieved_rows_per_s": rows_per_s, "achieved_gbps": round(rows_per_s * 128 / 1e9, 1),
+                                  "measured_random_128B_gather_peak_gbps": 1427.0, "frac_of_gather_peak": round(rows_per_s * 128 / 1427.0e9, 4),
+                                  "source": "profiles/r03/gather_rate_random_128B.txt (11.1 G rows/s; streaming read of the same buffer: 5678 GB/s)"}
 
     host_inputs = None
     if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
@@ -368,13 +379,20 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
     h = t_blobs[:nb * BLOB].cpu().numpy()
     hp = h.ctypes.data_as(C.c_char_p)
     ok1 = C.c_bool()
-    lat = []
-    for i in range(7):
-        t0 = time.perf_counter()
-        rc = L.kzg355_verify_blob_kzg_proof_batch(C.byref(ok1), hp, n_local, commitments[:48 * n_local], n_local, proofs[:48 * n_local], n_local, s.handle)
-        lat.append((time.perf_counter() - t0) * 1e3)
-        assert rc == 0 and ok1.value
-    lat = lat[2:]
+
+    def single_calls(reps):
+        ts = []
+        for i in range(reps + 2):
+            t0 = time.perf_counter()
+            rc = L.kzg355_verify_blob_kzg_proof_batch(C.byref(ok1), hp, n_local, commitments[:48 * n_local], n_local, proofs[:48 * n_local], n_local, s.handle)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert rc == 0 and ok1.value
+        return ts[2:]
+    lat = single_calls(15)                                        # the library's default route: challenges hashed on the host for a call of this size
+    hashed_on_host = s.host_hashed_calls > 0
+    s.set_host_hash(-1)
+    lat_dev = single_calls(7)                                     # the same call with the device hash forced (A/B of the host route)
+    s.set_host_hash(0)
     okg = (C.c_bool * groups)(); stg = (C.c_int * groups)()
     rates = []
     for i in range(4):
@@ -387,16 +405,23 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
     best = max(rates)
     return {"single_call_ms": round(statistics.median(lat), 3), "single_call_ms_min": round(min(lat), 3),
             "single_call_blobs_per_s": round(n_local / (statistics.median(lat) / 1e3), 1),
+            "single_call_route": "Fiat-Shamir challenges and the batch challenge hashed on host threads while the copies and point kernels run" if hashed_on_host else "device hash",
+            "single_call_ms_device_hash": round(statistics.median(lat_dev), 3),
             "stream_blobs_per_s": round(statistics.median(rates), 1), "stream_blobs_per_s_best": round(best, 1),
             "stream_h2d_gbps": round(statistics.median(rates) * (BLOB + 96) / 1e9, 2), "stream_blobs_per_call": nb,
-            "note": "pageable caller memory -> HBM inside the call (the runtime locks the caller's pages and DMAs from them, 1 GiB chunks over 3 streams); never `value`"}
+            "note": "pageable caller memory -> HBM inside the call (the runtime locks the caller's pages and DMAs from them, 1 GiB chunks over 3 streams); never `value`.  "
+                    "single_call = one verify_blob_kzg_proof_batch(n = 64) on host slices, the reference bench's own shape (benches/kzg_benches.rs:113-120)"}
 
 
-def newest_profile(stem, key):
-    """newest committed profiles/rNN/<stem>[_tag]_vK.json that has one of `key` in its per_kernel map (numeric round / version order)."""
+def newest_profile(stem, key, tag=None):
+    """newest committed profiles/rNN/<stem>[_tag]_vK.json that has one of `key` in its per_kernel map (numeric round / version order).  tag:
+    the summary of that bench op (`commit` / `proof`: their MSM kernels run at another launch size and table width than the ones in the verify
+    bench's untimed setup); None: the untagged (verify) summary.  Falls back to any summary that has the kernel."""
     def version(f):
-        m = re.search(r"r(\d+)[/\\]" + stem + r"(_\w+?)?_v(\d+)\.json$", f)
-        return (int(m.group(1)), int(m.group(3)), 0 if m.group(2) else 1) if m else (0, 0, 0)     # untagged (verify) summary first
+        m = re.search(r"r(\d+)[/\\]" + stem + r"(?:_(\w+?))?_v(\d+)\.json$", f)
+        if not m:
+            return (0, 0, 0)
+        return (1 if (m.group(2) or None) == tag else 0, int(m.group(1)), int(m.group(3)))
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", stem + "_*.json")), key=version, reverse=True):
         try:
             per = json.load(open(f))["per_kernel"]
@@ -407,13 +432,13 @@ def newest_profile(stem, key):
     return None, None
 
 
-def pmc_traffic(kernel_family, blobs_per_launch):
+def pmc_traffic(kernel_family, blobs_per_launch, tag=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE as is; separate passes, collected with this same bench command).  The counters are per
     blob there; scaled to this run's launch size.  None if no summary is committed for that kernel."""
     if kernel_family not in KERNEL_NAMES:
         return None, None
-    f, per = newest_profile("pmc_traffic", KERNEL_NAMES[kernel_family])
+    f, per = newest_profile("pmc_traffic", KERNEL_NAMES[kernel_family], tag)
     if not f:
         return None, None
     ds = [per[k] for k in KERNEL_NAMES[kernel_family] if k in per]

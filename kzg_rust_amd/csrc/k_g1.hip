@@ -8,6 +8,7 @@
 #define KZG_FP_MUL_NOINLINE 1
 #endif
 #include "kernels.h"
+#include "g1_quad.h"
 
 namespace kzg {
 
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, Pa
 // shifting hides under the hash next to the point validation.  More total work than either other form (every point is doubled
 // 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (fewer than 64 batches of <= 128 blobs; from 64 batches on the bucket form).
 constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
-constexpr int PS_THREADS = 256, PS_LANES_PER_BUCKET = 64, PS_BUCKETS_PER_WG = PS_THREADS / PS_LANES_PER_BUCKET, PS_PARTS = LC_BUCKETS / PS_BUCKETS_PER_WG;     // 4 buckets per workgroup, 4 workgroups per (batch, class)
+constexpr int PS_THREADS = 256;                            // one workgroup per (batch, class, bucket): 64 quads
 __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
 // thread (g, pt): Q[w] = 32^w P for w = 0..25.  Point 2n of every batch is -G (the term -[sum r^i y_i] G).
 // The chain starts from x ALONE, so it does not wait for the square root of the decompression (a second 0.6 ms chain; with the
@@ -460,53 +461,7 @@ __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }           
 // multiplies Z by y -- the sign of y included -- when it reads a shifted point; by then the decompression kernel has long finished.
 // Inputs: validated affine points (pts != null: entry points without a stage 1) or the compressed bytes themselves (a bad encoding
 // is treated as the point at infinity here; the decompression kernel raises the error).
-// The chain itself is walked by FOUR lanes per point (a DPP quad).  A lone wave issues one instruction per ~5 cycles whatever it is,
-// so a doubling costs its instruction count: 5 squarings + 2 products in a row on one lane (dbl-2009-l).  Its products come in three
-// dependent stages, and within a stage they are independent:
-//     stage 1:  A = X^2,  B = Y^2,  S = (Y + Z)^2,  ZZ = Z^2          (four lanes, one squaring each;  Z3 = S - B - ZZ = 2 Y Z)
-//     stage 2:  F = (3A)^2,  C = B^2,  G = (X + B)^2                   (three lanes;  D = 2 (G - A - C),  X3 = F - 2D)
-//     stage 3:  E (D - X3)                                             (every lane for itself;  Y3 = E (D - X3) - 8C)
-// so the quad runs ONE squaring body per stage, each lane on its own operand (picked by v_cndmask), and the results are broadcast with
-// quad_perm DPP moves: 2 squarings + 1 product deep instead of 5 + 2.  All four lanes carry the same (X, Y, Z) and do the cheap linear
-// steps redundantly.  Lazy bounds as in g1_dbl_lazy (g1.h): in X, Y, Z < 32p, out X < 26p, Y < 18p, Z < 6p.
-template <int K> __device__ __forceinline__ Fp fp_quad_bcast(const Fp &v) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < NFP; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55 /* quad_perm: [K, K, K, K] */, 0xf, 0xf, false);
-    return r;
-}
-__device__ __forceinline__ void fp_mul3_lz(Fp &r, const Fp &a) {        // 3a, limbs normalised
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < NFP; i++) { const uint32_t t = 3u * a.l[i] + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
-}
-__device__ __forceinline__ void fp_mul8_lz(Fp &r, const Fp &a) {        // 8a, limbs normalised (a's limbs below the top one < 2^29)
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < NFP; i++) { const uint32_t t = (a.l[i] << 3) + c; if (i < NFP - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t; }
-}
-__device__ __forceinline__ void g1_dbl_quad(G1Jac &p, int role) {
-    const uint32_t m2[NFP] = FP_MOD2_INIT, m8[NFP] = FP_MOD8_INIT, m16[NFP] = FP_MOD16_INIT, m32[NFP] = FP_MOD32_INIT;
-    Fp u, r, t, v;
-    fp_add_lz(t, p.y, p.z);                                       // Y + Z                           < 64p
-    fp_select(u, role == 1, p.x, p.y); fp_select(u, role == 2, u, t); fp_select(u, role == 3, u, p.z);
-    fp_sqr_lz(r, u);
-    const Fp A = fp_quad_bcast<0>(r), B = fp_quad_bcast<1>(r), S = fp_quad_bcast<2>(r), ZZ = fp_quad_bcast<3>(r);
-    Fp Z3; fp_sub_lz(t, S, B, m2); fp_sub_lz(Z3, t, ZZ, m2);     // S - B - ZZ + 4p                 in (0, 6p)
-    Fp E; fp_mul3_lz(E, A);                                       // E = 3A                          < 4p
-    fp_add_lz(t, p.x, B);                                         // X + B                           < 34p
-    fp_select(u, role == 1, E, B); fp_select(u, role == 2, u, t);
-    fp_sqr_lz(r, u);
-    const Fp F = fp_quad_bcast<0>(r), C = fp_quad_bcast<1>(r), G = fp_quad_bcast<2>(r);
-    fp_sub_lz(t, G, A, m2); fp_sub_lz(v, t, C, m2);               // G - A - C + 4p                  in (0, 6p)
-    Fp D; fp_add_lz(D, v, v);                                     // D                               < 12p
-    Fp X3; fp_sub_lz(t, F, D, m16); fp_sub_lz(X3, t, D, m8);      // F - 2D + 24p                    in (0, 26p)
-    fp_sub_lz(t, D, X3, m32);                                     // D - X3 + 32p                    in (6p, 44p)
-    Fp Y3; fp_mul_lz(Y3, E, t);
-    fp_mul8_lz(v, C);                                             // 8C                              < 9p
-    fp_sub_lz(p.y, Y3, v, m16);                                   //                                 in (0, 18p)
-    p.x = X3; p.z = Z3;
-}
+// (the DPP-quad doubling and addition the chain is walked with: g1_quad.h)
 constexpr int PS_SHIFT_THREADS = 256;
 __global__ void __launch_bounds__(PS_SHIFT_THREADS) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n, int groups, G1Jac *shifts) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
@@ -555,44 +510,33 @@ __device__ __forceinline__ int ps_point_of_item(int j, int n) {
     const int t = j >> 1;
     return t < n ? n + t : t < 2 * n ? n + (t - n) : t < 3 * n ? t - 2 * n : 2 * n;
 }
-// One 256-thread workgroup per (batch, class, quarter of the buckets): 4 buckets x 64 lanes, one wave per SIMD of its CU.  (One
-// 512-thread workgroup per (batch, class) kept all 16 buckets on ONE CU: 8 waves sharing 4 SIMDs through ~26 dependent additions,
-// 0.88 ms for a lone batch; spread over four CUs the same sums take ~13 additions at one wave per SIMD.)  Writes the 16 bucket sums.
+// One 256-thread workgroup per (batch, class, bucket): 64 DPP quads, each an accumulator of its own (g1_add_quad: an addition five
+// products deep instead of sixteen).  A quad takes entries q, q + 64, ... of the bucket's list (~6.5 at n = 64), the 16 quads of a wave
+// are summed by a shuffle butterfly (4 levels), the four waves through LDS (2 levels): ~13 quad additions in a row where the
+// lane-per-accumulator form had ~6.5 + 6 lane additions three times as deep.  Writes the bucket sum (canonical).
+constexpr int PS_QUADS = PS_THREADS / 4;
 __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const G1Affine *pts, const int8_t *digits, int n, LcSlot *S) {
-    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15, grouped by bucket (this workgroup's buckets only)
-    __shared__ int cnt[PS_BUCKETS_PER_WG + 1], start[PS_BUCKETS_PER_WG + 1], cursor[PS_BUCKETS_PER_WG + 1];
-    const int part = blockIdx.x % PS_PARTS, gc = blockIdx.x / PS_PARTS, g = gc >> 1, cls = gc & 1, tid = threadIdx.x;
-    const int b_lo = part * PS_BUCKETS_PER_WG;                   // this workgroup sums the buckets |digit| = b_lo + 1 .. b_lo + 4
+    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15 of this bucket; sized for every pair of the class landing here (27 KB)
+    __shared__ int cnt;
+    __shared__ G1Jac wsum[4];
+    const int bk = blockIdx.x % LC_BUCKETS, gc = blockIdx.x / LC_BUCKETS, g = gc >> 1, cls = gc & 1, tid = threadIdx.x;
+    const int role = tid & 3, quad = tid >> 2, lane = tid & 63, wid = tid >> 6;
     const int ni = lc_items(n), lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;      // the class's items (terms t < n are class 0)
     const int8_t *dg = digits + (size_t)g * ni * LC_DIG_STRIDE;
     const G1Jac *sh = shifts + (size_t)g * ps_points(n) * LC_WINDOWS;
     const int npairs = (hi - lo) * LC_WINDOWS;
-    if (tid <= PS_BUCKETS_PER_WG) cnt[tid] = 0;
+    if (tid == 0) cnt = 0;
     __syncthreads();
     for (int q = tid; q < npairs; q += PS_THREADS) {
         const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
-        const int d = dg[(size_t)j * LC_DIG_STRIDE + w], k = (d < 0 ? -d : d) - b_lo;
-        if (k >= 1 && k <= PS_BUCKETS_PER_WG) atomicAdd(&cnt[k], 1);
+        const int d = dg[(size_t)j * LC_DIG_STRIDE + w];
+        if ((d < 0 ? -d : d) == bk + 1) { const int pos = atomicAdd(&cnt, 1); list[pos] = (uint16_t)((j - lo) | (w << 10) | (d < 0 ? 0x8000 : 0)); }
     }
     __syncthreads();
-    if (tid == 0) { int run = 0; for (int k = 1; k <= PS_BUCKETS_PER_WG; k++) { start[k] = run; cursor[k] = run; run += cnt[k]; } }
-    __syncthreads();
-    for (int q = tid; q < npairs; q += PS_THREADS) {
-        const int j = lo + q / LC_WINDOWS, w = q % LC_WINDOWS;
-        const int d = dg[(size_t)j * LC_DIG_STRIDE + w], k = (d < 0 ? -d : d) - b_lo;
-        if (k >= 1 && k <= PS_BUCKETS_PER_WG) { const int pos = atomicAdd(&cursor[k], 1); list[pos] = (uint16_t)((j - lo) | (w << 10) | (d < 0 ? 0x8000 : 0)); }
-    }
-    __syncthreads();
-    // 64 lanes (one wave) per bucket: lane s takes entries s, s + 64, ... of the bucket's list
-    const int k = tid / PS_LANES_PER_BUCKET + 1, sl = tid % PS_LANES_PER_BUCKET;
+    const int c = cnt;
     const uint32_t bc[NFP] = FP_BETA_INIT;
     Fp beta; for (int i = 0; i < NFP; i++) beta.l[i] = bc[i];
-    G1Jac acc = g1_inf();
-    const int s0 = start[k], c = cnt[k];
-#pragma unroll 1
-    for (int q = sl; q < c; q += PS_LANES_PER_BUCKET) {
-        const uint32_t v = list[s0 + q];
-        const int j = lo + (int)(v & 0x3ff), w = (int)((v >> 10) & 31);
+    auto fetch = [&](int j, int w, bool neg) -> G1Jac {
         const int pt = ps_point_of_item(j, n);
         G1Jac p = sh[(size_t)pt * LC_WINDOWS + w];
         {   // the shift table holds points of E'' (k_ps_shift): Z picks up the y of the input point (zero for the point at infinity)
@@ -601,32 +545,52 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
             else { const uint32_t gy[NFP] = G1_GEN_Y_INIT; for (int q = 0; q < NFP; q++) y0.l[q] = gy[q]; fp_neg(y0, y0); }
             Fp zz; fp_mul(zz, p.z, y0); p.z = zz;
         }
-        bool neg = (v & 0x8000) != 0;
         if (j & 1) { Fp bx; fp_mul(bx, p.x, beta); p.x = bx; neg = !neg; }       // the odd item of a term is -phi(P) = (beta x, -y)
         if (neg) fp_neg(p.y, p.y);
-        g1_add_lazy(acc, acc, p);
-    }
-    g1_canon_lazy(acc, acc);
+        return p;
+    };
+    // ONE loop with ONE inlined instance of the addition (hipcc 7.2 has miscompiled kernels with several inlined instances of the G1
+    // routines in a row): the operand of a step is, in turn, the quad's next list entry (steps 0 .. rounds - 1;
+    // infinity once its share is used up), the partner quad's sum in the wave (4 butterfly steps), and -- behind a workgroup barrier --
+    // the wave sums: quads 0, 1 of every wave add (w0 + w1), (w2 + w3), then their sum.
+    const int rounds = (c + PS_QUADS - 1) / PS_QUADS;             // the same for every thread of the workgroup
+    G1Jac acc = g1_inf();
 #pragma unroll 1
-    for (int off = 1; off < PS_LANES_PER_BUCKET; off <<= 1) { G1Jac o = g1_shfl_xor(acc, off); g1_add(acc, acc, o); }
-    if (sl == 0) S[(size_t)gc * LC_BUCKETS + b_lo + k - 1].jac = acc;
+    for (int step = 0; step < rounds + 6; step++) {
+        G1Jac o = g1_inf();
+        if (step < rounds) {
+            const int q = quad + step * PS_QUADS;
+            if (q < c) { const uint32_t v = list[q]; o = fetch(lo + (int)(v & 0x3ff), (int)((v >> 10) & 31), (v & 0x8000) != 0); }
+        } else if (step < rounds + 4) {
+            o = g1_shfl_xor(acc, 4 << (step - rounds));
+        } else if (step == rounds + 4) {
+            if (lane == 0) wsum[wid] = acc;
+            __syncthreads();                                      // (uniform: every thread reaches this step)
+            acc = wsum[2 * (quad & 1)]; o = wsum[2 * (quad & 1) + 1];
+        } else {
+            o = g1_shfl_xor(acc, 4);
+        }
+        g1_add_quad(acc, acc, o, role);
+    }
+    if (tid == 0) { g1_canon_lazy(acc, acc); S[(size_t)gc * LC_BUCKETS + bk].jac = acc; }
 }
-// The weights of the bucket sums: lane (batch, class, b - 1); sum_b b * S_b = sum_k T_k with the suffix sums T_k = sum_{b >= k} S_b
-// (as in k_lc_horner), to affine.
+// The weights of the bucket sums, one wave per (batch, class): quad b of the wave holds S_{b+1};  sum_b b * S_b = sum_k T_k with the suffix
+// sums T_k = sum_{b >= k} S_b (as in k_lc_horner): 4-step suffix scan + 4-step butterfly of quad additions, to the pairing's form.
 __global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, PairPt *pair_pts) {
-    const int id = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
-    const bool live = id < 2 * LC_BUCKETS * groups;
-    const int gc = live ? id / LC_BUCKETS : 0;
-    G1Jac r = live ? S[id].jac : g1_inf();
+    const int gc = blockIdx.x, lane = threadIdx.x, role = lane & 3, bi = lane >> 2;
+    G1Jac r = S[(size_t)gc * LC_BUCKETS + bi].jac;
+    // one loop, one inlined addition (see k_ps_buckets): steps 0..3 the suffix scan (a quad keeps the sum only while a partner exists),
+    // steps 4..7 the butterfly
 #pragma unroll 1
-    for (int off = 1; off < LC_BUCKETS; off <<= 1) {
-        G1Jac o = g1_shfl_down16(r, off), t;
-        g1_add(t, r, o);
-        if ((lane % LC_BUCKETS) + off < LC_BUCKETS) r = t;
+    for (int step = 0; step < 8; step++) {
+        const int off = 1 << (step & 3);
+        const G1Jac o = step < 4 ? g1_shfl_down_w(r, 4 * off) : g1_shfl_xor(r, 4 * off);
+        G1Jac t;
+        g1_add_quad(t, r, o, role);
+        if (step >= 4 || bi + off < LC_BUCKETS) r = t;
     }
-#pragma unroll 1
-    for (int off = 1; off < LC_BUCKETS; off <<= 1) { G1Jac o = g1_shfl_xor(r, off); g1_add(r, r, o); }
-    if (!live || id % LC_BUCKETS != 0) return;
+    if (lane != 0) return;
+    g1_canon_lazy(r, r);
     PairPt a; pairpt_from_jac(a, r, (gc & 1) == 0);               // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[gc] = a;
 }
@@ -728,8 +692,8 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
     hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * PS_PARTS), dim3(PS_THREADS), 0, st, d_shifts, d_pts, digits, n_per_group, S);
-    hipLaunchKernelGGL(k_ps_weights, dim3((2 * LC_BUCKETS * groups + 63) / 64), dim3(64), 0, st, S, groups, d_pair_pts);
+    hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * LC_BUCKETS), dim3(PS_THREADS), 0, st, d_shifts, d_pts, digits, n_per_group, S);
+    hipLaunchKernelGGL(k_ps_weights, dim3(2 * groups), dim3(64), 0, st, S, groups, d_pair_pts);
 }
 size_t lincomb_partials_bytes(int n_per_group, int groups) {
     const size_t waves = (size_t)lincomb_waves_per_group(n_per_group) * groups;
