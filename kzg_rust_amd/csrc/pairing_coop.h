@@ -340,7 +340,9 @@ KZG_HD void fp_norm_lz(Fp &r, const Fp &a) {
 
 // dst = a * b (sc = mul / line schedule; for the line schedule b has non-zero coefficients only at w^{0,2,3,6,8,9}) or, with
 // sc = the square schedule and b = a, dst = a^2.  bmask: coefficients of b known to be zero are skipped.  dst may alias a or b.
-KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask) {
+// bs (or null): the line operand as its six non-zero coefficients (l0, l6, l2, l8, l3, l9 -- the layout of the evaluations made ahead of
+// the loop, coop_eval_lines_item) instead of an Fp12W slot: coefficient j of b is bs[slot(j)].
+KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t bmask, const Fp *bs = nullptr) {
     COOP_LANES(lane) {
         const uint32_t pg = sc.prog[lane];
         const int np = (int)(pg & 3u);
@@ -349,7 +351,8 @@ KZG_HD void coop_product(CoopMem &m, const CoopSched &sc, Fp12W &dst, const Fp12
             wide_zero(acc);
             for (int k = 0; k < np; k++) {
                 const int i = (int)((pg >> (4 + 8 * k)) & 15u), j = (int)((pg >> (8 + 8 * k)) & 15u);
-                if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, b.c[j].l);
+                const uint32_t *bj = bs ? bs[(0x5301004200ull >> (4 * j)) & 7u].l : b.c[j].l;       // j = 0, 2, 3, 6, 8, 9 -> slot 0, 2, 4, 1, 3, 5
+                if ((bmask >> j) & 1u) wide_mac(acc, a.c[i].l, bj);
             }
             // no carry sweep in front of the reduction: with limbs < 2^29 + 2^7 three products leave every column below 42 * 2^58, a doubled
             // pair of cross products below 56 * 2^58, and the reduction adds at most 14 * 2^58 + 2^35: < 2^64 either way
@@ -564,6 +567,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
                      const Fp *pre = nullptr) {
     if (pc1 <= pc0) return;
     CoopInsn nxt = prog[pc0];
+    int cur_line = 0;                                             // with pre: the line the next line products take (set by OP_LINE_EVAL)
     for (int pc = pc0; pc < pc1; pc++) {
         const CoopInsn in = nxt;
         if (pc + 1 < pc1) nxt = prog[pc + 1];                    // fetched a whole operation ahead of its use
@@ -572,7 +576,8 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
             const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2);
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
-            if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask);
+            const Fp *bs = (pre && mask == LINE_MASK) ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6 : nullptr;      // straight from the evaluations made ahead
+            if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask, bs);
             continue;
         }
         switch (in.op) {
@@ -581,17 +586,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             case OP_CYC_SQR: coop_cyc_sqr(m, dst, a); break;
             case OP_LINE_EVAL: {
                 const int n = in.a;
-                if (pre) {                                  // evaluated ahead of the loop: fetch
-                    COOP_LANES(lane) {
-                        if (lane < 12) {
-                            const int q = lane / 6, e = lane % 6;
-                            const int dst_k = e == 0 ? 0 : e == 1 ? 6 : e == 2 ? 2 : e == 3 ? 8 : e == 4 ? 3 : 9;
-                            m.line[q].c[dst_k] = pre[(q * N_LINES + n) * 6 + e];
-                        }
-                    }
-                    COOP_SYNC();
-                    break;
-                }
+                if (pre) { cur_line = n; break; }          // evaluated ahead of the loop: the line products read them in place
                 COOP_LANES(lane) {                          // evaluate both lines at their points, scaled by Z^3: 12 products on 12 lanes,
                     if (lane < 12) {                        // ONE product body for all of them (operands picked per lane, no divergent arms)
                         const int q = lane / 6, e = lane % 6;
