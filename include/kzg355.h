@@ -89,7 +89,7 @@ typedef struct kzg355_options {
     int host_threads;          /* host worker threads of the handle (Fiat-Shamir hashing of small host-buffer calls, staging copies);
                                   0 = min(16, cpus the process may run on / 2)                                             KZG355_HOST_THREADS */
     int host_hash;             /* challenges of host-buffer verify / blob-proof calls hashed on the host: 0 by size, 1 always, -1 never  KZG355_HOST_HASH=auto|on|off */
-    int host_hash_max_blobs;   /* ... up to this many blobs per call (0 = 4096: measured crossover, profiles/r03/host_hash_crossover_v3.txt)          KZG355_HOST_HASH_MAX */
+    int host_hash_max_blobs;   /* ... up to this many blobs per call (0 = 4096: measured crossover, profiles/r03/host_hash_crossover_v4.txt)          KZG355_HOST_HASH_MAX */
     int host_sha;              /* host SHA-256 form: 0 SHA extensions when the CPU has them, 1 portable C, 2 SHA extensions      KZG355_HOST_SHA=portable|shani */
     int host_rhash;            /* batch challenge r of lone small calls hashed on the host (records copied back, ~60 us instead of a 0.33 ms
                                   device chain): 0 by size, -1 never                                                       KZG355_HOST_RHASH=off */

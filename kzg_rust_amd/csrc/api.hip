@@ -203,7 +203,7 @@ struct kzg355_settings {
     std::mutex mu;
     hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
-    int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v3.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
+    int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v4.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
     int host_rhash = 0;              // batch challenge r of lone small calls hashed on the host (records copied back): 0 by size, -1 never (KZG355_HOST_RHASH=off)
     int host_rhash_max_records = 256;    // records per call up to which that is done
     int sha_impl = 0;                // host SHA-256 form: 0 auto (SHA extensions when the CPU has them), 1 portable, 2 SHA extensions (KZG355_HOST_SHA=portable|shani)
@@ -660,7 +660,10 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
             HIPCHK(hipEventRecord(w->ev_fork, w->stream));       // after the memset of the error words
             HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
             w->side_pending = true;
-            tm.begin("validate_points", w->side); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->side); tm.end(w->side);
+            // (few blobs: the decoding and the subgroup test as two kernels -- neither spills, 0.45 + 1.0 ms for a lone point against 1.7 ms fused)
+            if ((rc = w->pts.ensure(sizeof(G1Affine) * 2 * n))) return rc;
+            tm.begin("decompress_points", w->side); launch_decompress_points(d_c, nullptr, (int)n, 1, w->pts.as<G1Affine>(), w->err.as<int>(), w->side); tm.end(w->side);
+            tm.begin("validate_points", w->side); launch_subgroup_points(w->pts.as<G1Affine>(), (int)n, 1, w->err.as<int>(), w->side, 1); tm.end(w->side);
             HIPCHK(hipEventRecord(w->ev_join, w->side));
         } else { tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end(); }
         if (hf) {                                                 // challenges hashed on the host (see run_stage1)

@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(64) k_decompress_points(const uint8_t *commitm
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
     const bool is_proof = j >= n_total;
+    if (is_proof && !proofs) return;                              // commitments only (compute_blob_kzg_proof's challenge step, kzg.rs:321)
     const int i = is_proof ? j - n_total : j;
     const uint8_t *src = (is_proof ? proofs : commitments) + (size_t)stride * i;
     uint8_t b[48];
@@ -49,9 +50,10 @@ __global__ void __launch_bounds__(64) k_decompress_points(const uint8_t *commitm
     if (g1_decompress(p, b) != 0) { atomicOr(&err[g], ERR_BAD_POINT); p = g1a_inf(); }
     pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
 }
-__global__ void __launch_bounds__(64) k_subgroup_points(const G1Affine *pts, int n_points, int n_per_group, int *err) {
+__global__ void __launch_bounds__(64) k_subgroup_points(const G1Affine *pts, int n_points, int n_per_group, int *err, int commitments_only) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_points) return;
+    if (commitments_only && (j % (2 * n_per_group)) >= n_per_group) return;       // the proof slots of the layout were never written
     const G1Affine p = pts[j];
     if (!g1a_is_inf(p) && !g1_in_subgroup(p)) atomicOr(&err[j / (2 * n_per_group)], ERR_BAD_POINT);      // infinity is accepted (utils.rs:298-301)
 }
@@ -625,9 +627,9 @@ void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_pro
     if (n_total <= 0) return;
     hipLaunchKernelGGL(k_decompress_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
 }
-void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st) {
+void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_subgroup_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_pts, 2 * n_total, n_per_group, d_err);
+    hipLaunchKernelGGL(k_subgroup_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_pts, 2 * n_total, n_per_group, d_err, commitments_only);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
     if (n_total <= 0) return;
