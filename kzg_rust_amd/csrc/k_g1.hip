@@ -58,6 +58,42 @@ __global__ void __launch_bounds__(64) k_subgroup_points(const G1Affine *pts, int
     if (!g1a_is_inf(p) && !g1_in_subgroup(p)) atomicOr(&err[j / (2 * n_per_group)], ERR_BAD_POINT);      // infinity is accepted (utils.rs:298-301)
 }
 
+// The subgroup test by DPP quads (g1_quad.h), for few points: the two [|x|] ladders are 126 doublings + 10 additions in a row, 2 + 1 and
+// 5 products deep here instead of 7 and 16 (1.0 -> 0.67 ms for a lone point: it is the critical path of compute_blob_kzg_proof once the
+// challenge is hashed on the host).  Same predicate as g1_in_subgroup (g1.h): phi(P) == -[x^2]P.
+__global__ void __launch_bounds__(256) k_subgroup_points_quad(const G1Affine *pts, int n_points, int n_per_group, int *err, int commitments_only) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, role = tid & 3;
+    const bool live = (tid >> 2) < n_points;
+    const int j = live ? (tid >> 2) : n_points - 1;               // idle quads redo the last point (every lane takes part in the DPP moves)
+    const bool skip = !live || (commitments_only && (j % (2 * n_per_group)) >= n_per_group);      // (the proof slots of the layout were never written)
+    G1Affine p = pts[skip ? 0 : j];
+    if (skip) p = g1a_inf();
+    G1Jac base; g1_from_affine(base, p);
+    G1Jac t = base;
+    // one loop, one inlined instance of each quad routine: two passes of the 63-step ladder for |x| = 0xd201000000010000
+#pragma unroll 1
+    for (int step = 0; step < 126; step++) {
+        const int i = 62 - (step % 63);
+        if (step == 63) { g1_canon_lazy(t, t); base = t; }       // second ladder: [|x|] of the first one's result
+        g1_dbl_quad(t, role);
+        if ((BLS_X_ABS >> i) & 1) g1_add_quad(t, t, base, role);  // (a constant exponent: the branch is uniform)
+    }
+    g1_canon_lazy(t, t);
+    bool ok = true;
+    if (!g1a_is_inf(p)) {
+        ok = !g1_is_inf(t);
+        const uint32_t bc[NFP] = FP_BETA_INIT;
+        Fp beta; for (int q = 0; q < NFP; q++) beta.l[q] = bc[q];
+        Fp z2, z3, lhs, rhs;
+        fp_sqr(z2, t.z); fp_mul(z3, z2, t.z);
+        fp_mul(lhs, p.x, beta); fp_mul(lhs, lhs, z2);             // beta x Z^2 == X
+        ok = ok && fp_eq(lhs, t.x);
+        fp_mul(lhs, p.y, z3); fp_neg(rhs, t.y);                   // y Z^3 == -Y
+        ok = ok && fp_eq(lhs, rhs);
+    }
+    if (!skip && role == 0 && !ok) atomicOr(&err[j / (2 * n_per_group)], ERR_BAD_POINT);      // infinity is accepted (utils.rs:298-301)
+}
+
 // Decompress the C_i / proof_i fields of gathered records (already validated by their owner rank).
 __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *records, int n_total, int n_per_group, G1Affine *pts, int *err) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,6 +665,10 @@ void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_pro
 }
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only) {
     if (n_total <= 0) return;
+    if (2 * n_total <= 1024) {          // few points: four lanes per point (latency form)
+        hipLaunchKernelGGL(k_subgroup_points_quad, dim3((8 * n_total + 255) / 256), dim3(256), 0, st, d_pts, 2 * n_total, n_per_group, d_err, commitments_only);
+        return;
+    }
     hipLaunchKernelGGL(k_subgroup_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_pts, 2 * n_total, n_per_group, d_err, commitments_only);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
