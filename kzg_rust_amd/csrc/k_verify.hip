@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
     const Fr z = z_in[blob_i];
     const Fr imag = roots[2];                                     // position 2 holds w^(N/4)
     Fr z4; fr_sqr(z4, z); fr_sqr(z4, z4);
-    Fr P, S;
+    Fr P, S, H;
     bool bad = false;
     constexpr int STEPS = N_FE / 4 / 64;
     EvalGroupTab gn = tab[lane];
@@ -285,9 +285,10 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
 #pragma unroll 1
             for (int e = 0; e < 4; e++) bad = bad || !fr_words_canonical(pw[e]);
         }
-        eval_fold_group4(P, S, it == 0, pw, z, z4, g, imag);
+        eval_fold_group4(P, S, H, it == 0, pw, z, z4, g, imag);
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
+    eval_fold_finish(S, P, H, z4);                                // the lane's S = sum_k N_k prod_{l != k} D_l from its triple (rho = z^4 - D never multiplied in)
     Fr ex, tot;
     wave_product_except_self<true>(ex, tot, P, lane);
     fr_mul(S, S, ex);                                             // canonical again: the chain of lazy products ends here

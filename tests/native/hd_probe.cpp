@@ -46,8 +46,8 @@ int hd_fr_mul2(uint8_t *out, const uint8_t *a, const uint8_t *b, const uint8_t *
     fr_mul(r, l, fr_one());                     // ... and the canonical product that ends the chain
     fr_to_be32(out, r); return 0;
 }
-// y = p(z) through eval_core.h's group-of-four fold, all 1024 groups on one "lane" (the device spreads them over 64 lanes and
-// combines the pairs with a product scan; the fold itself is this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
+// y = p(z) through eval_core.h's group-of-four fold, the 1024 groups dealt to 64 "lanes" of 16 as on the device (which combines the
+// lanes' pairs with a product scan; the fold and its finish are this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
 int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
     constexpr int N_FE = 4096;
     static Fr roots[N_FE]; static EvalGroupTab tab[N_FE / 4]; static bool ready = false;
@@ -63,12 +63,29 @@ int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
         ready = true;
     }
     uint32_t w[8]; be32_to_words(w, z_be);
-    Fr z, z4, P, S; fr_from_words(z, w);
+    Fr z, z4; fr_from_words(z, w);
     fr_sqr(z4, z); fr_sqr(z4, z4);
-    for (int k = 0; k < N_FE / 4; k++) {
-        uint32_t pw[4][8];
-        for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * k + e)); if (!fr_words_canonical(pw[e])) return 1; }
-        eval_fold_group4(P, S, k == 0, pw, z, z4, tab[k], roots[2]);
+    // 64 "lanes" of 16 groups each, group k = it * 64 + lane as on the device; then sum_l S_l prod_{m != l} P_m serially
+    Fr Pl[64], Sl[64];
+    for (int lane = 0; lane < 64; lane++) {
+        Fr P, S, H;
+        for (int it = 0; it < 16; it++) {
+            const int k = it * 64 + lane;
+            uint32_t pw[4][8];
+            for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * k + e)); if (!fr_words_canonical(pw[e])) return 1; }
+            eval_fold_group4(P, S, H, it == 0, pw, z, z4, tab[k], roots[2]);
+        }
+        eval_fold_finish(S, P, H, z4);
+        Fr one = fr_one();
+        fr_mul(Pl[lane], P, one);                            // canonical copies for the serial combination below (Montgomery domain kept: P * R / R)
+        Sl[lane] = S;
+    }
+    Fr S = fr_zero();
+    for (int l = 0; l < 64; l++) {
+        Fr ex = fr_one();
+        for (int m = 0; m < 64; m++) if (m != l) fr_mul(ex, ex, Pl[m]);
+        Fr term; fr_mul(term, Sl[l], ex);                    // plain * Montgomery -> plain, canonical
+        fr_add(S, S, term);
     }
     const uint32_t inv4096[NFR] = FR_INV4096_INIT;
     Fr k4096, y; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
