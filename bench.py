@@ -43,6 +43,8 @@ NOMINAL_WAVE_INSTS_PER_S = N_SIMD * NOMINAL_CLOCK_HZ / 2
 PATH_BYTES_PER_BLOB = 131072 + 131072 + 48 + 48
 KERNEL_BYTES_PER_BLOB = {
     "challenge": 16 + 16 + 131072 + 48 + 32,          # the 131,152-byte transcript in, z out
+    "challenge_from_digest": 32 + 48 + 48 + 160,      # small host-buffer calls: the digest hashed on the host in, the record's C / z / proof fields out
+    "decompress_points": 96,
     "eval": 131072 + 1024 * 72 + 32 + 32,             # blob + the 1024-entry group table (w^-1, w^4) + z in, y out
     "validate_points": 96,
     "points_from_records": 96,
@@ -296,6 +298,11 @@ def main():
                     "avg_launch_ms": round(tot_ms / cnt, 4), "launches": cnt,
                     "kernel_timing": "HIP events on the launch stream around every kernel, recorded during the timed region",
                     "kernel_ms_share": {f: round(v[0], 3) for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0])},
+                    # every kernel family against the same HBM peak (algorithmic bytes per launch / its average launch duration): the dominant kernel above is
+                    # the one with the most TIME, which need not be the one closest to the memory roofline
+                    "per_kernel": {f: {"avg_launch_ms": round(v[0] / v[1], 4), "achieved_gbps": round(KERNEL_BYTES_PER_BLOB[f] * blobs_per_launch_of(f) / (v[0] / v[1] / 1e3) / 1e9, 1),
+                                       "frac": round(KERNEL_BYTES_PER_BLOB[f] * blobs_per_launch_of(f) / (v[0] / v[1] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                                   for f, v in sorted(stats.items(), key=lambda kv: -kv[1][0]) if f in KERNEL_BYTES_PER_BLOB},
                     "path_bytes_per_blob": OP_BYTES_PER_BLOB[args.op],
                     "path_frac_of_hbm_peak": value * OP_BYTES_PER_BLOB[args.op] / (world * HBM_PEAK_GBPS * 1e9),
                     "measured_stream_copy_gbps": stream_copy_peak(torch, dev) if rank == 0 else None,

@@ -18,6 +18,9 @@ cd $ROOT
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_$V.json > /dev/null
 python tools/sq_summary.py $OUT/pmc_sq $OUT/sq_$V.json > /dev/null
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_default_$V.csv \;
+python tools/trace_summary.py $OUT/trace $OUT/kernel_trace_largest_launch_$V.csv      # per kernel: its full-size launches only (what the live HIP-event average is)
+# the fresh summaries go into the tree of THIS box as well, so that the un-profiled bench lines below cite and use them (copy the same files into profiles/ at home)
+mkdir -p $ROOT/profiles/$R && cp $OUT/pmc_traffic_$V.json $OUT/sq_$V.json $ROOT/profiles/$R/
 # commit / proof: their own counter passes (the MSM kernels of the verify bench's untimed setup run at another launch size and table width)
 for op in commit proof; do
   echo "== $op counters"
@@ -29,6 +32,7 @@ for op in commit proof; do
   cd $ROOT
   python tools/pmc_summary.py $OUT/pmc_fetch_$op $OUT/pmc_write_$op $OUT/pmc_traffic_${op}_$V.json > /dev/null
   python tools/sq_summary.py $OUT/pmc_sq_$op $OUT/sq_${op}_$V.json > /dev/null
+  cp $OUT/pmc_traffic_${op}_$V.json $OUT/sq_${op}_$V.json $ROOT/profiles/$R/
   rm -rf $OUT/pmc_fetch_$op $OUT/pmc_write_$op $OUT/pmc_sq_$op
 done
 for op in commit proof; do
