@@ -45,7 +45,7 @@ KERNEL_BYTES_PER_BLOB = {
     "challenge": 16 + 16 + 131072 + 48 + 32,          # the 131,152-byte transcript in, z out
     "challenge_from_digest": 32 + 48 + 48 + 160,      # small host-buffer calls: the digest hashed on the host in, the record's C / z / proof fields out
     "decompress_points": 96,
-    "eval": 131072 + 1024 * 72 + 32 + 32,             # blob + the 1024-entry group table (w^-1, w^4) + z in, y out
+    "eval": 131072 + 1364 * 36 + 32 + 32,             # blob + the 1364 inverse node roots of the radix-4 tree (eval_core.h) + z in, y out
     "validate_points": 96,
     "points_from_records": 96,
     "rpowers": 160 + 64,

@@ -72,15 +72,16 @@ __global__ void __launch_bounds__(256) k_setup_roots(Fr *roots) {
     roots[brp12((uint32_t)i)] = acc;
 }
 
-// Per group of four domain points (positions 4k..4k+3 = w, -w, iw, -iw): w^-1 and w^4 for k_eval (eval_core.h).
-__global__ void __launch_bounds__(256) k_setup_eval_tab(const Fr *roots, EvalGroupTab *tab) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N_FE / 4) return;
-    const Fr w = roots[4 * k];
-    EvalGroupTab g;
-    fr_inv(g.inv_root, w);
-    fr_sqr(g.rho, w); fr_sqr(g.rho, g.rho);
-    tab[k] = g;
+// k_eval's radix-4 tree (eval_core.h): level l = 1..5, node j -> w_(4^l j) ^ -(4^(l-1)), one flat table of EVAL_TAB_ENTRIES.
+__global__ void __launch_bounds__(256) k_setup_eval_tab(const Fr *roots, Fr *tab) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= EVAL_TAB_ENTRIES) return;
+    const int level = e < EVAL_TAB_L2 ? 1 : e < EVAL_TAB_L3 ? 2 : e < EVAL_TAB_L4 ? 3 : e < EVAL_TAB_L5 ? 4 : 5;
+    const int first = level == 1 ? EVAL_TAB_L1 : level == 2 ? EVAL_TAB_L2 : level == 3 ? EVAL_TAB_L3 : level == 4 ? EVAL_TAB_L4 : EVAL_TAB_L5;
+    const int j = e - first;
+    Fr v; fr_inv(v, roots[j << (2 * level)]);
+    for (int s = 0; s < 2 * (level - 1); s++) fr_sqr(v, v);
+    tab[e] = v;
 }
 
 // Fixed-base precomputation: table[w][i] = 2^(8w) * g1_values[i] in affine form, w = 1..31 (window 0 is g1_values).
@@ -107,7 +108,7 @@ int launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTab
     hipLaunchKernelGGL(k_setup_lagrange_check, dim3(1), dim3(64), 0, st, t.g1_first2, t.lines, t.lines_inf, d_err);
     if (mainnet) {
         hipLaunchKernelGGL(k_setup_roots, dim3(N_FE / 256), dim3(256), 0, st, t.roots);
-        hipLaunchKernelGGL(k_setup_eval_tab, dim3(N_FE / 4 / 256), dim3(256), 0, st, t.roots, t.eval_tab);
+        hipLaunchKernelGGL(k_setup_eval_tab, dim3((EVAL_TAB_ENTRIES + 255) / 256), dim3(256), 0, st, t.roots, t.eval_tab);
         hipLaunchKernelGGL(k_setup_msm_table, dim3(N_FE / 64), dim3(64), 0, st, t.msm_table);
     }
     const hipError_t e = hipStreamSynchronize(st);

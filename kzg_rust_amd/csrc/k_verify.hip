@@ -222,21 +222,23 @@ __global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *dig
 // The reference evaluates  y = (z^N - 1)/N * sum_i p_i w_i / (z - w_i)  with a 4096-long batch inversion and special-
 // cases z == w_i.  Because  prod_j (z - w_j) = z^N - 1,  the same value is
 //         y = (1/N) * sum_i  p_i w_i * prod_{j != i} (z - w_j)
-// which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m).
-// One wave per blob, no LDS and no barrier.  The arithmetic is eval_core.h: the domain is taken four points at a time
-// (w, -w, iw, -iw are the roots of x^4 = w^4), a lane folds its 16 groups into the pair
-//     P = prod_k D_k ,  S = sum_k N_k prod_{l != k} D_l        (D_k = z^4 - w_k^4, N_k the group's numerator)
-// at 8.5 product-equivalents per group, and the wave combines the 64 pairs as  sum_l S_l prod_{m != l} P_m  with one
-// "product of all the others" scan.  Group k = it*64 + lane: a lane reads 128 contiguous bytes, a wave 8 KiB.
-// z inside the domain needs no special case (for z = w_m every term but the m-th vanishes and the m-th equals N p_m,
-// which is what kzg.rs:360-362 returns).  y comes out as the canonical integer with no conversion.
+// which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m,
+// which is what kzg.rs:360-362 returns).  The arithmetic is eval_core.h: a radix-4 tree over the domain, five lazy products per
+// node of four children, the same node function at every level with z^(4^(l-1)) for z.
+// One wave per blob.  Step it = 0..15 takes the 64 groups 64 it .. 64 it + 63 (8 KiB of the blob), one level-1 node per lane.
+// The four children of a level-2 node are four NEIGHBOURING lanes of one step, so a lane parks its h in LDS and after every
+// fourth step the 256 parked values are dealt out again, four consecutive ones per lane: 64 level-2 nodes, one per lane.  The same
+// exchange after the loop gives every lane one level-3 node (its four level-2 results go through the same buffer), and levels
+// 4-6 (16, 4, 1 nodes) run replicated across the lanes.  y comes out as the canonical integer with no conversion.
 // Loads: a lane needs the 128 contiguous bytes of its group, but a load instruction whose lanes are 128 bytes apart touches 64
 // cache lines for 1 KiB.  The wave instead moves its 8 KiB per step with 8 fully coalesced global -> LDS loads
-// (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~2,800 instructions
+// (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~2,000 instructions
 // without costing registers -- staging it in VGPRs spilled to scratch, and waiting for a scratch reload waits for every older
 // load too: 59 % of the wave cycles were s_waitcnt).  The LDS side of such a load is linear (lane L of instruction q lands in
 // slot 64 q + L), so the bank-spreading XOR is applied on the global side: slot 8 g + s receives chunk 8 g + (s ^ (g & 7)) of
 // the tile (still the same 1 KiB per instruction), and lane g reads its part j back from slot 8 g + (j ^ (g & 7)).
+// The exchange buffer holds 256 values of 9 limbs, entry e at words 9 e .. 9 e + 8: a lane's writes are 9 words apart (odd:
+// conflict-free), its four children are 36 consecutive words read as nine b128 (lanes 36 words apart: 16 lanes cover all banks).
 constexpr uint32_t FR_MOD_TOP_WORD = 0x73eda753u;    // r = 0x73eda753 299d7d48 ...
 __device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, uint4 *tile, int lane) {
 #pragma unroll
@@ -246,19 +248,37 @@ __device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, ui
                                          (void __attribute__((address_space(3))) *)(tile + 64 * q), 16, 0, 0);
     }
 }
-__global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, const EvalGroupTab *tab, int n_per_group,
+__device__ __forceinline__ void eval_park(uint32_t *hx, int entry, const Fr &h) {
+#pragma unroll
+    for (int k = 0; k < NFR; k++) hx[NFR * entry + k] = h.l[k];
+}
+// the four consecutive entries 4 node .. 4 node + 3, after every lane's eval_park has landed
+__device__ __forceinline__ void eval_children(Fr c[4], const uint32_t *hx, int node) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint4 *src = reinterpret_cast<const uint4 *>(hx + 4 * NFR * node);
+    uint32_t w[4 * NFR];
+#pragma unroll
+    for (int q = 0; q < NFR; q++) { const uint4 v = src[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int k = 0; k < NFR; k++) c[e].l[k] = w[NFR * e + k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();       // all reads done before the buffer is written again
+}
+__global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, const Fr *tab, int n_per_group,
                                                  Fr *y_out, uint8_t *records, int *err) {
     __shared__ uint4 tile[512];
+    __shared__ __attribute__((aligned(16))) uint32_t hx[256 * NFR];
     const int blob_i = blockIdx.x, lane = threadIdx.x;
     const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob_i);
     eval_issue_tile_loads(blob, tile, lane);
     const Fr z = z_in[blob_i];
     const Fr imag = roots[2];                                     // position 2 holds w^(N/4)
-    Fr z4; fr_sqr(z4, z); fr_sqr(z4, z4);
-    Fr P, S, H;
+    Fr zp; fr_sqr(zp, z); fr_sqr(zp, zp);                         // z^4; later z^16, z^64, ...
+    Fr h2[4];
     bool bad = false;
     constexpr int STEPS = N_FE / 4 / 64;
-    EvalGroupTab gn = tab[lane];
+    Fr inv_next = tab[EVAL_TAB_L1 + lane];
 #pragma unroll 1
     for (int it = 0; it < STEPS; it++) {
         __builtin_amdgcn_s_waitcnt(0);                            // this step's tile (and table entry) have landed
@@ -266,11 +286,11 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
         uint4 cur[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) cur[j] = tile[8 * lane + (j ^ (lane & 7))];
-        const EvalGroupTab g = gn;
+        const Fr inv1 = inv_next;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();   // every lane has its 128 bytes
         if (it + 1 < STEPS) {                                     // next step's loads fly during this one's products
             eval_issue_tile_loads(blob + 512 * (it + 1), tile, lane);
-            gn = tab[(it + 1) * 64 + lane];
+            inv_next = tab[EVAL_TAB_L1 + (it + 1) * 64 + lane];
         }
         uint32_t pw[4][8];
 #pragma unroll
@@ -285,19 +305,44 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
 #pragma unroll 1
             for (int e = 0; e < 4; e++) bad = bad || !fr_words_canonical(pw[e]);
         }
-        eval_fold_group4(P, S, H, it == 0, pw, z, z4, g, imag);
+        Fr T, h;
+        fr_mul_lazy(T, z, inv1);                                  // z / w_(4g)
+        eval_level1(h, pw, T, imag);
+        eval_park(hx, 64 * (it & 3) + lane, h);                   // group 64 it + lane = entry 64 (it & 3) + lane of this batch of four steps
+        if ((it & 3) == 3) {                                      // level 2: node 64 (it >> 2) + lane = entries 4 lane .. 4 lane + 3
+            Fr c[4];
+            eval_children(c, hx, lane);
+            fr_mul_lazy(T, zp, tab[EVAL_TAB_L2 + 64 * (it >> 2) + lane]);
+            Fr r2; eval_level2(r2, c, T, imag);
+#pragma unroll
+            for (int a = 0; a < 4; a++) if ((it >> 2) == a) h2[a] = r2;
+        }
     }
     if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
-    eval_fold_finish(S, P, H, z4);                                // the lane's S = sum_k N_k prod_{l != k} D_l from its triple (rho = z^4 - D never multiplied in)
-    Fr ex, tot;
-    wave_product_except_self<true>(ex, tot, P, lane);
-    fr_mul(S, S, ex);                                             // canonical again: the chain of lazy products ends here
+    Fr c[4], T, h;
+    // level 3: node n = lane, children the level-2 nodes 4 lane .. 4 lane + 3 (node 64 a + l sits in lane l's h2[a])
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { Fr o = fr_shfl_down(S, off); fr_add(S, S, o); }
+    for (int a = 0; a < 4; a++) eval_park(hx, 64 * a + lane, h2[a]);
+    eval_children(c, hx, lane);
+    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^16
+    fr_mul_lazy(T, zp, tab[EVAL_TAB_L3 + lane]);
+    eval_level3(h, c, T, imag);
+    // levels 4, 5, 6: 16, 4 and 1 nodes, every lane computes the node (lane mod 16), (lane mod 4), the root
+    eval_park(hx, lane, h);
+    eval_children(c, hx, lane & 15);
+    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^64
+    fr_mul_lazy(T, zp, tab[EVAL_TAB_L4 + (lane & 15)]);
+    eval_level4(h, c, T, imag);
+    if (lane < 16) eval_park(hx, lane, h);
+    eval_children(c, hx, lane & 3);
+    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^256
+    fr_mul_lazy(T, zp, tab[EVAL_TAB_L5 + (lane & 3)]);
+    eval_level5(h, c, T, imag);
+    if (lane < 4) eval_park(hx, lane, h);
+    eval_children(c, hx, 0);
+    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^1024
+    Fr y; eval_level6(y, c, zp, imag);                            // canonical integer value of y
     if (lane == 0) {
-        const uint32_t inv4096[NFR] = FR_INV4096_INIT;
-        Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-        Fr y; fr_mul(y, S, k4096);                                // canonical integer value of y
         if (records) {
             uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
             uint8_t *rec = records + (size_t)RECORD_BYTES * blob_i + 80;

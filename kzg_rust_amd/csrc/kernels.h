@@ -37,7 +37,7 @@ struct alignas(128) WideRow { Fp x, y; uint32_t pad[4]; };       // one affine p
 struct DeviceTables {
     int n_fe;                // FIELD_ELEMENTS_PER_BLOB of this handle: 4096 (mainnet) or a small power of two (minimal preset: 4)
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
-    EvalGroupTab *eval_tab;  // [1024] per group of four domain points: w^-1, w^4 (eval_core.h)
+    Fr *eval_tab;            // [EVAL_TAB_ENTRIES] inverse node roots of k_eval's radix-4 tree, levels 1..5 (eval_core.h)
     WideShape wide;          // shape of wide_table
     WideRow *wide_table;        // [22][4096][2048] multiples m * 2^(12w) * g1_values[i], 23.6 GB; null: 8-bit bucket form only
     G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)

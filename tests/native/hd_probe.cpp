@@ -46,11 +46,11 @@ int hd_fr_mul2(uint8_t *out, const uint8_t *a, const uint8_t *b, const uint8_t *
     fr_mul(r, l, fr_one());                     // ... and the canonical product that ends the chain
     fr_to_be32(out, r); return 0;
 }
-// y = p(z) through eval_core.h's group-of-four fold, the 1024 groups dealt to 64 "lanes" of 16 as on the device (which combines the
-// lanes' pairs with a product scan; the fold and its finish are this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
+// y = p(z) through eval_core.h's radix-4 tree, level by level over arrays (the device deals the same nodes to the lanes of a wave and
+// moves the children through LDS; the node arithmetic and its lazy bounds are this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
 int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
     constexpr int N_FE = 4096;
-    static Fr roots[N_FE]; static EvalGroupTab tab[N_FE / 4]; static bool ready = false;
+    static Fr roots[N_FE]; static Fr tab[EVAL_TAB_ENTRIES]; static bool ready = false;
     if (!ready) {
         const uint32_t rootc[NFR] = FR_ROOT4096_INIT;
         Fr base; for (int k = 0; k < NFR; k++) base.l[k] = rootc[k];
@@ -59,37 +59,33 @@ int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
             uint32_t rev = 0; for (int b = 0; b < 12; b++) rev |= ((i >> b) & 1u) << (11 - b);
             roots[rev] = acc; fr_mul(acc, acc, base);
         }
-        for (int k = 0; k < N_FE / 4; k++) { fr_inv(tab[k].inv_root, roots[4 * k]); fr_sqr(tab[k].rho, roots[4 * k]); fr_sqr(tab[k].rho, tab[k].rho); }
+        const int first[6] = {0, EVAL_TAB_L1, EVAL_TAB_L2, EVAL_TAB_L3, EVAL_TAB_L4, EVAL_TAB_L5};
+        for (int level = 1; level <= 5; level++)
+            for (int j = 0; j < (N_FE >> (2 * level)); j++) {
+                Fr v; fr_inv(v, roots[j << (2 * level)]);
+                for (int q = 0; q < 2 * (level - 1); q++) fr_sqr(v, v);
+                tab[first[level] + j] = v;
+            }
         ready = true;
     }
     uint32_t w[8]; be32_to_words(w, z_be);
-    Fr z, z4; fr_from_words(z, w);
-    fr_sqr(z4, z); fr_sqr(z4, z4);
-    // 64 "lanes" of 16 groups each, group k = it * 64 + lane as on the device; then sum_l S_l prod_{m != l} P_m serially
-    Fr Pl[64], Sl[64];
-    for (int lane = 0; lane < 64; lane++) {
-        Fr P, S, H;
-        for (int it = 0; it < 16; it++) {
-            const int k = it * 64 + lane;
-            uint32_t pw[4][8];
-            for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * k + e)); if (!fr_words_canonical(pw[e])) return 1; }
-            eval_fold_group4(P, S, H, it == 0, pw, z, z4, tab[k], roots[2]);
-        }
-        eval_fold_finish(S, P, H, z4);
-        Fr one = fr_one();
-        fr_mul(Pl[lane], P, one);                            // canonical copies for the serial combination below (Montgomery domain kept: P * R / R)
-        Sl[lane] = S;
+    Fr z, zp[6]; fr_from_words(z, w);
+    zp[0] = z;
+    for (int l = 1; l < 6; l++) { fr_sqr(zp[l], zp[l - 1]); fr_sqr(zp[l], zp[l]); }      // z^(4^l)
+    const Fr imag = roots[2];
+    static Fr h1[1024], h2[256], h3[64], h4[16], h5[4];
+    Fr T;
+    for (int g = 0; g < 1024; g++) {
+        uint32_t pw[4][8];
+        for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * g + e)); if (!fr_words_canonical(pw[e])) return 1; }
+        fr_mul_lazy(T, zp[0], tab[EVAL_TAB_L1 + g]);
+        eval_level1(h1[g], pw, T, imag);
     }
-    Fr S = fr_zero();
-    for (int l = 0; l < 64; l++) {
-        Fr ex = fr_one();
-        for (int m = 0; m < 64; m++) if (m != l) fr_mul(ex, ex, Pl[m]);
-        Fr term; fr_mul(term, Sl[l], ex);                    // plain * Montgomery -> plain, canonical
-        fr_add(S, S, term);
-    }
-    const uint32_t inv4096[NFR] = FR_INV4096_INIT;
-    Fr k4096, y; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-    fr_mul(y, S, k4096);                                     // S is plain, k4096 Montgomery: y plain and canonical
+    for (int m = 0; m < 256; m++) { fr_mul_lazy(T, zp[1], tab[EVAL_TAB_L2 + m]); eval_level2(h2[m], h1 + 4 * m, T, imag); }
+    for (int n = 0; n < 64; n++) { fr_mul_lazy(T, zp[2], tab[EVAL_TAB_L3 + n]); eval_level3(h3[n], h2 + 4 * n, T, imag); }
+    for (int u = 0; u < 16; u++) { fr_mul_lazy(T, zp[3], tab[EVAL_TAB_L4 + u]); eval_level4(h4[u], h3 + 4 * u, T, imag); }
+    for (int v = 0; v < 4; v++) { fr_mul_lazy(T, zp[4], tab[EVAL_TAB_L5 + v]); eval_level5(h5[v], h4 + 4 * v, T, imag); }
+    Fr y; eval_level6(y, h5, zp[5], imag);
     limbs_to_words<NFR, 8>(w, y.l);
     for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8; out32[4 * i + 3] = v; }
     return 0;

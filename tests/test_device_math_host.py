@@ -207,7 +207,10 @@ def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_b
             return len(b) == 131072 and bool(oracle.blob_to_kzg_commitment(b, oracle_settings))
         except Exception:
             return False
-    blobs = [random_blob(4242), next(b for b in golden_blobs if valid(b)), bytes(131072)]
+    top = (R_ - 1).to_bytes(32, "big")
+    # the lazy bounds of the tree (eval_core.h header) at their worst: every value r - 1, and r - 1 / 0 patterns that maximise the differences
+    extremes = [top * 4096, (top + bytes(32)) * 2048, (bytes(32) + top) * 2048, (top + top + bytes(64)) * 1024, (bytes(64) + top + top) * 1024]
+    blobs = [random_blob(4242), next(b for b in golden_blobs if valid(b)), bytes(131072)] + extremes
     out = C.create_string_buffer(32)
     for blob in blobs:
         for z in zs:
