@@ -74,7 +74,7 @@ struct Workspace {
     // work on the side streams that the main stream has not waited for yet: everything (ev_join: the validation verdicts are in the error
     // words), the decoded points alone (ev_pts; recorded only when they are ready before the verdicts), the window shifts (ev_shift)
     bool side_pending = false, pts_pending = false, shift_pending = false;
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests, zpow;
     bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
     PinBuf h_ok, h_err, h_out, h_digests, h_records, h_rdig;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
@@ -91,7 +91,7 @@ struct Workspace {
         in_flight = false; side_pending = false; pts_pending = false; shift_pending = false; shift_ready = false;
     }
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests}) b->release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift}) if (e) (void)hipEventDestroy(e);
@@ -399,6 +399,7 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     int rc;
     w->shift_ready = false;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
+    if (!is_small(s) && (rc = w->zpow.ensure(sizeof(Fr) * EVAL_ZPOWERS * (size_t)n_total))) return rc;
     if (is_small(s)) {   // minimal preset: one lane per blob does conversion, challenge and evaluation (k_small.hip)
         tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
         tm.begin("small_records"); launch_small_records(d_blobs, d_c, d_p, n_total, npg, s->t, w->z.as<Fr>(), d_records, d_err, w->stream); tm.end();
@@ -419,11 +420,11 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
         hf->finish();
         HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * (size_t)n_total, hipMemcpyHostToDevice, w->stream));
-        tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream); tm.end();
+        tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(), d_records, w->stream); tm.end();
     } else {
-        tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), d_records, w->stream, s->challenge_form ? s->challenge_form : n_total <= s->challenge_two_wave_upto ? 2 : 1); tm.end();
+        tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(), d_records, w->stream, s->challenge_form ? s->challenge_form : n_total <= s->challenge_two_wave_upto ? 2 : 1); tm.end();
     }
-    tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
+    tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), w->zpow.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
     return KZG355_OK;
 }
 int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_records, int npg, int groups, int check_zy, const G1Affine *d_pts,
@@ -670,8 +671,8 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
             HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
             hf->finish();
             HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * n, hipMemcpyHostToDevice, w->stream));
-            tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream); tm.end();
-        } else { tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, w->stream, s->challenge_form ? s->challenge_form : (int)n <= s->challenge_two_wave_upto ? 2 : 1); tm.end(); }
+            tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, nullptr, w->stream); tm.end();
+        } else { tm.begin("challenge"); launch_challenges(d_blobs, d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, nullptr, w->stream, s->challenge_form ? s->challenge_form : (int)n <= s->challenge_two_wave_upto ? 2 : 1); tm.end(); }
         if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
         if ((rc = join_side(w))) return rc;
     }

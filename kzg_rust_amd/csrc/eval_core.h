@@ -37,6 +37,8 @@ namespace kzg {
 
 // inverse "roots" of the tree's nodes, one flat table: level l (1..5) node j holds  w_(4^l j) ^ -(4^(l-1))  (Montgomery), w_idx the
 // domain in bit-reversal order; level 6 is the single node with rho' = 1.
+constexpr int EVAL_ZPOWERS = 5;        // z^4, z^16, z^64, z^256, z^1024: the z of levels 2..6, squared up once per blob by the challenge kernel
+constexpr int EVAL_WAVES = 4;          // blobs (waves) per workgroup of k_eval: the last three levels of the four trees run together on wave 0
 constexpr int EVAL_TAB_L1 = 0, EVAL_TAB_L2 = 1024, EVAL_TAB_L3 = 1280, EVAL_TAB_L4 = 1344, EVAL_TAB_L5 = 1360, EVAL_TAB_ENTRIES = 1364;
 
 // K r as normalised limbs (the top limb keeps the excess), at compile time

@@ -77,11 +77,16 @@ struct ChallengeReader {
     }
 };
 
-__device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, uint8_t *records) {
+__device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, Fr *zpow_out, uint8_t *records) {
     // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
     const uint32_t dw[8] = {hh[7], hh[6], hh[5], hh[4], hh[3], hh[2], hh[1], hh[0]};
     Fr z; fr_from_words(z, dw);
     z_out[i] = z;
+    if (zpow_out) {                                   // z^4, z^16, z^64, z^256, z^1024 for the levels of k_eval's tree: ten squarings on the lane that
+        Fr p = z;                                     // has z anyway, instead of ten on every wave of the evaluation
+#pragma unroll 1
+        for (int k = 0; k < EVAL_ZPOWERS; k++) { fr_sqr(p, p); fr_sqr(p, p); zpow_out[EVAL_ZPOWERS * (size_t)i + k] = p; }
+    }
     if (!records) return;
     uint8_t *rec = records + (size_t)RECORD_BYTES * i;
     for (int k = 0; k < 48; k++) rec[k] = cm[k];
@@ -92,7 +97,7 @@ __device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, co
 }
 
 __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
-                                                    Fr *z_out, uint8_t *records) {
+                                                    Fr *z_out, Fr *zpow_out, uint8_t *records) {
     __shared__ uint4 wk[2][16][64];                 // [buffer][t/4][lane] -> W[t..t+3] + K[t..t+3]
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int i_raw = blockIdx.x * 64 + lane;
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
     }
     if (role != 0 || i_raw >= n_total) return;
     const uint32_t hh[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
-    challenge_finish(hh, i, cm, proofs, z_out, records);
+    challenge_finish(hh, i, cm, proofs, z_out, zpow_out, records);
 }
 
 // The same hash with schedule and rounds in ONE wave.  The two-wave form above halves the dependent chain per block, which is
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(128) k_challenge(const uint8_t *blobs, const u
 // block, no LDS hand-off, no barrier) finishes sooner.
 constexpr int CH1W_THREADS = 256;       // four waves per workgroup: one per SIMD of the CU it lands on
 __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, int n_total,
-                                                      Fr *z_out, uint8_t *records) {
+                                                      Fr *z_out, Fr *zpow_out, uint8_t *records) {
     const int i_raw = blockIdx.x * CH1W_THREADS + threadIdx.x;
     const int i = i_raw < n_total ? i_raw : n_total - 1;
     const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * i);
@@ -202,19 +207,19 @@ __global__ void __launch_bounds__(CH1W_THREADS) k_challenge_1w(const uint8_t *bl
         hh[0] += a; hh[1] += bb; hh[2] += c; hh[3] += d; hh[4] += e; hh[5] += f; hh[6] += g; hh[7] += h;
     }
     if (i_raw >= n_total) return;
-    challenge_finish(hh, i, cm, proofs, z_out, records);
+    challenge_finish(hh, i, cm, proofs, z_out, zpow_out, records);
 }
 
 // Host-hashed form (host_sha256.h): the digests of the challenge transcripts arrive from the host (32 bytes each, big-endian as
 // SHA-256 emits them); what is left is hash_to_bls_field (utils.rs:250-258) and the record's C / z / proof fields.
 __global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *digests, const uint8_t *commitments, const uint8_t *proofs, int n_total,
-                                                              Fr *z_out, uint8_t *records) {
+                                                              Fr *z_out, Fr *zpow_out, uint8_t *records) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_total) return;
     uint32_t hh[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) hh[k] = load_be32(digests + 32 * (size_t)i + 4 * k);
-    challenge_finish(hh, i, commitments + 48 * (size_t)i, proofs, z_out, records);
+    challenge_finish(hh, i, commitments + 48 * (size_t)i, proofs, z_out, zpow_out, records);
 }
 
 // ------------------------------------------------------------------------------------------------ evaluation
@@ -265,16 +270,22 @@ __device__ __forceinline__ void eval_children(Fr c[4], const uint32_t *hx, int n
         for (int k = 0; k < NFR; k++) c[e].l[k] = w[NFR * e + k];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();       // all reads done before the buffer is written again
 }
-__global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *roots, const Fr *tab, int n_per_group,
-                                                 Fr *y_out, uint8_t *records, int *err) {
-    __shared__ uint4 tile[512];
-    __shared__ __attribute__((aligned(16))) uint32_t hx[256 * NFR];
-    const int blob_i = blockIdx.x, lane = threadIdx.x;
+// EVAL_WAVES blobs per workgroup, one wave each, with its own tile and exchange buffer; the waves meet once, after level 3.
+__global__ void __launch_bounds__(64 * EVAL_WAVES) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *zpow, const Fr *roots, const Fr *tab, int n_total,
+                                                          int n_per_group, Fr *y_out, uint8_t *records, int *err) {
+    __shared__ uint4 tiles[EVAL_WAVES][512];
+    __shared__ __attribute__((aligned(16))) uint32_t hxs[EVAL_WAVES][256 * NFR];
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int blob_raw = blockIdx.x * EVAL_WAVES + wid;
+    const int blob_i = blob_raw < n_total ? blob_raw : n_total - 1;          // a tail wave redoes the last blob (no out-of-bounds loads) and reports nothing
+    uint4 *tile = tiles[wid];
+    uint32_t *hx = hxs[wid];
     const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob_i);
     eval_issue_tile_loads(blob, tile, lane);
     const Fr z = z_in[blob_i];
     const Fr imag = roots[2];                                     // position 2 holds w^(N/4)
-    Fr zp; fr_sqr(zp, z); fr_sqr(zp, zp);                         // z^4; later z^16, z^64, ...
+    const Fr *zp = zpow + EVAL_ZPOWERS * (size_t)blob_i;          // z^4, z^16, z^64, z^256, z^1024 (k_challenge*)
+    const Fr z4 = zp[0];
     Fr h2[4];
     bool bad = false;
     constexpr int STEPS = N_FE / 4 / 64;
@@ -312,40 +323,43 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
         if ((it & 3) == 3) {                                      // level 2: node 64 (it >> 2) + lane = entries 4 lane .. 4 lane + 3
             Fr c[4];
             eval_children(c, hx, lane);
-            fr_mul_lazy(T, zp, tab[EVAL_TAB_L2 + 64 * (it >> 2) + lane]);
+            fr_mul_lazy(T, z4, tab[EVAL_TAB_L2 + 64 * (it >> 2) + lane]);
             Fr r2; eval_level2(r2, c, T, imag);
 #pragma unroll
             for (int a = 0; a < 4; a++) if ((it >> 2) == a) h2[a] = r2;
         }
     }
-    if (bad) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
+    if (bad && blob_raw < n_total) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
     Fr c[4], T, h;
     // level 3: node n = lane, children the level-2 nodes 4 lane .. 4 lane + 3 (node 64 a + l sits in lane l's h2[a])
 #pragma unroll
     for (int a = 0; a < 4; a++) eval_park(hx, 64 * a + lane, h2[a]);
     eval_children(c, hx, lane);
-    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^16
-    fr_mul_lazy(T, zp, tab[EVAL_TAB_L3 + lane]);
+    fr_mul_lazy(T, zp[1], tab[EVAL_TAB_L3 + lane]);
     eval_level3(h, c, T, imag);
-    // levels 4, 5, 6: 16, 4 and 1 nodes, every lane computes the node (lane mod 16), (lane mod 4), the root
-    eval_park(hx, lane, h);
-    eval_children(c, hx, lane & 15);
-    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^64
-    fr_mul_lazy(T, zp, tab[EVAL_TAB_L4 + (lane & 15)]);
+    // Levels 4, 5, 6 have 16, 4 and 1 nodes per blob: the workgroup's four blobs share ONE wave for them, 16 lanes per blob (a wave
+    // on its own would run each of them on all 64 lanes for 16, 4 and 1 distinct results).
+    eval_park(hx, lane, h);                                       // this blob's 64 level-3 results: entries 0..63 of its own buffer
+    __syncthreads();
+    if (wid != 0) return;
+    const int b = lane >> 4, u = lane & 15;                       // blob b of the workgroup, level-4 node u
+    const int mine_raw = blockIdx.x * EVAL_WAVES + b, mine = mine_raw < n_total ? mine_raw : n_total - 1;
+    const Fr *zq = zpow + EVAL_ZPOWERS * (size_t)mine;
+    eval_children(c, hxs[b], u);
+    fr_mul_lazy(T, zq[2], tab[EVAL_TAB_L4 + u]);
     eval_level4(h, c, T, imag);
-    if (lane < 16) eval_park(hx, lane, h);
-    eval_children(c, hx, lane & 3);
-    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^256
-    fr_mul_lazy(T, zp, tab[EVAL_TAB_L5 + (lane & 3)]);
+    uint32_t *hx0 = hxs[0];                                       // from here on wave 0's buffer, read only by wave 0: entry 16 b + u, then 4 b + v
+    eval_park(hx0, lane, h);
+    eval_children(c, hx0, 4 * b + (lane & 3));
+    fr_mul_lazy(T, zq[3], tab[EVAL_TAB_L5 + (lane & 3)]);
     eval_level5(h, c, T, imag);
-    if (lane < 4) eval_park(hx, lane, h);
-    eval_children(c, hx, 0);
-    fr_sqr(zp, zp); fr_sqr(zp, zp);                               // z^1024
-    Fr y; eval_level6(y, c, zp, imag);                            // canonical integer value of y
-    if (lane == 0) {
+    if (u < 4) eval_park(hx0, 4 * b + u, h);
+    eval_children(c, hx0, b);
+    Fr y; eval_level6(y, c, zq[4], imag);                         // canonical integer value of y
+    if (u == 0 && mine_raw < n_total) {
         if (records) {
             uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
-            uint8_t *rec = records + (size_t)RECORD_BYTES * blob_i + 80;
+            uint8_t *rec = records + (size_t)RECORD_BYTES * mine + 80;
 #pragma unroll
             for (int i = 0; i < 8; i++) {                         // big-endian bytes, straight from registers
                 const uint32_t v = yw[7 - i];
@@ -356,7 +370,7 @@ __global__ void __launch_bounds__(64, 3) k_eval(const uint8_t *blobs, const Fr *
             const uint32_t r2[NFR] = FR_R2_INIT;
             Fr R2; for (int i = 0; i < NFR; i++) R2.l[i] = r2[i];
             Fr ym; fr_mul(ym, y, R2);
-            y_out[blob_i] = ym;
+            y_out[mine] = ym;
         }
     }
 }
@@ -562,22 +576,23 @@ __global__ void __launch_bounds__(64) k_pairing(const PairPt *pair_pts, const Li
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
+void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, Fr *d_zpow, uint8_t *d_records,
                        hipStream_t st, int form) {
     if (n_total <= 0) return;
     const int wgs = (n_total + 63) / 64;
-    if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
-    else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_records);
+    if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
+    else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
 }
-void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
-                                    hipStream_t st) {
+void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, Fr *d_zpow,
+                                    uint8_t *d_records, hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_challenge_from_digest, dim3((n_total + 63) / 64), dim3(64), 0, st, d_digests, d_commitments, d_proofs, n_total, d_z, d_records);
+    hipLaunchKernelGGL(k_challenge_from_digest, dim3((n_total + 63) / 64), dim3(64), 0, st, d_digests, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
 }
-void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
+void launch_eval(const uint8_t *d_blobs, const Fr *d_z, const Fr *d_zpow, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_eval, dim3(n_total), dim3(64), 0, st, d_blobs, d_z, t.roots, t.eval_tab, n_per_group, d_y, d_records, d_err);
+    hipLaunchKernelGGL(k_eval, dim3((n_total + EVAL_WAVES - 1) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, st, d_blobs, d_z, d_zpow, t.roots, t.eval_tab, n_total, n_per_group,
+                       d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe, int lanes_from, int have_digest) {

@@ -65,12 +65,13 @@ void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_pro
                               int stride = 48);
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only = 0);
 void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
+// d_zpow (may be null): EVAL_ZPOWERS values per blob, z^4, z^16, .. z^1024 (Montgomery) -- what launch_eval needs beside z
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
-                       Fr *d_z, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
+                       Fr *d_z, Fr *d_zpow, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
 // the same records / z from digests hashed on the host (32 bytes per blob, host_sha256.h)
-void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, uint8_t *d_records,
-                                    hipStream_t st);
-void launch_eval(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
+void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, Fr *d_zpow,
+                                    uint8_t *d_records, hipStream_t st);
+void launch_eval(const uint8_t *d_blobs, const Fr *d_z, const Fr *d_zpow, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
                  uint8_t *d_records /* y written at +80; may be null */, int *d_err, hipStream_t st);
 // stage 2 (per group of n records): points from records, r-powers, lincomb, pairing
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st);

@@ -171,6 +171,36 @@ def _product_commit_prove(kz, settings, blobs):
     return B, cs, ps
 
 
+def test_eval_tree_extreme_blobs_match_oracle(kz, settings, oracle, oracle_settings):
+    """k_eval's radix-4 tree (csrc/eval_core.h) at the worst case of its lazy bounds ON THE DEVICE: blobs whose values are all r - 1, or
+    r - 1 / 0 patterns that maximise the sums and differences of every level.  y (and z) of the stage-1 records byte-exact against the
+    oracle's evaluate_polynomial_in_evaluation_form (kzg.rs:346-389); the commitments are whatever the product computes (any G1 point
+    gives a well-defined challenge)."""
+    import torch
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    top, zero = (R_ - 1).to_bytes(32, "big"), bytes(32)
+    blobs = [top * 4096, (top + zero) * 2048, (zero + top) * 2048, (top + top + zero + zero) * 1024, (zero + zero + top + top) * 1024,
+             (top * 16 + zero * 16) * 128, (zero * 64 + top * 64) * 32, top * 2048 + zero * 2048]
+    B, cs, ps = _product_commit_prove(kz, settings, blobs)
+    cs, ps = [bytes(c) for c in cs], [bytes(q) for q in ps]
+    n = len(blobs)
+    dev = torch.device("cuda", settings.device)
+    t_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    t_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
+    t_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
+    t_rec = torch.zeros(160 * n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = (C.c_int * 1)(-1)
+    L = kz.kzg.lib()
+    assert L.kzg355_verify_shard_records_device(t_rec.data_ptr(), st, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n, 1, settings.handle) == 0 and st[0] == 0
+    rec = bytes(t_rec.cpu().numpy())
+    inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+    for i in range(n):
+        assert rec[160 * i + 48:160 * i + 80] == inter["z"][i], f"z[{i}]"
+        assert rec[160 * i + 80:160 * i + 112] == inter["y"][i], f"y[{i}]"
+    assert kz.Kzg.verify_blob_kzg_proof_batch(B, [kz.Bytes48(c) for c in cs], [kz.Bytes48(q) for q in ps], settings) is True
+
+
 def test_batch64_round_trip_and_oracle_agreement(kz, settings, oracle, oracle_settings):
     """The only n = 64 correctness signal the reference has is its bench (benches/kzg_benches.rs:34-41, 113-120: commit,
     prove, then unwrap() the batch verify).  Made explicit here: honest batch -> true, one swapped proof -> false, and the
