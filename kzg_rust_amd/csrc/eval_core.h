@@ -62,20 +62,53 @@ template <int K> KZG_HD void fr_sub_bias(Fr &r, const Fr &a, const Fr &b) {
     }
 }
 
-// One node of the tree: four children (plain lazy values < KC r, in bit-reversal order: roots w, -w, iw, -iw of the node's
-// X^4 = w^4), T = (z^(4^(l-1))) / w and imag = w^(N/4), both Montgomery.  h = F_0 + T F_3 + T^2 F_2 + T^3 F_1.
+// Carry-free forms for values that only feed a product or a later normalising sum: the 64-bit columns of mont_mul_lazy take one operand
+// with limbs up to 2^31 against a normalised one (9 x 2^60 + 9 x 2^58 + carries < 2^64).
+KZG_HD void fr_add_raw(Fr &r, const Fr &a, const Fr &b) {                    // limbs add up, no carries
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = a.l[i] + b.l[i];
+}
+// K r with 2^29 lent to every limb below the top one (and taken back from the limb above): a - b + that is limb-wise positive for normalised b
+template <int K> struct FrMultipleRaw {
+    uint32_t l[NFR];
+    constexpr FrMultipleRaw() : l{} {
+        const FrMultiple<K> n;
+        for (int i = 0; i < NFR; i++) l[i] = n.l[i] + (i < NFR - 1 ? (1u << LB) : 0u) - (i > 0 ? 1u : 0u);
+    }
+};
+// r = a - b + K r', limb by limb without carries: a, b normalised, K r' > b; limbs of the result in [1, 3 * 2^29), top limb >= 0 because
+// (K r' - b) / 2^232 >= 1 whenever K exceeds b's bound by 2^-22
+template <int K> KZG_HD void fr_sub_bias_raw(Fr &r, const Fr &a, const Fr &b) {
+    constexpr FrMultipleRaw<K> kr;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) r.l[i] = a.l[i] - b.l[i] + kr.l[i];
+}
+// r = a + b with the carries swept (b may be a raw sum with limbs up to 2^31)
+KZG_HD void fr_add_sweep(Fr &r, const Fr &a, const Fr &b) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFR; i++) {
+        const uint32_t t = a.l[i] + b.l[i] + c;                               // < 2^29 + 2^31 + 2^3
+        if (i < NFR - 1) { c = t >> LB; r.l[i] = t & LMASK; } else r.l[i] = t;
+    }
+}
+
+// One node of the tree: four children (plain lazy values < KC r with normalised limbs, in bit-reversal order: roots w, -w, iw, -iw of
+// the node's X^4 = w^4), T = (z^(4^(l-1))) / w and imag = w^(N/4), both Montgomery and normalised.  h = F_0 + T F_3 + T^2 F_2 + T^3 F_1,
+// normalised.  Sums that only feed a product (A, B, D', F_1, the Horner partial sums) or the final sweep (F_0) are carry-free.
 template <int KC, int KF2> KZG_HD void eval_node4(Fr &h, const Fr &c0, const Fr &c1, const Fr &c2, const Fr &c3, const Fr &T, const Fr &imag) {
     Fr A, B, C, Dd, iD, F0, F1, F2, F3;
-    fr_add_lazy(A, c0, c1); fr_add_lazy(B, c2, c3);
-    fr_sub_bias<KC>(C, c0, c1); fr_sub_bias<KC>(Dd, c2, c3);
+    fr_add_raw(A, c0, c1); fr_add_raw(B, c2, c3);                             // limbs < 2^30
+    fr_sub_bias<KC>(C, c0, c1);                                               // normalised: it enters F_3's normalising difference
+    fr_sub_bias_raw<KC>(Dd, c2, c3);                                          // limbs < 3 * 2^29
     fr_mul_lazy(iD, Dd, imag);
-    fr_add_lazy(F0, A, B);
-    fr_sub_bias<KF2>(F2, A, B);
-    fr_add_lazy(F1, C, iD);
+    fr_add_raw(F0, A, B);                                                     // limbs < 2^31
+    fr_sub_bias<KF2>(F2, A, B);                                               // normalised (int32 range: |A_i - B_i| < 2^30)
+    fr_add_raw(F1, C, iD);                                                    // limbs < 2^30
     fr_sub_bias<3>(F3, C, iD);
-    fr_mul_lazy(h, F1, T); fr_add_lazy(h, h, F2);
-    fr_mul_lazy(h, h, T); fr_add_lazy(h, h, F3);
-    fr_mul_lazy(h, h, T); fr_add_lazy(h, h, F0);
+    fr_mul_lazy(h, F1, T); fr_add_raw(h, h, F2);
+    fr_mul_lazy(h, h, T); fr_add_raw(h, h, F3);
+    fr_mul_lazy(h, h, T); fr_add_sweep(h, h, F0);
 }
 // The six levels with the bias constants their input bounds call for (header comment).  Level 1 takes the blob's values: < r when
 // the blob is valid, anything below 2^256 = 2.21 r otherwise (flagged by the caller; KC = 3 keeps even those differences positive).

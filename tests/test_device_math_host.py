@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "modinv.h", "sha256.h", "consts_gen.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
@@ -209,7 +209,9 @@ def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_b
             return False
     top = (R_ - 1).to_bytes(32, "big")
     # the lazy bounds of the tree (eval_core.h header) at their worst: every value r - 1, and r - 1 / 0 patterns that maximise the differences
-    extremes = [top * 4096, (top + bytes(32)) * 2048, (bytes(32) + top) * 2048, (top + top + bytes(64)) * 1024, (bytes(64) + top + top) * 1024]
+    ones = (((R_ >> 232) << 232) - 1).to_bytes(32, "big")          # every 29-bit limb below the top one at its maximum: the widest product columns
+    extremes = [top * 4096, (top + bytes(32)) * 2048, (bytes(32) + top) * 2048, (top + top + bytes(64)) * 1024, (bytes(64) + top + top) * 1024,
+                ones * 4096, (ones + bytes(32)) * 2048, (bytes(64) + ones + ones) * 1024]
     blobs = [random_blob(4242), next(b for b in golden_blobs if valid(b)), bytes(131072)] + extremes
     out = C.create_string_buffer(32)
     for blob in blobs:

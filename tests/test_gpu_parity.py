@@ -181,6 +181,8 @@ def test_eval_tree_extreme_blobs_match_oracle(kz, settings, oracle, oracle_setti
     top, zero = (R_ - 1).to_bytes(32, "big"), bytes(32)
     blobs = [top * 4096, (top + zero) * 2048, (zero + top) * 2048, (top + top + zero + zero) * 1024, (zero + zero + top + top) * 1024,
              (top * 16 + zero * 16) * 128, (zero * 64 + top * 64) * 32, top * 2048 + zero * 2048]
+    ones = (((R_ >> 232) << 232) - 1).to_bytes(32, "big")          # every 29-bit limb below the top one at its maximum: the widest product columns
+    blobs += [ones * 4096, (ones + zero) * 2048, (zero + zero + ones + ones) * 1024]
     B, cs, ps = _product_commit_prove(kz, settings, blobs)
     cs, ps = [bytes(c) for c in cs], [bytes(q) for q in ps]
     n = len(blobs)
