@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 //                 lane and walked back to back in one loop                          -> bucket sums B[class][window][b]
 //   k_lc_horner   one lane per (batch, class, b): Horner over the 26 windows (5 doublings + 1 addition each), then the
 //                 weights b over the 16 lanes of a class (suffix scan + butterfly), to affine
-//   k_lc_wsum + k_lc_hchain   the tail for many batches (from 6144 on): window sums weighted first, one Horner chain per class
+//   k_lc_wsum + k_lc_hchain_quad   the tail for many batches (from 6144 on): window sums weighted first, one Horner chain per class
 // Window width: the bucket kernel's work is (items x windows) additions -- 4-bit digits 11.6 k per 64-blob batch, 5-bit 9.7 k,
 // 6-bit 8.4 k -- while the Horner tail has one chain per bucket index: 16 lanes per class at 5 bits still leave it a
 // latency-bound kernel of ~one wave per SIMD at 2048 batches; at 6 bits it would be as much work as the buckets.
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) k_lc_horner(const LcSlot *S, int groups, 
 // Many batches (issue-bound): the 16 chains per class above walk 125 doublings each -- 4000 doublings per batch.  Weighting the
 // buckets first leaves ONE chain per class:
 //   k_lc_wsum    one lane per (batch, class, window):  W = sum_b b B[b]  by running sums (acc += B[b]; W += acc, b = 16 .. 1)
-//   k_lc_hchain  one lane per (batch, class): Horner over the 26 W's (5 doublings + 1 addition each), to affine
+//   k_lc_hchain_quad  one DPP quad per (batch, class): Horner over the 26 W's (5 doublings + 1 addition each), to affine
 // ~200 k wave instructions per batch instead of ~390 k; the dependent chain is ~20 % longer, so the form above stays for fewer batches.
 __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups, G1Jac *W) {
     // the running total is parked in LDS between its additions (limb-major: conflict-free): with acc, the total, the bucket being
@@ -458,16 +458,21 @@ __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups,
     G1Jac j; g1x_to_jac(j, c);
     W[id] = j;
 }
-__global__ void __launch_bounds__(64) k_lc_hchain(const G1Jac *W, int groups, PairPt *pair_pts) {
-    const int gc = blockIdx.x * blockDim.x + threadIdx.x;         // 2 g + class
-    if (gc >= 2 * groups) return;
+// The same chain walked by a DPP quad per (batch, class) (g1_quad.h): 256 waves of pure latency become 1024, each 3 + 3 + .. product stages
+// deep per window instead of 5 x 7 + 16 products on one lane (1.4 -> 0.85 ms per 8192 batches).
+__global__ void __launch_bounds__(256) k_lc_hchain_quad(const G1Jac *W, int groups, PairPt *pair_pts) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, role = tid & 3;
+    const bool live = (tid >> 2) < 2 * groups;
+    const int gc = live ? (tid >> 2) : 2 * groups - 1;            // idle quads redo the last chain (every lane takes part in the DPP moves)
     const G1Jac *w = W + (size_t)gc * LC_WINDOWS;
     G1Jac acc = w[LC_WINDOWS - 1];
+    // one loop, one inlined instance of each quad routine
 #pragma unroll 1
     for (int k = LC_BITS * (LC_WINDOWS - 1) - 1; k >= 0; k--) {
-        g1_dbl_lazy(acc, acc);
-        if (k % LC_BITS == 0) { const G1Jac v = w[k / LC_BITS]; g1_add_lazy(acc, acc, v); }
+        g1_dbl_quad(acc, role);
+        if (k % LC_BITS == 0) { const G1Jac v = w[k / LC_BITS]; g1_add_quad(acc, acc, v, role); }      // (uniform branch)
     }
+    if (!live || role != 0) return;
     G1Jac r; g1_canon_lazy(r, acc);
     PairPt a; pairpt_from_jac(a, r, (gc & 1) == 0);               // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[gc] = a;
@@ -704,7 +709,7 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
         if (groups >= chain_from) {
             G1Jac *W = reinterpret_cast<G1Jac *>(glists + lc_glists_entries(n_per_group, groups));
             hipLaunchKernelGGL(k_lc_wsum, dim3((2 * LC_WINDOWS * groups + 255) / 256), dim3(256), 0, st, S, groups, W);
-            hipLaunchKernelGGL(k_lc_hchain, dim3((2 * groups + 63) / 64), dim3(64), 0, st, W, groups, d_pair_pts);
+            hipLaunchKernelGGL(k_lc_hchain_quad, dim3((8 * groups + 255) / 256), dim3(256), 0, st, W, groups, d_pair_pts);
         } else hipLaunchKernelGGL(k_lc_horner, dim3((2 * LC_BUCKETS * groups + 255) / 256), dim3(256), 0, st, S, groups, d_pair_pts);
     }
 }
