@@ -78,6 +78,55 @@ KERNEL_NAMES = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge
 ALTERNATIVE_FORMS = ("challenge", "msm_bucket", "msm_wide")     # lists of alternative forms of one kernel, not sequences
 
 
+class PowerSampler:
+    """Shader clock and socket power of this rank's GPU from its hwmon files (amdgpu: freq1_input = sclk in Hz, power1_input = PPT in
+    microwatts, power1_cap), sampled every 10 ms by a thread while the timed steps run (the main thread sits in a ctypes call with the GIL
+    released).  Best effort: any missing file turns it off.  On the MI355X boxes measured the verify path sits at the 1400 W cap with the
+    shader clock around 2.28 of 2.4 GHz -- the card, not the kernel, picks the clock."""
+    def __init__(self, dev_index):
+        import threading
+        self.ok, self.samples, self._stop, self._thread = False, [], threading.Event(), None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if not hw:
+                return
+            self.f_clk, self.f_pow, f_cap = hw[0] + "/freq1_input", hw[0] + "/power1_input", hw[0] + "/power1_cap"
+            self.cap_w = int(open(f_cap).read()) / 1e6 if os.path.exists(f_cap) else None
+            int(open(self.f_clk).read()); int(open(self.f_pow).read())
+            self.ok = True
+        except Exception:
+            self.ok = False
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((int(open(self.f_clk).read()) / 1e6, int(open(self.f_pow).read()) / 1e6))
+            except Exception:
+                pass
+            self._stop.wait(0.01)
+
+    def start(self):
+        if self.ok:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True); self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set(); self._thread.join(timeout=1.0)
+        if len(self.samples) < 3:
+            return None
+        clk = sorted(c for c, _ in self.samples); pw = sorted(w for _, w in self.samples)
+        q = lambda v, f: round(v[min(len(v) - 1, int(f * len(v)))], 1)
+        return {"samples": len(self.samples), "interval_ms": 10, "sclk_mhz": {"median": q(clk, 0.5), "p10": q(clk, 0.1), "p90": q(clk, 0.9)},
+                "socket_power_w": {"median": q(pw, 0.5), "p10": q(pw, 0.1), "p90": q(pw, 0.9)}, "power_cap_w": self.cap_w,
+                "source": "amdgpu hwmon freq1_input / power1_input of this GPU, sampled over the timed steps",
+                "note": "nominal-issue fractions in roofline.alu are priced at 2.4 GHz; at the clock the card actually sustains under its power cap they are 2400 / sclk higher"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,7 +288,9 @@ def main():
     exchange_acc.clear()
     s.set_kernel_timing(not args.no_kernel_timing)     # HIP events around every kernel, on its launch stream; the schedule is unchanged
     step_ms = []
+    sampler = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
     barrier()
+    if sampler: sampler.start()
     t0 = time.perf_counter()
     tp = t0
     for _ in range(K):
@@ -247,6 +298,7 @@ def main():
         tn = time.perf_counter(); step_ms.append((tn - tp) * 1e3); tp = tn
     barrier()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler else None
     s.set_kernel_timing(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -340,7 +392,7 @@ def main():
                        "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
-                       "host_inputs": host_inputs},
+                       "host_inputs": host_inputs, "power": power},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if host_inputs:
