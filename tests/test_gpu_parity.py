@@ -685,7 +685,7 @@ def lincomb_handles(kz, setup_bytes):
         finally:
             del os.environ["KZG355_LINCOMB"]
     # and one that takes the many-batch kernels whatever the batch count (by default from 1024 and 6144 batches on): r-transcripts hashed one
-    # lane per batch (k_rhash_lanes), bucket form ending in one Horner chain per class (k_lc_wsum + k_lc_hchain)
+    # lane per batch (k_rhash_lanes), bucket form ending in one Horner chain per class (k_lc_wsum + k_lc_hchain_quad)
     os.environ["KZG355_RHASH_LANES_FROM"] = "1"; os.environ["KZG355_LC_CHAIN_FROM"] = "1"; os.environ["KZG355_LINCOMB"] = "bucket"
     try:
         hs["rhash-lanes"] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
