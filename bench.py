@@ -127,6 +127,44 @@ class PowerSampler:
                 "note": "nominal-issue fractions in roofline.alu are priced at 2.4 GHz; at the clock the card actually sustains under its power cap they are 2400 / sclk higher"}
 
 
+def launcher_command(n, argv, port):
+    """The command the driver itself uses for N > 1 (task statement): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """Start the N ranks of `bench.py --gpus N` as a child torch.distributed.run, relay rank 0's JSON line on stdout (everything else the
+    ranks print goes to stderr) and return the child's exit code.  Called before this process has imported torch or touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "8")
+    child = subprocess.Popen(launcher_command(n, argv, port), stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    lines = 0
+    for ln in child.stdout:
+        is_line = False
+        if ln.startswith("{"):
+            try:
+                is_line = "metric" in json.loads(ln)
+            except ValueError:
+                is_line = False
+        if is_line:
+            lines += 1
+            sys.stdout.write(ln); sys.stdout.flush()
+        else:
+            sys.stderr.write(ln); sys.stderr.flush()
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"bench.py launcher: expected one JSON line from rank 0, saw {lines}\n")
+        return 1
+    return rc if rc >= 0 else 128 - rc                          # killed by a signal: shell convention
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +182,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels of the timed region (A/B of their cost; no roofline)")
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (two-stage HipEngine driver of sharded.py) even at world size 1")
+    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall"),
+                    help="N > 1: alltoall = stage 2 split by batch (default); allgather = BASELINE north_star's single all-gather with stage 2 replicated")
     ap.add_argument("--sweep", action="store_true",
                     help="criterion sweep: verify_blob_kzg_proof_batch for n in {1,..,64} and the five single-op benches, single calls on host inputs")
     args = ap.parse_args()
@@ -151,9 +191,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` the way the N = 1 run is started: this process becomes the launcher.  It has made no GPU call and
+        # imported neither torch nor libkzg355.so; the N ranks are CHILD processes (no exec of a process that has touched the GPU).
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("KZG355_BENCH_ECHO"):
+        # test hook (tests/test_bench_launcher.py, no GPU): every rank reports how it was started; rank 0 prints the line
+        if rank == 0:
+            print(json.dumps({"metric": "echo", "argv": sys.argv[1:], "world": world, "gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                              "exchange": args.exchange, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        raise SystemExit(int(os.environ.get("KZG355_BENCH_ECHO_RC", "0")) if rank == world - 1 else 0)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     import torch
     import torch.distributed as dist
     # Rehearsal hooks for a one-GPU box (never set by the driver): KZG355_BENCH_BACKEND=gloo and KZG355_BENCH_ONE_GPU=1 run the N-rank
@@ -264,7 +313,7 @@ def main():
             assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         else:
             # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
-            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, timings=exchange_acc)
+            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, exchange=args.exchange, timings=exchange_acc)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
     def barrier():
@@ -314,7 +363,7 @@ def main():
         if world > 1:
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-        exchange_stats = {"mode": os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall"), "per_rank_ms_per_step": per_rank,
+        exchange_stats = {"mode": args.exchange, "per_rank_ms_per_step": per_rank,
                           "exchange_ms": max(r.get("exchange_ms", 0.0) for r in per_rank), "stage1_ms": max(r.get("stage1_ms", 0.0) for r in per_rank),
                           "stage2_ms": max(r.get("stage2_ms", 0.0) for r in per_rank), "merge_ms": max(r.get("merge_ms", 0.0) for r in per_rank),
                           "note": "wall ms per step, max over ranks; alltoall: records + decoded points of each rank's share of the batches, then an all-reduce of "
@@ -447,10 +496,11 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
             ts.append((time.perf_counter() - t0) * 1e3)
             assert rc == 0 and ok1.value
         return ts[2:]
+    before = s.host_hashed_calls
     lat = single_calls(15)                                        # the library's default route: challenges hashed on the host for a call of this size
-    hashed_on_host = s.host_hashed_calls > 0
-    s.set_host_hash(-1)
-    lat_dev = single_calls(7)                                     # the same call with the device hash forced (A/B of the host route)
+    hashed_on_host = s.host_hashed_calls - before >= 15           # every timed call took the host route
+    s.set_host_hash(-1)                                           # -1: the per-blob challenges AND the batch challenge r stay on the device
+    lat_dev = single_calls(7)                                     # the same call with both device hashes forced (A/B of the host route)
     s.set_host_hash(0)
     okg = (C.c_bool * groups)(); stg = (C.c_int * groups)()
     rates = []

@@ -107,6 +107,8 @@ typedef struct kzg355_options {
     int chunks_in_flight;      /* workspaces such a call rotates over (0 = 3)                                               KZG355_CHUNKS_IN_FLIGHT */
     int staging_ring;          /* 1: stage caller memory through pinned slots instead of letting the runtime DMA from it    KZG355_STAGING=ring */
     int exchange;              /* handles over several devices: 0 RCCL all-gather when available, 1 peer copies, 2 RCCL or fail   KZG355_EXCHANGE=peer|rccl */
+    int verify_only;           /* 1: the handle serves verification: no wide-window MSM table is built or kept in HBM (the verify path never reads it;
+                                  commitments / proofs still work, through the 15 MB bucket form)                          KZG355_VERIFY_ONLY=1 */
 } kzg355_options;
 void kzg355_options_default(kzg355_options *options);
 void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */
@@ -217,7 +219,7 @@ int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, l
  * [4, 64] -> the small-domain path (one lane per blob, naive lincomb as utils.rs:369-371 takes below 8 points).  Every `blob`
  * argument of this header is 32 * FIELD_ELEMENTS_PER_BLOB bytes for the handle it is passed with. */
 int kzg355_settings_field_elements_per_blob(const kzg355_settings *s);
-/* Which MSM form commitments / proofs take on this handle: 12, 13 or 14 = wide-window table of that digit width; 8 = the 8-bit
+/* Which MSM form commitments / proofs take on this handle: 10 .. 15 = wide-window table of that digit width; 8 = the 8-bit
  * bucket form because KZG355_MSM=bucket asked for it; -8 = the bucket form because the wide table could NOT be allocated (also
  * reported once on stderr by the load function; KZG355_MSM=wide makes that a load error instead). */
 int kzg355_settings_msm_form(const kzg355_settings *s);
@@ -233,7 +235,8 @@ const char *kzg355_version(void);
 /* compute_challenge (kzg.rs:298-339) hashes 131,152 bytes per blob: on the device a 3.7 ms dependent chain for a small call, on a
  * host core with the SHA extensions ~60 us.  Host-buffer verify / blob-proof calls of at most `max_blobs` blobs (one chunk) therefore
  * hash their transcripts on the handle's host threads WHILE the H2D copy and the point kernels run and upload 32-byte digests; larger
- * and device-resident calls keep the device kernels.  mode: 0 by size (default), 1 always, -1 never; max_blobs 0 keeps the current
+ * and device-resident calls keep the device kernels.  mode: 0 by size (default), 1 always, -1 never (the batch challenge r of lone small
+ * calls -- kzg355_options.host_rhash -- follows the same mode: -1 keeps every hash on the device); max_blobs 0 keeps the current
  * crossover (default 4096; KZG355_HOST_HASH=auto|on|off and KZG355_HOST_HASH_MAX in the environment set the same at load). */
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs);
 /* How many host-buffer calls on this handle had their challenges hashed on the host so far. */

@@ -371,9 +371,10 @@ int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uin
     w->side_pending = true;                                       // (from here on a failing call has to drain the side streams: quiesce())
     if (pre) {
         tm.begin("decompress_points", w->side); launch_decompress_points(d_c, d_p, n_total, npg, d_pts, d_err, w->side, stride); tm.end(w->side);
+        // (no second side stream: the shifts follow the decoding on this one, and ev_pts -- what join_points() waits for -- covers both)
+        if (!shift_on_side2) { tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side); }
         HIPCHK(hipEventRecord(w->ev_pts, w->side));
         w->pts_pending = true;
-        if (!shift_on_side2) { tm.begin("lincomb_shift", w->side); launch_lincomb_preshift(d_pts, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side); tm.end(w->side); }
         tm.begin("validate_points", w->side); launch_subgroup_points(d_pts, n_total, npg, d_err, w->side); tm.end(w->side);
         w->shift_ready = true;
     } else {
@@ -427,8 +428,10 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), w->zpow.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
     return KZG355_OK;
 }
+// lone_call: this launch set is the whole of a synchronous call with nothing else of the caller in flight (a single-chunk host-buffer call,
+// a one-set device-resident call) -- the only place where a host round trip in the middle of the chain costs nobody anything.
 int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_records, int npg, int groups, int check_zy, const G1Affine *d_pts,
-               int *d_err, int *d_ok) {
+               int *d_err, int *d_ok, bool lone_call = false) {
     int rc;
     const size_t n_total = (size_t)npg * groups;
     const bool shift_ready = w->shift_ready;                      // consumed here whatever happens below
@@ -440,8 +443,9 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     // The batch challenge r hashes every record of the batch (utils.rs:439-473): one serial SHA-256 chain per batch -- 161 compressions
     // for 64 records, 0.33 ms on a lone GPU lane whatever else the card does.  For a lone small call the records go to the host instead
     // (10 KB for 64), a host core hashes them in microseconds (host_sha256.h) and 32 bytes per batch come back: ~60 us of round trip
-    // in place of the chain.  Large or many-batch calls keep the device forms (k_rpowers / k_rhash_lanes).
-    bool host_rhash = s->host_rhash >= 0 && npg > 1 && n_total <= (size_t)s->host_rhash_max_records && !is_small(s);
+    // in place of the chain.  Large or many-batch calls keep the device forms (k_rpowers / k_rhash_lanes), and so does every launch set that
+    // is one of several in flight (split / pipelined sets, the stage-2 entry points of the sharded path): the wait below would serialise them.
+    bool host_rhash = lone_call && s->host_rhash >= 0 && npg > 1 && n_total <= (size_t)s->host_rhash_max_records && !is_small(s);
     if (host_rhash && ((rc = w->h_records.ensure((size_t)RECORD_BYTES * n_total)) || (rc = w->h_rdig.ensure(32 * (size_t)groups)))) return rc;
     if (host_rhash) {
         HIPCHK(hipMemcpyAsync(w->h_records.p, d_records, (size_t)RECORD_BYTES * n_total, hipMemcpyDeviceToHost, w->stream));
@@ -492,7 +496,7 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
 
 // Enqueue one launch set on w->stream (no host synchronisation) ...
 int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
-                   size_t res_off = 0, size_t res_cap = 0, HostFront *hf = nullptr) {
+                   size_t res_off = 0, size_t res_cap = 0, HostFront *hf = nullptr, bool lone_call = false) {
     // res_off / res_cap: several launch sets queued on one workspace (stream order keeps the device scratch safe) park their
     // verdicts at different offsets of the pinned result buffers, sized res_cap entries up front
     const int n_total = npg * G;
@@ -507,7 +511,7 @@ int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
     if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>(), true, hf))) return rc;
-    if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+    if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>(), lone_call))) return rc;
     if ((rc = join_side(w))) return rc;                           // the subgroup verdicts, before the error words go back
     HIPCHK(hipMemcpyAsync(w->h_ok.as<int>() + res_off, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.as<int>() + res_off, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
@@ -552,7 +556,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         WsGuard g(cs);
         if (!g.w) return KZG355_NO_DEVICE;
         Timed tm(g.s, g.w);
-        int rc = verify_enqueue(g.s, g.w, tm, d_blobs, d_c, d_p, (int)npg, (int)groups);
+        int rc = verify_enqueue(g.s, g.w, tm, d_blobs, d_c, d_p, (int)npg, (int)groups, 0, 0, nullptr, true);
         if (rc) return rc;
         return verify_collect(g.w, tm, ok, status, (int)groups);
     }
@@ -826,7 +830,7 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         }
         t_stage += now() - t0; t0 = now();
         HostFront *hfp = hf.running ? &hf : nullptr;
-        if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt, 0, 0, hfp);
+        if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg, (int)cnt, 0, 0, hfp, nchunks == 1);
         else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt, hfp);
         if (rc) return rc;
         if (dbg && !direct) (void)hipEventRecord(dev_ev[3 * k + 2], w->stream);
@@ -909,6 +913,7 @@ void kzg355_options_from_env(kzg355_options *o) {
     if (const char *e = getenv("KZG355_CHALLENGE")) o->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_LINCOMB")) o->lincomb_form = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
     if (const char *e = getenv("KZG355_EXCHANGE")) o->exchange = strcmp(e, "peer") == 0 ? 1 : strcmp(e, "rccl") == 0 ? 2 : 0;
+    num("KZG355_VERIFY_ONLY", 0, 1, &o->verify_only);
 }
 // the caller's struct may be older (smaller) than this library's: fields beyond its struct_size keep their defaults
 static kzg355_options options_of(const kzg355_options *opt) {
@@ -1026,7 +1031,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
     g1b.release(); g2b.release(); err.release();
     {   // the 23.6 GB wide-window MSM table (msm_bits = 8 keeps the 15 MB 8-bit form only; so does a failed allocation)
-        if (!small && opt.msm_bits != 8) {
+        if (!small && opt.msm_bits != 8 && !opt.verify_only) {
             const int bits = opt.msm_bits >= 10 && opt.msm_bits <= 15 ? opt.msm_bits : 12;
             const bool required = opt.msm_require_wide != 0;
             s->t.wide = wide_shape(bits);
@@ -1335,7 +1340,8 @@ void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timin
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s) { return s ? s->n_host_hashed.load() : 0L; }
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs) {
     if (!s || mode < -1 || mode > 1 || max_blobs < 0) return KZG355_BADARGS;
-    for (kzg355_settings *r : s->multi ? replicas_of(s) : std::vector<kzg355_settings *>{s}) { r->host_hash = mode; if (max_blobs) r->host_hash_max = max_blobs; }
+    // both Fiat-Shamir hashes follow the mode: -1 keeps the per-blob challenges AND the batch challenge r on the device
+    for (kzg355_settings *r : s->multi ? replicas_of(s) : std::vector<kzg355_settings *>{s}) { r->host_hash = mode; r->host_rhash = mode < 0 ? -1 : 0; if (max_blobs) r->host_hash_max = max_blobs; }
     return KZG355_OK;
 }
 int kzg355_host_sha256(uint8_t out[32], const uint8_t *msg, size_t len, int impl) {
@@ -1432,7 +1438,7 @@ int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_poi
 namespace {
 // stage 2 over gathered records; `dump` (host, groups*128 bytes or null) receives r | proof_lincomb | rhs per batch; d_points (or
 // null): the validated affine points of the records as stage 1 produced them ([batch][commitments, proofs]), sparing their decompression
-int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs,
+static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs,
                         const uint8_t *d_points = nullptr) {
     if (!cs || !ok) return KZG355_BADARGS;
     if (groups == 0) return KZG355_OK;
@@ -1504,14 +1510,14 @@ int kzg355_debug_batch_intermediates(uint8_t *out, bool *ok, int *status, const 
 // ---- multi-device execution of the host-buffer entry points ------------------------------------------------------------
 namespace {
 
-int single_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+static int single_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
                        const kzg355_settings *cs) {
     HostCall hc{0, blobs, commitments, proofs, npg, ok, nullptr, status};
     return host_pipeline(hc, groups, cs);
 }
 
 // contiguous ranges of `units` over D devices; the work of device d is fn(d, first unit, count) on its own host thread
-int fan_out(size_t D, size_t units, const std::function<int(size_t, size_t, size_t)> &fn) {
+static int fan_out(size_t D, size_t units, const std::function<int(size_t, size_t, size_t)> &fn) {
     std::vector<std::future<int>> fut;
     for (size_t d = 0; d < D; d++) {
         const size_t lo = units * d / D, hi = units * (d + 1) / D;
@@ -1523,7 +1529,7 @@ int fan_out(size_t D, size_t units, const std::function<int(size_t, size_t, size
 }
 
 // Fewer batches than devices: every batch is sharded over the devices in contiguous blocks of blobs.
-int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+static int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
                          const kzg355_settings *cs) {
     MultiDev *m = cs->multi;
     const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
@@ -1674,7 +1680,7 @@ int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint
     return KZG355_OK;
 }
 
-int multi_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
+static int multi_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
                       const kzg355_settings *cs) {
     MultiDev *m = cs->multi;
     const size_t D = m->rep.size(), BB = blob_bytes_of(cs);

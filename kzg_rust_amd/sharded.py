@@ -18,7 +18,7 @@ combination challenge r, a hash over ALL (C_i, z_i, y_i, proof_i) (utils.rs:454-
                                          is an Err everywhere (the `?` semantics)
 
 BASELINE.json's north_star names the other form -- a single all-gather of the records with stage 2 replicated on every rank; it is
-here as exchange="allgather" (KZG355_BENCH_EXCHANGE=allgather for bench.py), so that an 8-GPU run can compare the two.
+here as exchange="allgather" (bench.py --exchange allgather), so that an 8-GPU run can compare the two.
 
 The compute stages are delegated to an `engine` with two methods, so that the orchestration (partitioning, gather
 order, status merging) is testable on CPU with gloo; the product engine is HipEngine (C ABI of libkzg355.so).
@@ -43,8 +43,10 @@ class HipEngine:
 
     def shard_records(self, blobs, commitments, proofs, n_local, groups):
         import torch
-        rec = torch.zeros(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
-        pts = torch.zeros(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
+        # torch.empty, not zeros: a fill kernel would be queued on torch's stream, which nothing orders against the engine's own streams
+        # (a late fill could wipe records stage 1 has already written).  A call that writes nothing reports it in every status.
+        rec = torch.empty(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
+        pts = torch.empty(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
         st = (C.c_int * max(groups, 1))()
         rc = self.L.kzg355_verify_shard_records_points_device(rec.data_ptr(), pts.data_ptr(), st, blobs.data_ptr(), commitments.data_ptr(), proofs.data_ptr(),
                                                               n_local, groups, self.s.handle)
@@ -113,14 +115,13 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     """`groups` independent batches; this rank holds n_local blobs of each (group-major uint8 tensors).
     Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err.
 
-    exchange (default: $KZG355_BENCH_EXCHANGE or "alltoall"):
+    exchange (default "alltoall"; an ARGUMENT only -- ranks that read it from their environments could disagree and hang in different collectives):
       "alltoall"   stage 2 split by batch: ONE all-to-all brings every rank the records (+ decoded points) of its share of the batches,
                    one small all-reduce(MAX) spreads the verdicts and merges the statuses;
       "allgather"  BASELINE.json's north_star form: ONE all-gather of every rank's records (+ points + stage-1 statuses), then EVERY rank
                    runs stage 2 on all batches (replicated: no second collective, world x the stage-2 work).
     timings (dict or None): accumulates stage1_ms / exchange_ms / stage2_ms / merge_ms of this rank, so that a scaling curve can be
     attributed (bench.py reports them per rank in config.exchange)."""
-    import os
     import time
     import numpy as np
     import torch
@@ -128,7 +129,7 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if n_local == 0:
         return [True] * groups, [0] * groups                       # kzg.rs:653-655
-    mode = exchange or os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall")
+    mode = exchange or "alltoall"
     if mode not in ("alltoall", "allgather"):
         raise ValueError(f"exchange must be alltoall or allgather, not {mode!r}")
     dev = local_blobs.device

@@ -46,6 +46,7 @@ pub struct kzg355_options {
     pub chunks_in_flight: c_int,
     pub staging_ring: c_int,
     pub exchange: c_int,
+    pub verify_only: c_int,
 }
 
 extern "C" {

@@ -30,6 +30,17 @@ def test_header_symbols_exported(lib):
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
 
 
+def test_library_exports_the_c_abi_and_nothing_else(lib):
+    """Every dynamic symbol libkzg355.so defines is an entry point of include/kzg355.h (csrc/exports.map): no unprefixed helpers, no C++
+    standard-library instantiations, no kernel stubs -- nothing that could collide inside the program it is linked into."""
+    so = os.path.join(ROOT, "kzg_rust_amd", "libkzg355.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names and not [n for n in names if not n.startswith("kzg355_")]
+    from kzg_rust_amd import _lib
+    assert sorted(names) == sorted(_lib.EXPORTED_SYMBOLS)
+
+
 def test_product_does_not_link_the_oracle():
     so = os.path.join(ROOT, "kzg_rust_amd", "libkzg355.so")
     out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
