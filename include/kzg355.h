@@ -250,6 +250,14 @@ long kzg355_settings_host_hashed_calls(const kzg355_settings *s);
 int kzg355_debug_verify_host_records(uint8_t *records_out /* groups*n_per_group*160, host */, bool *ok /* groups */, int *status /* groups or NULL */,
                                      const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t n_per_group, size_t groups,
                                      const kzg355_settings *s);
+/* Test / audit form of the SHARDED execution of kzg355_verify_blob_kzg_proof_batch_many on a handle over several devices (BASELINE config 5: one
+ * 512-blob batch cut into per-device blocks): every batch goes through stage 1 per block -> the record exchange -> stage 2 on one
+ * device, whatever the batch count, and out[128 g ..] receives r | proof_lincomb | rhs of batch g as kzg355_debug_batch_intermediates lays them
+ * out.  n_per_group >= the handle's device count; plain handles -> KZG355_BADARGS.  tests/test_gpu_multi_device.py diffs these against
+ * tests/golden/batch512.json. */
+int kzg355_debug_verify_sharded_intermediates(uint8_t *out /* groups*128, host */, bool *ok /* groups */, int *status /* groups or NULL */,
+                                              const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t n_per_group, size_t groups,
+                                              const kzg355_settings *s);
 int kzg355_host_sha256(uint8_t out[32], const uint8_t *msg, size_t len, int impl);
 int kzg355_host_challenge_digests(uint8_t *out /* n*32 */, const uint8_t *blobs, size_t blob_bytes, const uint8_t *commitments /* n*48 */, size_t n, int impl);
 

@@ -74,6 +74,7 @@ def load():
         "kzg355_host_sha256": [u8p, u8p, sz, C.c_int],
         "kzg355_debug_verify_host_records": [u8p, bp, ip, u8p, u8p, u8p, sz, sz, vp],
         "kzg355_host_challenge_digests": [u8p, u8p, sz, u8p, sz, C.c_int],
+        "kzg355_debug_verify_sharded_intermediates": [u8p, bp, ip, u8p, u8p, u8p, sz, sz, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -108,5 +109,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_kernel_ms_stats", "kzg355_reset_kernel_stats",
     "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_verify_shard_records_points_device", "kzg355_verify_records_points_device", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
     "kzg355_settings_set_host_hash", "kzg355_settings_host_hashed_calls", "kzg355_host_sha256", "kzg355_host_challenge_digests", "kzg355_debug_verify_host_records",
-    "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex",
+    "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex", "kzg355_debug_verify_sharded_intermediates",
 ]

@@ -1529,8 +1529,10 @@ static int fan_out(size_t D, size_t units, const std::function<int(size_t, size_
 }
 
 // Fewer batches than devices: every batch is sharded over the devices in contiguous blocks of blobs.
+// `dump` (host, groups * 128 bytes or null; kzg355_debug_verify_sharded_intermediates): r | proof_lincomb | rhs of every batch, read back from
+// the device that ran its stage 2.
 static int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t npg, size_t groups,
-                         const kzg355_settings *cs) {
+                         const kzg355_settings *cs, uint8_t *dump = nullptr) {
     MultiDev *m = cs->multi;
     const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
     DeviceScope keep; keep.hold();               // this thread visits every replica's device below
@@ -1651,6 +1653,11 @@ static int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, con
                 HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * G, w->stream));
                 Timed tm(rs, w);
                 if ((rc = run_stage2(rs, w, tm, gath.as<uint8_t>(), (int)npg, (int)G, 0, gpts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>()))) return rc;
+                if (dump) {
+                    if ((rc = w->out48.ensure(128 * G)) || (rc = w->h_out.ensure(128 * G))) return rc;
+                    launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<PairPt>(), (int)npg, (int)G, w->out48.as<uint8_t>(), w->stream);
+                    HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 128 * G, hipMemcpyDeviceToHost, w->stream));
+                }
                 HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
                 HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * G, hipMemcpyDeviceToHost, w->stream));
                 HIPCHK(hipStreamSynchronize(w->stream));
@@ -1658,6 +1665,7 @@ static int multi_verify_sharded(bool *ok, int *status, const uint8_t *blobs, con
                 tm.collect();
                 for (size_t k = 0; k < G; k++) {
                     const size_t g = mine[k];
+                    if (dump) memcpy(dump + 128 * g, w->h_out.as<uint8_t>() + 128 * k, 128);
                     int st = status_from_err(w->h_err.as<int>()[k]);
                     for (size_t d = 0; d < D; d++) if (st == KZG355_OK) st = st1[d][g];    // an Err on any block is an Err of the batch (the `?`s of kzg.rs:673-682)
                     if (status) status[g] = st;
@@ -1715,6 +1723,13 @@ int kzg355_debug_verify_host_records(uint8_t *records_out, bool *ok, int *status
     HostCall hc{0, blobs, commitments, proofs, n_per_group, ok, nullptr, status};
     hc.records_out = records_out;
     return host_pipeline(hc, groups, cs);
+}
+
+int kzg355_debug_verify_sharded_intermediates(uint8_t *out, bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
+                                              size_t n_per_group, size_t groups, const kzg355_settings *cs) {
+    if (!cs || !ok || !out || !blobs || !commitments || !proofs || !cs->multi || groups == 0) return KZG355_BADARGS;
+    if (n_per_group < cs->multi->rep.size() || n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;      // every device gets a block of every batch
+    return multi_verify_sharded(ok, status, blobs, commitments, proofs, n_per_group, groups, cs, out);
 }
 
 int kzg355_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, size_t n_blobs, const uint8_t *commitments, size_t n_commitments,

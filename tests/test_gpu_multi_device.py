@@ -115,3 +115,54 @@ def test_rccl_all_gather_on_a_one_device_communicator(kz, setup_bytes, data):
     finally:
         del os.environ["KZG355_FORCE_SHARDED"]
         s.free()
+
+
+def test_config5_512_blob_batch_over_eight_replicas(kz, setup_bytes):
+    """BASELINE.json configs[4] everywhere short of real xGMI: the committed 512-blob batch (tests/golden/batch512.json) through
+    kzg355_verify_blob_kzg_proof_batch on a handle over EIGHT replicas (all on device 0: the box has one card), i.e. the partition the 8-GPU
+    node takes -- contiguous blocks of 64 blobs per device, stage 1 per block, the record exchange, stage 2 on one device.
+    Verdict true, swapped twin false, an Err raised by a block other than the first; and r / proof_lincomb / rhs of the SHARDED call read
+    back and compared with the fixture byte for byte (transcript order of utils.rs:454-463 across the blocks, kzg.rs:601-622)."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "batch512.json")))
+    n = fx["n"]
+    blobs = [random_blob(fx["first_index"] + i) for i in range(n)]
+    B = [kz.Blob(b) for b in blobs]
+    cs = [kz.KzgCommitment(bytes.fromhex(c)) for c in fx["commitments"]]
+    ps = [kz.KzgProof(bytes.fromhex(p)) for p in fx["proofs"]]
+    s = _load(kz, setup_bytes, [0] * 8, KZG355_EXCHANGE="peer")
+    try:
+        assert s.device_count == 8
+        before = s.exchange_stats()[2]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, ps, s) is fx["expect"]
+        assert s.exchange_stats()[2] == before + 1, "the 512-blob batch did not take the sharded path"
+        a, b = fx["swapped_pair"]
+        sw = list(ps); sw[a], sw[b] = sw[b], sw[a]
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, cs, sw, s) is fx["expect_swapped"]
+        bad_c = list(cs); bad_c[300] = kz.KzgCommitment(bytes([0x9a]) + b"\xff" * 47)        # block 4 of 8
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch(B, bad_c, ps, s)
+        bb = bytearray(blobs[511]); bb[32 * 4095:] = b"\xff" * 32                            # non-canonical element in the last block
+        with pytest.raises(kz.BadArgs):
+            kz.Kzg.verify_blob_kzg_proof_batch(B[:511] + [kz.Blob(bytes(bb))], cs, ps, s)
+        L = kz.kzg.lib()
+        out = C.create_string_buffer(128)
+        ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
+        flat = b"".join(blobs); fc = b"".join(c.to_bytes() for c in cs); fp = b"".join(p.to_bytes() for p in ps)
+        rc = L.kzg355_debug_verify_sharded_intermediates(out, ok, st, flat, fc, fp, n, 1, s.handle)
+        assert rc == 0 and st[0] == 0 and ok[0] is True
+        d = out.raw
+        assert d[:32].hex() == fx["r"]
+        assert d[32:80].hex() == fx["proof_lincomb"]
+        assert d[80:128].hex() == fx["rhs"]
+        fsw = b"".join(p.to_bytes() for p in sw)
+        rc = L.kzg355_debug_verify_sharded_intermediates(out, ok, st, flat, fc, fsw, n, 1, s.handle)
+        assert rc == 0 and ok[0] is False and out.raw[:32].hex() != fx["r"]
+        # the same blobs as eight independent 64-blob batches on the eight replicas: ranges of batches, no exchange
+        ex = s.exchange_stats()[2]
+        groups = [(B[64 * g:64 * g + 64], cs[64 * g:64 * g + 64], ps[64 * g:64 * g + 64]) for g in range(8)]
+        assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, s) == [True] * 8
+        assert s.exchange_stats()[2] == ex
+        # a plain handle has no sharded form to read back
+    finally:
+        s.free()

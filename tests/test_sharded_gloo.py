@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the sharded verify orchestration in kzg_rust_amd/sharded.py: partitioning, the single
+"""world_size-2 and world_size-8 gloo tests (CPU) of the sharded verify orchestration in kzg_rust_amd/sharded.py: partitioning, the single
 all-to-all of 160-byte records, gather order (= transcript order), status merging.  The compute stages are played by the
 CPU oracle here (test infrastructure); on the GPU box the same driver runs over HipEngine (tests/test_gpu_parity.py and
 bench.py --gpus N)."""
@@ -12,8 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_TOTAL = 4        # blobs per batch, 2 per rank
-GROUPS = 3         # batch 0 honest, batch 1 has swapped proofs (false), batch 2 has an invalid commitment on rank 1 (Err)
+N_LOCAL = 2        # blobs of every batch per rank (BASELINE config 5 has 64 per rank: same code path, the oracle is the slow part)
+GROUPS = 3         # batch 0 honest, batch 1 has swapped proofs (false), batch 2 has an invalid commitment on one rank (Err)
 
 
 class OracleEngine:
@@ -52,14 +52,14 @@ class OracleEngine:
         return ok, st
 
 
-def _inputs():
+def _inputs(n_total):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle.oracle import Oracle
     from synth import random_blob
     o = Oracle()
     g = os.path.join(ROOT, "tests", "golden")
     s = o.load_trusted_setup(open(os.path.join(g, "trusted_setup_g1.bin"), "rb").read(), open(os.path.join(g, "trusted_setup_g2.bin"), "rb").read())
-    blobs = [random_blob(500 + i) for i in range(N_TOTAL)]
+    blobs = [random_blob(500 + i) for i in range(n_total)]
     cs = [o.blob_to_kzg_commitment(b, s) for b in blobs]
     ps = [o.compute_blob_kzg_proof(b, c, s) for b, c in zip(blobs, cs)]
     return blobs, cs, ps
@@ -71,15 +71,15 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from kzg_rust_amd.sharded import partition, verify_blob_kzg_proof_batch_sharded
-    lo, hi = partition(N_TOTAL, world)[rank]
+    lo, hi = partition(N_LOCAL * world, world)[rank]
     n_local = hi - lo
     batches = []
     for g in range(GROUPS):
         b, c, p = blobs[lo:hi], list(cs[lo:hi]), list(ps[lo:hi])
         if g == 1 and rank == 0:
             p[0], p[1] = p[1], p[0]                        # valid points, wrong statement -> false
-        if g == 2 and rank == 1:
-            c[0] = bytes([0x9A]) + b"\xff" * 47            # x >= p -> Err on rank 1 only
+        if g == 2 and rank == world - 3 + 2 * (world == 2):
+            c[0] = bytes([0x9A]) + b"\xff" * 47            # x >= p -> Err on one rank only (rank 1 of 2, rank 5 of 8)
         batches.append((b, c, p))
     tb = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[0])), dtype=torch.uint8)
     tc = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[1])), dtype=torch.uint8)
@@ -88,8 +88,9 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     timings = {}
     ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange, timings=timings)
     assert timings.get("stage1_ms", 0) > 0 and "exchange_ms" in timings and "merge_ms" in timings, timings
-    # ONE batch over two ranks: rank 0's share of the batches is EMPTY (groups * 0 // 2 == groups * 1 // 2), rank 1 runs stage 2
-    # alone, and the all-reduce still has to hand rank 0 the verdict -- honest first, then with rank 0's proofs swapped, then with
+    # ONE batch over the ranks (BASELINE config 5's shape): every share of the batches but the last rank's is EMPTY
+    # (groups * r // world == groups * (r + 1) // world), the last rank runs stage 2 alone, and the all-reduce still has to hand
+    # the others the verdict -- honest first, then with rank 0's proofs swapped, then with
     # an invalid proof on rank 0 (Err raised by a rank that verifies nothing itself)
     one = lambda t, per: t[:n_local * per].clone()
     ok1, st1 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), one(tp, 48), n_local, 1, eng, exchange=exchange)
@@ -105,19 +106,20 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
-def test_sharded_verify_world2_gloo(exchange):
-    """both exchanges: the all-to-all with stage 2 split by batch, and BASELINE.json's single all-gather with stage 2 replicated"""
-    blobs, cs, ps = _inputs()
+@pytest.mark.parametrize("world,exchange", [(2, "alltoall"), (2, "allgather"), (8, "alltoall"), (8, "allgather")])
+def test_sharded_verify_gloo(world, exchange):
+    """both exchanges: the all-to-all with stage 2 split by batch, and BASELINE.json's single all-gather with stage 2 replicated; at world 8
+    (config 5's rank count) the three batches fall to ranks 2, 5 and 7 -- five ranks with an empty share of the batches"""
+    blobs, cs, ps = _inputs(N_LOCAL * world)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, blobs, cs, ps, q, exchange)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, blobs, cs, ps, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in procs)
+    res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
