@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels of the timed region (A/B of their cost; no roofline)")
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (two-stage HipEngine driver of sharded.py) even at world size 1")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="launch sets in flight (device-resident verify, 1 GPU): >1 submits every step with kzg355_verify_blob_kzg_proof_batch_many_device_submit and "
+                         "collects the oldest once this many are queued -- mid-size sets (--batches-per-step 1024) kept in flight from one thread")
     ap.add_argument("--exchange", choices=["alltoall", "allgather"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall"),
                     help="N > 1: alltoall = stage 2 split by batch (default); allgather = BASELINE north_star's single all-gather with stage 2 replicated")
     ap.add_argument("--sweep", action="store_true",
@@ -331,8 +334,36 @@ def main():
             barrier(); t0 = time.perf_counter(); run_steps(1); barrier(); lat.append((time.perf_counter() - t0) * 1e3)
     latency_ms = statistics.median(lat)
 
+    # --pipeline D: one host thread keeps D launch sets in flight (submit / collect halves of the same entry point; every set on its own
+    # stream of the handle, so the narrow tail of one set runs under the wide kernels of the next)
+    pipeline = args.pipeline if (args.pipeline > 1 and args.op == "verify" and world == 1 and not args.host_inputs and not args.sharded_path) else 1
+    pending, free_slots = [], [((C.c_bool * Cc)(), (C.c_int * Cc)()) for _ in range(pipeline)]
+
+    def collect_oldest():
+        tk, slot = pending.pop(0)
+        rc = L.kzg355_verify_collect(tk, slot[0], slot[1])
+        assert rc == 0, rc
+        assert bytes(slot[0])[:Cc] == b"\x01" * Cc, "a verification returned false on honest inputs"
+        free_slots.append(slot)
+
+    def step_pipelined():
+        tk = C.c_void_p()
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, Cc, s.handle)
+        assert rc == 0, rc
+        pending.append((tk, free_slots.pop()))
+        if len(pending) >= pipeline:
+            collect_oldest()
+
+    def one_step():
+        if pipeline > 1:
+            step_pipelined()
+        else:
+            run_steps(Cc)                              # synchronous: returns when this step's verdicts are on the host
+
     for _ in range(W):
-        run_steps(Cc)
+        one_step()
+    while pending:
+        collect_oldest()
     L.kzg355_reset_kernel_stats(s.handle)
     exchange_acc.clear()
     s.set_kernel_timing(not args.no_kernel_timing)     # HIP events around every kernel, on its launch stream; the schedule is unchanged
@@ -343,8 +374,10 @@ def main():
     t0 = time.perf_counter()
     tp = t0
     for _ in range(K):
-        run_steps(Cc)                                  # synchronous: returns when this step's verdicts are on the host
+        one_step()
         tn = time.perf_counter(); step_ms.append((tn - tp) * 1e3); tp = tn
+    while pending:                                     # (pipelined: the sets still in flight belong to the K timed steps)
+        collect_oldest()
     barrier()
     dt = time.perf_counter() - t0
     power = sampler.stop() if sampler else None
@@ -437,7 +470,7 @@ def main():
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-to-all of 160-B records"),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
-                       "field_elements_per_blob": 4096, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
+                       "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
                        "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),

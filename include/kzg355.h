@@ -109,6 +109,9 @@ typedef struct kzg355_options {
     int exchange;              /* handles over several devices: 0 RCCL all-gather when available, 1 peer copies, 2 RCCL or fail   KZG355_EXCHANGE=peer|rccl */
     int verify_only;           /* 1: the handle serves verification: no wide-window MSM table is built or kept in HBM (the verify path never reads it;
                                   commitments / proofs still work, through the 15 MB bucket form)                          KZG355_VERIFY_ONLY=1 */
+    int submit_sets;           /* submit / collect: 0 by size (sets of <= 128 blobs per CU as 1, larger ones as 2); 1 = every submitted set on a stream of its
+                                  own; 2 = two-stage pipeline: stage 1 of the submitted sets in order on one stream, stage 2 of a set on a second
+                                  one, queued behind the NEXT set's Fiat-Shamir kernel                                   KZG355_SUBMIT=sets|pipeline */
 } kzg355_options;
 void kzg355_options_default(kzg355_options *options);
 void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */
@@ -159,6 +162,17 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok /* groups */, int *status /
  * ok / status are host pointers.  Synchronous: returns when the verdicts are on the host. */
 int kzg355_verify_blob_kzg_proof_batch_many_device(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
                                                    const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *s);
+/* The same call in two halves, for a caller that keeps several launch sets in flight from ONE host thread (a set of 1024 batches is 8.6 GB of
+ * blobs; the synchronous call wants ~8192 batches = 69 GB per call to reach the same rate): _submit queues the whole set on a private stream of
+ * the handle and returns at once with a ticket; kzg355_verify_collect waits for that set, writes ok[g] / status[g] (host, `groups` entries as
+ * submitted) and CONSUMES the ticket, whatever it returns.  Stage 2 of a submitted set (r powers, linear combination, pairing) runs beside the
+ * evaluation and point kernels of the set submitted after it; keep THREE sets in flight (submit k + 2 before collecting k) and 1024-batch sets
+ * run at 4.0 M blobs/s against 3.4 M one at a time (profiles/r04/pipeline_sweep.txt).  Collect in any order; every ticket must be collected before the handle is freed; the
+ * device buffers of a set must stay untouched until its collect returns.  Returns as the synchronous call (first non-OK status at collect). */
+typedef struct kzg355_ticket kzg355_ticket;
+int kzg355_verify_blob_kzg_proof_batch_many_device_submit(kzg355_ticket **ticket, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                                          const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *s);
+int kzg355_verify_collect(kzg355_ticket *ticket, bool *ok /* groups */, int *status /* groups or NULL */);
 int kzg355_blob_to_kzg_commitment_many_device(uint8_t *out /* host n*48 */, int *status /* host n or NULL */, const uint8_t *d_blobs, size_t n,
                                               const kzg355_settings *s);
 int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,

@@ -70,6 +70,8 @@ struct PinBuf {
 // concurrent host threads get different workspaces from the pool in the settings handle.
 struct Workspace {
     hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;     // side, side2: kernels independent of the main chain (point validation; window shifts)
+    hipStream_t own_stream = nullptr;                                  // `stream` is this one except while a submitted set borrows the handle's pipeline streams
+    hipEvent_t ev_stage = nullptr, ev_done = nullptr, ev_fork2 = nullptr;   // submit / collect: stage 1 queued on pipe_main is done; the whole set is done; this set's hash is done
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pts = nullptr, ev_shift = nullptr;
     // work on the side streams that the main stream has not waited for yet: everything (ev_join: the validation verdicts are in the error
     // words), the decoded points alone (ev_pts; recorded only when they are ready before the verdicts), the window shifts (ev_shift)
@@ -81,21 +83,25 @@ struct Workspace {
     hipEvent_t ev[32];
     bool ev_ok = false;
     bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
+    hipStream_t borrowed[2] = {nullptr, nullptr};   // the handle's pipeline streams while a submitted set of this workspace is on them
     // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
     void quiesce() {
         if (in_flight || side_pending || pts_pending || shift_pending) {
             if (side) (void)hipStreamSynchronize(side);
             if (side2) (void)hipStreamSynchronize(side2);
+            for (hipStream_t st : borrowed) if (st) (void)hipStreamSynchronize(st);
             if (stream) (void)hipStreamSynchronize(stream);
         }
+        borrowed[0] = borrowed[1] = nullptr;
+        stream = own_stream;
         in_flight = false; side_pending = false; pts_pending = false; shift_pending = false; shift_ready = false;
     }
     ~Workspace() {
         for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift}) if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);       // (side is the handle's shared stream: not owned)
+        for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift, ev_stage, ev_done, ev_fork2}) if (e) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(own_stream);       // (side is the handle's shared stream: not owned)
     }
 };
 
@@ -202,6 +208,10 @@ struct kzg355_settings {
     int challenge_two_wave_upto = 32768; // blobs per launch set up to which the Fiat-Shamir hash runs as producer / consumer wave pairs (2 workgroups per CU)
     std::mutex mu;
     hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
+    hipStream_t pipe_main = nullptr, pipe_tail = nullptr;         // submit / collect: stage 1 of every submitted set in order on pipe_main, stage 2 on pipe_tail
+    std::mutex pipe_mu;                                           // orders the submits / collects that queue work on the two
+    struct kzg355_ticket *pending_tail = nullptr;                 // the submitted set whose stage 2 is not queued yet (it goes out behind the next set's hash)
+    int submit_mode = 0;             // 0 by size; 1: every submitted set on its workspace's own stream; 2: two-stage software pipeline over pipe_main / pipe_tail (KZG355_SUBMIT=sets|pipeline)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
     int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v4.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
     int host_rhash = 0;              // batch challenge r of lone small calls hashed on the host (records copied back): 0 by size, -1 never (KZG355_HOST_RHASH=off)
@@ -229,11 +239,12 @@ Workspace *ws_acquire(kzg355_settings *s) {
         if (!s->pool.empty()) { Workspace *w = s->pool.back(); s->pool.pop_back(); return w; }
     }
     Workspace *w = new Workspace();
-    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { w->stream = nullptr; delete w; return nullptr; }
+    w->own_stream = w->stream;
     // (ONE side stream per handle, created on first use and shared by its workspaces: HIP multiplexes streams onto a handful of
     // hardware queues -- 4 unless GPU_MAX_HW_QUEUES says otherwise -- and two workspaces whose main streams land on the same queue
     // run their launch sets one after the other.  Measured: with a side stream per workspace no more than two calls overlapped.)
-    for (hipEvent_t *e : {&w->ev_fork, &w->ev_join, &w->ev_pts, &w->ev_shift})
+    for (hipEvent_t *e : {&w->ev_fork, &w->ev_join, &w->ev_pts, &w->ev_shift, &w->ev_stage, &w->ev_done, &w->ev_fork2})
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; delete w; return nullptr; }
     bool ok = true;
     for (auto &e : w->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -395,8 +406,11 @@ int join_side(Workspace *w) {         // everything the side streams were given,
     if (w->side_pending) { w->side_pending = false; HIPCHK(hipStreamWaitEvent(w->stream, w->ev_join, 0)); }
     return KZG355_OK;
 }
+// after_challenge (submit / collect pipeline): called right after the Fiat-Shamir kernel is queued, which then goes FIRST -- the stage 2 of the
+// previously submitted set is queued from there, so that it runs beside this set's evaluation and point kernels and never beside the hash
 int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total,
-               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true, HostFront *hf = nullptr) {
+               int npg, uint8_t *d_records, G1Affine *d_pts, int *d_err, bool allow_preshift = true, HostFront *hf = nullptr,
+               const std::function<int()> *after_challenge = nullptr) {
     int rc;
     w->shift_ready = false;
     if ((rc = w->z.ensure(sizeof(Fr) * (size_t)n_total))) return rc;
@@ -410,9 +424,10 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     // (-> r powers) chain.  With many batches in flight every kernel fills the card on its own and sharing the SIMDs only slows the
     // challenge kernel's producer/consumer hand-off (measured per 65,536 blobs: 6.7 + 4.2 ms apart, 19 ms together: one-wave workgroups
     // of a latency-bound kernel land unevenly on SIMDs that another grid is filling).
-    if (n_total <= s->beside_max_blobs && ensure_side(s, w)) {
+    const bool beside = n_total <= s->beside_max_blobs && ensure_side(s, w);
+    if (beside) {
         if ((rc = enqueue_points_beside(s, w, tm, d_c, d_p, n_total, npg, d_pts, d_err, allow_preshift))) return rc;
-    } else {
+    } else if (!after_challenge) {
         tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end();
     }
     if (hf) {
@@ -424,6 +439,10 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(), d_records, w->stream); tm.end();
     } else {
         tm.begin("challenge"); launch_challenges(d_blobs, d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(), d_records, w->stream, s->challenge_form ? s->challenge_form : n_total <= s->challenge_two_wave_upto ? 2 : 1); tm.end();
+    }
+    if (after_challenge) {
+        if ((rc = (*after_challenge)())) return rc;
+        if (!beside) { tm.begin("validate_points"); launch_validate_points(d_c, d_p, n_total, npg, d_pts, d_err, w->stream); tm.end(); }
     }
     tm.begin("eval"); launch_eval(d_blobs, w->z.as<Fr>(), w->zpow.as<Fr>(), s->t, n_total, npg, nullptr, d_records, d_err, w->stream); tm.end();
     return KZG355_OK;
@@ -495,10 +514,10 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
 }
 
 // Enqueue one launch set on w->stream (no host synchronisation) ...
-int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
-                   size_t res_off = 0, size_t res_cap = 0, HostFront *hf = nullptr, bool lone_call = false) {
-    // res_off / res_cap: several launch sets queued on one workspace (stream order keeps the device scratch safe) park their
-    // verdicts at different offsets of the pinned result buffers, sized res_cap entries up front
+// res_off / res_cap: several launch sets queued on one workspace (stream order keeps the device scratch safe) park their
+// verdicts at different offsets of the pinned result buffers, sized res_cap entries up front
+int verify_enqueue_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
+                          size_t res_cap = 0, HostFront *hf = nullptr, const std::function<int()> *after_challenge = nullptr) {
     const int n_total = npg * G;
     int rc;
     if (res_cap < (size_t)G) res_cap = (size_t)G;
@@ -510,12 +529,21 @@ int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
     if ((rc = w->h_err.ensure(sizeof(int) * res_cap))) return rc;
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * (size_t)G, w->stream));
-    if ((rc = run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>(), true, hf))) return rc;
+    return run_stage1(s, w, tm, d_blobs, d_c, d_p, n_total, npg, w->records.as<uint8_t>(), w->pts.as<G1Affine>(), w->err.as<int>(), true, hf, after_challenge);
+}
+int verify_enqueue_stage2(kzg355_settings *s, Workspace *w, Timed &tm, int npg, int G, size_t res_off = 0, bool lone_call = false) {
+    int rc;
     if ((rc = run_stage2(s, w, tm, w->records.as<uint8_t>(), npg, G, 0, w->pts.as<G1Affine>(), w->err.as<int>(), w->ok.as<int>(), lone_call))) return rc;
     if ((rc = join_side(w))) return rc;                           // the subgroup verdicts, before the error words go back
     HIPCHK(hipMemcpyAsync(w->h_ok.as<int>() + res_off, w->ok.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.as<int>() + res_off, w->err.p, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, w->stream));
     return KZG355_OK;
+}
+int verify_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int npg, int G,
+                   size_t res_off = 0, size_t res_cap = 0, HostFront *hf = nullptr, bool lone_call = false) {
+    int rc = verify_enqueue_stage1(s, w, tm, d_blobs, d_c, d_p, npg, G, res_cap, hf);
+    if (rc) return rc;
+    return verify_enqueue_stage2(s, w, tm, npg, G, res_off, lone_call);
 }
 // ... and wait for it: verdicts / statuses of its G batches.  Returns the first non-OK status.
 int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G, size_t res_off = 0) {
@@ -914,6 +942,7 @@ void kzg355_options_from_env(kzg355_options *o) {
     if (const char *e = getenv("KZG355_LINCOMB")) o->lincomb_form = strcmp(e, "bucket") == 0 ? 2 : strcmp(e, "window") == 0 ? 1 : strcmp(e, "preshift") == 0 ? 3 : 0;
     if (const char *e = getenv("KZG355_EXCHANGE")) o->exchange = strcmp(e, "peer") == 0 ? 1 : strcmp(e, "rccl") == 0 ? 2 : 0;
     num("KZG355_VERIFY_ONLY", 0, 1, &o->verify_only);
+    if (const char *e = getenv("KZG355_SUBMIT")) o->submit_sets = strcmp(e, "sets") == 0 ? 1 : strcmp(e, "pipeline") == 0 ? 2 : 0;
 }
 // the caller's struct may be older (smaller) than this library's: fields beyond its struct_size keep their defaults
 static kzg355_options options_of(const kzg355_options *opt) {
@@ -1019,6 +1048,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (opt.split_streams >= 1 && opt.split_streams <= 8) s->split_streams = opt.split_streams;
     s->challenge_form = opt.challenge_form;
     s->lincomb_mode = opt.lincomb_form;
+    s->submit_mode = opt.submit_sets >= 0 && opt.submit_sets <= 2 ? opt.submit_sets : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (hipMemset(err.p, 0, sizeof(int)) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
@@ -1313,6 +1343,8 @@ static void free_single(kzg355_settings *s) {
     s->pool.clear();
     if (s->side_stream) { (void)hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
     if (s->side2_stream) { (void)hipStreamDestroy(s->side2_stream); s->side2_stream = nullptr; }
+    if (s->pipe_main) { (void)hipStreamDestroy(s->pipe_main); s->pipe_main = nullptr; }
+    if (s->pipe_tail) { (void)hipStreamDestroy(s->pipe_tail); s->pipe_tail = nullptr; }
     delete s->host_pool; s->host_pool = nullptr;
     s->roots.release(); s->eval_tab.release(); s->wide.release(); s->msm_table.release(); s->lines.release(); s->lines_inf.release(); s->g1_first2.release();
     s->lines_w.release(); s->frob.release(); s->prog.release(); s->scheds.release();
@@ -1374,6 +1406,130 @@ void kzg355_reset_kernel_stats(kzg355_settings *s) {
     if (!s) return;
     std::lock_guard<std::mutex> lk(s->mu);
     s->last_ms.clear();
+}
+
+// ---- asynchronous device-resident verification: submit / collect -----------------------------------------------------------------
+// One host thread keeps several launch sets in flight: submit() takes a workspace (its own stream and scratch) from the handle's pool,
+// queues the whole chain of a launch set on it without waiting and hands back a ticket; collect() waits for that set, writes its
+// verdicts and returns the workspace.  Sets submitted back to back sit on different streams, so the narrow tail of set k (r powers,
+// Horner chains, pairing: a few waves per SIMD at most) runs under the wide kernels of set k + 1 -- what a caller with mid-size sets
+// (1024 batches = 8.6 GB of blobs) needs instead of one 69 GB set.  The batch challenge stays on the device here (no host round trip
+// inside a chain that is one of several in flight).
+struct kzg355_ticket {
+    kzg355_settings *s = nullptr;
+    Workspace *w = nullptr;
+    std::unique_ptr<Timed> tm;
+    size_t npg = 0, groups = 0;
+    bool immediate = false;          // nothing was queued (groups == 0 or empty batches: kzg.rs:653-655)
+    bool tail_queued = false;        // stage 2 of this set is on the tail stream (else it is the handle's pending_tail)
+    int tail_rc = KZG355_OK;         // what queueing it returned
+};
+
+namespace {
+// Stage 2 of a submitted set, onto the handle's tail stream: behind the set's own stage 1 (ev_stage) and, when the next set's hash has just
+// been queued, behind that as well (after).  Called with s->pipe_mu held.
+int queue_tail(kzg355_ticket *t, hipEvent_t after) {
+    Workspace *w = t->w;
+    t->tail_queued = true;
+    w->stream = t->s->pipe_tail;
+    HIPCHK(hipStreamWaitEvent(w->stream, w->ev_stage, 0));
+    if (after) HIPCHK(hipStreamWaitEvent(w->stream, after, 0));
+    int rc = verify_enqueue_stage2(t->s, w, *t->tm, (int)t->npg, (int)t->groups);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(w->ev_done, w->stream));
+    return KZG355_OK;
+}
+}  // namespace
+
+int kzg355_verify_blob_kzg_proof_batch_many_device_submit(kzg355_ticket **ticket, const uint8_t *d_blobs, const uint8_t *d_commitments,
+                                                          const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *cs) {
+    if (!ticket || !cs) return KZG355_BADARGS;
+    *ticket = nullptr;
+    if (n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    std::unique_ptr<kzg355_ticket> t(new kzg355_ticket());
+    kzg355_settings *s = t->s = const_cast<kzg355_settings *>(cs);
+    t->npg = n_per_group; t->groups = groups;
+    if (groups == 0 || n_per_group == 0) { t->immediate = true; *ticket = t.release(); return KZG355_OK; }
+    if (!d_blobs || !d_commitments || !d_proofs || ((uintptr_t)d_blobs & 15) || ((uintptr_t)d_commitments & 3) || ((uintptr_t)d_proofs & 3)) return KZG355_BADARGS;
+    DeviceScope scope;
+    if (!scope.enter(s->device)) return KZG355_NO_DEVICE;
+    Workspace *w = t->w = ws_acquire(s);
+    if (!w) return KZG355_NO_DEVICE;
+    t->tm.reset(new Timed(s, w));
+    auto fail = [&](int rc) { w->quiesce(); ws_release(s, w); return rc; };
+    // Small sets (up to two launch sets' worth of the "point kernels beside the hash" regime: 512 batches of 64 on 256 CUs) are chains of
+    // kernels that leave most of the card idle: each on the stream of its own workspace, they simply overlap (measured, blobs/s with one /
+    // four sets in flight: 256 batches 1.54 -> 1.89 M, 512 batches 2.17 -> 2.80 M; the two-stage pipeline below: 1.86 M, 2.59 M).
+    if (s->submit_mode == 1 || (s->submit_mode == 0 && n_per_group * groups <= 2 * (size_t)s->beside_max_blobs)) {
+        int rc = verify_enqueue(s, w, *t->tm, d_blobs, d_commitments, d_proofs, (int)n_per_group, (int)groups);
+        if (rc == KZG355_OK && hipEventRecord(w->ev_done, w->stream) != hipSuccess) rc = KZG355_DEVICE_ERROR;
+        if (rc) return fail(rc);
+        t->tail_queued = true;
+        *ticket = t.release();
+        return KZG355_OK;
+    }
+    // Two-stage software pipeline.  Stage 1 of the submitted sets runs in submission order on ONE stream (two hash or evaluation kernels
+    // side by side gain nothing: each fills the card).  Stage 2 of set k goes to a second stream, and it is queued LATE: when set k + 1 is
+    // submitted, right behind that set's Fiat-Shamir kernel -- so it runs beside the evaluation and point kernels of set k + 1 and never
+    // beside the hash, whose 11 KB loop the instruction streams of the point-arithmetic kernels evict from the instruction cache
+    // (measured, profiles/r04/pipeline_sweep.txt: hash 5.9 -> 12.3 ms next to the bucket kernel, a step slower than the two in a row) --
+    // or when set k is collected, whichever comes first.
+    std::lock_guard<std::mutex> lk(s->pipe_mu);
+    if (!s->pipe_main) {
+        if (hipStreamCreateWithFlags(&s->pipe_main, hipStreamNonBlocking) != hipSuccess) { s->pipe_main = nullptr; (void)hipGetLastError(); return fail(KZG355_DEVICE_ERROR); }
+        if (hipStreamCreateWithFlags(&s->pipe_tail, hipStreamNonBlocking) != hipSuccess) { s->pipe_tail = nullptr; (void)hipGetLastError(); return fail(KZG355_DEVICE_ERROR); }
+    }
+    w->stream = s->pipe_main; w->borrowed[0] = s->pipe_main; w->borrowed[1] = s->pipe_tail;
+    kzg355_ticket *prev = s->pending_tail;
+    const std::function<int()> after_challenge = [&]() -> int {
+        if (!prev) return KZG355_OK;
+        s->pending_tail = nullptr;
+        HIPCHK(hipEventRecord(w->ev_fork2, w->stream));           // this set's hash is queued up to here
+        prev->tail_rc = queue_tail(prev, w->ev_fork2);            // (a failure is reported when that set is collected)
+        return KZG355_OK;
+    };
+    int rc = verify_enqueue_stage1(s, w, *t->tm, d_blobs, d_commitments, d_proofs, (int)n_per_group, (int)groups, 0, nullptr, &after_challenge);
+    if (rc == KZG355_OK && hipEventRecord(w->ev_stage, w->stream) != hipSuccess) rc = KZG355_DEVICE_ERROR;
+    if (rc) {
+        if (s->pending_tail == prev && prev) { s->pending_tail = nullptr; prev->tail_rc = queue_tail(prev, nullptr); }   // the earlier set must not wait for a set that never came
+        return fail(rc);
+    }
+    s->pending_tail = t.get();
+    *ticket = t.release();
+    return KZG355_OK;
+}
+
+int kzg355_verify_collect(kzg355_ticket *ticket, bool *ok, int *status) {
+    if (!ticket) return KZG355_BADARGS;
+    std::unique_ptr<kzg355_ticket> t(ticket);                    // the ticket is consumed whatever happens
+    if (t->immediate) {
+        if (!ok && t->groups) return KZG355_BADARGS;
+        for (size_t g = 0; g < t->groups; g++) { ok[g] = true; if (status) status[g] = KZG355_OK; }
+        return KZG355_OK;
+    }
+    kzg355_settings *s = t->s; Workspace *w = t->w;
+    DeviceScope scope;
+    const bool entered = scope.enter(s->device);
+    int rc = !entered ? KZG355_NO_DEVICE : KZG355_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->pipe_mu);
+        if (s->pending_tail == t.get()) {                         // no later set came: stage 2 goes out now
+            s->pending_tail = nullptr;
+            if (rc == KZG355_OK) t->tail_rc = queue_tail(t.get(), nullptr);
+        }
+    }
+    if (rc == KZG355_OK) rc = t->tail_rc;
+    if (rc == KZG355_OK && !ok) rc = KZG355_BADARGS;
+    if (rc == KZG355_OK && w->borrowed[0]) {
+        // the set sits on the handle's shared pipeline streams: wait for ITS end (later sets may be queued behind it), then hand the
+        // workspace its own stream back, so that verify_collect's stream wait returns at once
+        if (hipEventSynchronize(w->ev_done) != hipSuccess) rc = KZG355_DEVICE_ERROR;
+        else { w->borrowed[0] = w->borrowed[1] = nullptr; w->stream = w->own_stream; }
+    }
+    if (rc == KZG355_OK) rc = verify_collect(w, *t->tm, ok, status, (int)t->groups);
+    w->quiesce();
+    ws_release(s, w);
+    return rc;
 }
 
 // ---- device-resident entry points ---------------------------------------------------------------------

@@ -47,6 +47,7 @@ pub struct kzg355_options {
     pub staging_ring: c_int,
     pub exchange: c_int,
     pub verify_only: c_int,
+    pub submit_sets: c_int,
 }
 
 extern "C" {

@@ -900,6 +900,62 @@ def test_overlapped_launch_sets_keep_order(kz, setup_bytes, random_set):
         s.free()
 
 
+def test_submit_collect_keeps_sets_apart(kz, settings, random_set):
+    """kzg355_verify_blob_kzg_proof_batch_many_device_submit / kzg355_verify_collect: one thread keeps four launch sets in flight on four
+    streams of the handle (sets of 5, 3, 1 and 4 batches with a false verdict, an Err and an honest set among them) and collects them out of
+    order: every verdict and status lands at its set's batch index; an empty set and a zero-blob set answer without a device; a misaligned
+    pointer is refused at submit; the synchronous call agrees with the collected verdicts."""
+    import torch
+    blobs, cs, ps = random_set
+    n = len(blobs)
+    L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
+    sizes = [5, 3, 1, 4]
+    sets = []
+    for k, G in enumerate(sizes):
+        P = [list(ps) for _ in range(G)]; Cc = [list(cs) for _ in range(G)]
+        expect_ok, expect_st = [True] * G, [0] * G
+        if k == 0:
+            P[3][0], P[3][1] = P[3][1], P[3][0]; expect_ok[3] = False
+        if k == 1:
+            Cc[2][5] = bytes([0x9a]) + b"\xff" * 47; expect_st[2] = 1
+        if k == 3:
+            P[0][6], P[0][7] = P[0][7], P[0][6]; expect_ok[0] = False
+        tb = torch.frombuffer(bytearray(b"".join(blobs) * G), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(b"".join(b"".join(c) for c in Cc)), dtype=torch.uint8).to(dev)
+        tp = torch.frombuffer(bytearray(b"".join(b"".join(p) for p in P)), dtype=torch.uint8).to(dev)
+        sets.append((G, tb, tc, tp, expect_ok, expect_st))
+    torch.cuda.synchronize()
+    tickets = []
+    for G, tb, tc, tp, _, _ in sets:
+        tk = C.c_void_p()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle) == 0
+        assert tk.value
+        tickets.append(tk)
+    for k in (2, 0, 3, 1):                                                    # out of order
+        G, tb, tc, tp, expect_ok, expect_st = sets[k]
+        ok = (C.c_bool * G)(); st = (C.c_int * G)()
+        rc = L.kzg355_verify_collect(tickets[k], ok, st)
+        assert rc == (1 if any(expect_st) else 0), (k, rc)
+        assert [st[g] for g in range(G)] == expect_st, k
+        assert [ok[g] for g in range(G) if not expect_st[g]] == [e for e, f in zip(expect_ok, expect_st) if not f], k
+        ok2 = (C.c_bool * G)(); st2 = (C.c_int * G)()
+        L.kzg355_verify_blob_kzg_proof_batch_many_device(ok2, st2, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle)
+        assert list(st2) == list(st) and [ok2[g] for g in range(G) if not st[g]] == [ok[g] for g in range(G) if not st[g]]
+    # nothing to queue: no batches, or batches of no blobs (kzg.rs:653-655: Ok(true))
+    G, tb, tc, tp, _, _ = sets[0]
+    tk = C.c_void_p()
+    assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), None, None, None, 0, 3, settings.handle) == 0
+    ok = (C.c_bool * 3)(); st = (C.c_int * 3)(7, 7, 7)
+    assert L.kzg355_verify_collect(tk, ok, st) == 0 and list(ok) == [True] * 3 and list(st) == [0] * 3
+    tk = C.c_void_p()
+    assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 0, settings.handle) == 0
+    assert L.kzg355_verify_collect(tk, None, None) == 0
+    tk = C.c_void_p()
+    assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr() + 4, tc.data_ptr(), tp.data_ptr(), n, G, settings.handle) == 1
+    assert not tk.value
+    assert L.kzg355_verify_collect(None, ok, st) == 1
+
+
 def test_device_entry_points_refuse_misaligned_pointers(kz, settings, random_set):
     """The device-resident entry points read blobs and records 16 bytes at a time: a pointer that is not 16-byte aligned is BadArgs,
     not a faulting kernel."""
