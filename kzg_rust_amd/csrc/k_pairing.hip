@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(128) k_pairing_coop2(const PairPt *pair_pts, i
     const LineW *lines1 = lines_w + 2 * N_LINES, *lines2 = lines_w;      // lines_w[2] = setup g2[1] = [tau]G2 ; lines_w[0] = G2 generator
     coop_init(m, scheds, p1, p2);
 #pragma unroll 1
-    for (int item = threadIdx.x; item < 2 * N_LINES * 6; item += 128) coop_eval_lines_item(pre, item, lines1, lines2, p1, p2);
+    for (int item = threadIdx.x; item < 2 * N_LINES * 6; item += 128) coop_eval_lines_item(pre, item, lines1, lines2, pair_pts + 2 * (size_t)g);
     __syncthreads();
     coop_run(m, prog, 0, COOP_MILLER_INSNS, lines1, lines2, wid == 0 && use1, wid == 1 && use2, *frob, pre);
     __syncthreads();                                              // both waves reach this; wave 1 is done afterwards

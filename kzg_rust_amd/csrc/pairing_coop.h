@@ -451,28 +451,78 @@ KZG_HD bool coop_is_one(CoopMem &m, const Fp12W &a) {
     COOP_SYNC();
     return m.flag != 0;
 }
-// In-place inverse of an Fp6 element stored in the w basis (even powers of w only; the odd coefficients are zero):
-// a short single-lane tower computation.  With N = a * conj(a) in Fp6 this gives a^-1 = conj(a) * N^-1.
-KZG_HD void coop_fp6_inv(Fp12W &x) {
+// In-place inverse of an Fp6 element stored in the w basis (even powers of w only; the odd coefficients are zero).  With
+// N = a * conj(a) in Fp6 this gives a^-1 = conj(a) * N^-1.  Round 4: cooperative -- the ~40 base-field products of the tower formulas
+//     A = a0^2 - xi a1 a2,  B = xi a2^2 - a0 a1,  C = a1^2 - a0 a2,  D = a0 A + xi (a2 B + a1 C),  a^-1 = (A, B, C) / D      (xi = 1 + u)
+// are five stages of independent products, one per lane (schoolbook Fp2 products: x0 y0, x1 y1, x0 y1, x1 y0 on four lanes), with the
+// sums in between on a few lanes; only the one Fp inversion (divsteps, ~25k instructions) stays on a single lane.  Operands and results
+// live in LDS (V: 24 scratch values in two free Fp12 slots; m.red: the products), nothing on the private stack -- the single-lane tower
+// version kept two Fp6 and a dozen Fp2 temporaries in scratch memory and took 0.19 of the 1.38 ms of a lone pairing check.
+// red[l] = V[ia[l]] * V[ib[l]] for l < n
+KZG_HD void coop_fp_products(CoopMem &m, const Fp *V, int n, const uint8_t *ia, const uint8_t *ib) {
+    COOP_LANES(lane) { if (lane < n) fp_mul(m.red[lane], V[ia[lane]], V[ib[lane]]); }
+    COOP_SYNC();
+}
+// dst[l] = sum of +red[t - 1] / -red[-t - 1] over row l of tab (0 ends a row; an empty row gives 0) for l < n; canonical in, canonical out
+constexpr int COOP_LIN_W = 10;
+KZG_HD void coop_fp_lincomb(CoopMem &m, Fp *dst, int n, const int8_t (*tab)[COOP_LIN_W]) {
     COOP_LANES(lane) {
-        if (lane == 0) {
-            Fp6 n, ni;
-            Fp2 *nc[3] = {&n.c0, &n.c1, &n.c2};
-            for (int j = 0; j < 3; j++) {              // (x0 + x1 u) v^j  <-  w^(2j): x0 - x1, w^(2j+6): x1   (lazy -> canonical first)
-                Fp lo, hi; fp_norm_lz(lo, x.c[2 * j]); fp_canon64(lo, lo); fp_norm_lz(hi, x.c[2 * j + 6]); fp_canon64(hi, hi);
-                nc[j]->c1 = hi;
-                fp_add(nc[j]->c0, lo, hi);
+        if (lane < n) {
+            Fp acc = fp_zero();
+            for (int i = 0; i < COOP_LIN_W; i++) {
+                const int t = tab[lane][i];
+                if (!t) break;
+                if (t > 0) fp_add(acc, acc, m.red[t - 1]); else fp_sub(acc, acc, m.red[-t - 1]);
             }
-            fp6_inv(ni, n);
-            const Fp2 *ic[3] = {&ni.c0, &ni.c1, &ni.c2};
-            for (int k = 0; k < 12; k++) x.c[k] = fp_zero();
-            for (int j = 0; j < 3; j++) {
-                fp_sub(x.c[2 * j], ic[j]->c0, ic[j]->c1);
-                x.c[2 * j + 6] = ic[j]->c1;
-            }
+            dst[lane] = acc;
         }
     }
     COOP_SYNC();
+}
+// V: 24 Fp of scratch (two Fp12 slots the program does not hold anything in at this point)
+KZG_HD void coop_fp6_inv(CoopMem &m, Fp12W &x, Fp *V) {
+    // the Fp2 product of operands at V[x], V[x + 1] and V[y], V[y + 1]: products x0 y0, x1 y1, x0 y1, x1 y0 on four lanes; with them at
+    // red[4k .. 4k + 3] the result is (r0 - r1, r2 + r3)
+#define KZG_FP2P_A(x, y) x, x + 1, x, x + 1
+#define KZG_FP2P_B(x, y) y, y + 1, y + 1, y
+    // V[0..5] = a0, a1, a2 (c0, c1 each); V[6..11] = A, B, C; V[12..13] = D; V[14] = 1 / (D0^2 + D1^2); V[15..16] = 1 / D
+    static const uint8_t s1a[24] = {KZG_FP2P_A(0, 0), KZG_FP2P_A(2, 4), KZG_FP2P_A(4, 4), KZG_FP2P_A(0, 2), KZG_FP2P_A(2, 2), KZG_FP2P_A(0, 4)};
+    static const uint8_t s1b[24] = {KZG_FP2P_B(0, 0), KZG_FP2P_B(2, 4), KZG_FP2P_B(4, 4), KZG_FP2P_B(0, 2), KZG_FP2P_B(2, 2), KZG_FP2P_B(0, 4)};
+    static const uint8_t s3a[12] = {KZG_FP2P_A(0, 6), KZG_FP2P_A(4, 8), KZG_FP2P_A(2, 10)};
+    static const uint8_t s3b[12] = {KZG_FP2P_B(0, 6), KZG_FP2P_B(4, 8), KZG_FP2P_B(2, 10)};
+    static const uint8_t s5a[2] = {12, 13}, s5b[2] = {12, 13};
+    static const uint8_t s7a[2] = {12, 13}, s7b[2] = {14, 14};
+    static const uint8_t s8a[12] = {KZG_FP2P_A(6, 15), KZG_FP2P_A(8, 15), KZG_FP2P_A(10, 15)};
+    static const uint8_t s8b[12] = {KZG_FP2P_B(6, 15), KZG_FP2P_B(8, 15), KZG_FP2P_B(10, 15)};
+#undef KZG_FP2P_A
+#undef KZG_FP2P_B
+    // rows are 1-based indices into red, signed.  With P_k = (r[4k] - r[4k+1], r[4k+2] + r[4k+3]) and xi (m0, m1) = (m0 - m1, m0 + m1):
+    static const int8_t l0[6][COOP_LIN_W] = {{1, 2}, {2}, {3, 4}, {4}, {5, 6}, {6}};                                  // a_j = (lo + hi, hi) from w^(2j), w^(2j+6)
+    static const int8_t l2[6][COOP_LIN_W] = {{1, -2, -5, 6, 7, 8}, {3, 4, -5, 6, -7, -8},                            // A = P0 - xi P1
+                                             {9, -10, -11, -12, -13, 14}, {9, -10, 11, 12, -15, -16},                // B = xi P2 - P3
+                                             {17, -18, -21, 22}, {19, 20, -23, -24}};                                // C = P4 - P5
+    static const int8_t l4[2][COOP_LIN_W] = {{1, -2, 5, -6, 9, -10, -7, -8, -11, -12}, {3, 4, 5, -6, 9, -10, 7, 8, 11, 12}};   // D = Q0 + xi (Q1 + Q2)
+    static const int8_t l7[2][COOP_LIN_W] = {{1}, {-2}};                                                               // 1 / D = (D0, -D1) / (D0^2 + D1^2)
+    static const int8_t l9[12][COOP_LIN_W] = {{1, -2, -3, -4}, {0}, {5, -6, -7, -8}, {0}, {9, -10, -11, -12}, {0},     // w^(2j): r0 - r1
+                                              {3, 4}, {0}, {7, 8}, {0}, {11, 12}, {0}};                                // w^(2j+6): r1
+    COOP_LANES(lane) {      // lazy -> canonical: (lo_0, hi_0, lo_1, hi_1, lo_2, hi_2) = coefficients 0, 6, 2, 8, 4, 10
+        if (lane < 6) { Fp c; fp_norm_lz(c, x.c[2 * (lane >> 1) + 6 * (lane & 1)]); fp_canon64(c, c); m.red[lane] = c; }
+    }
+    COOP_SYNC();
+    coop_fp_lincomb(m, V, 6, l0);
+    coop_fp_products(m, V, 24, s1a, s1b);
+    coop_fp_lincomb(m, V + 6, 6, l2);
+    coop_fp_products(m, V, 12, s3a, s3b);
+    coop_fp_lincomb(m, V + 12, 2, l4);
+    coop_fp_products(m, V, 2, s5a, s5b);
+    COOP_LANES(lane) {
+        if (lane == 0) { Fp n; fp_add(n, m.red[0], m.red[1]); fp_inv(n, n); V[14] = n; }
+    }
+    COOP_SYNC();
+    coop_fp_products(m, V, 2, s7a, s7b);
+    coop_fp_lincomb(m, V + 15, 2, l7);
+    coop_fp_products(m, V, 12, s8a, s8b);
+    coop_fp_lincomb(m, x.c, 12, l9);
 }
 
 struct FrobTables { Fp a1[12], b1[12], a2[12]; };     // power-1 tables and the power-2 table (its g1 part is zero)
@@ -494,6 +544,7 @@ enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_
 struct CoopInsn { uint8_t op, dst, a, b; };
 enum : uint8_t { S_F = 0, S_T0 = 1, S_T1 = 2, S_T2 = 3, S_T3 = 4, S_T4 = 5, S_L0 = 6, S_L1 = 7 };
 constexpr int COOP_PROGRAM_MAX = 1024;
+constexpr int COOP_LINE_CHUNK = 5;       // line steps evaluated at once inside the Miller loop: 5 steps x 2 pairs x 6 coefficients = 60 lanes, 60 Fp = the slots t0 .. t4
 
 inline int build_pairing_program(CoopInsn *p) {
     int n = 0;
@@ -576,7 +627,9 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
             const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2);
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
-            const Fp *bs = (pre && mask == LINE_MASK) ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6 : nullptr;      // straight from the evaluations made ahead
+            const Fp *bs = mask != LINE_MASK ? nullptr                                     // the line as its six evaluated coefficients:
+                           : pre ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6      // all made ahead of the loop (two-wave kernel)
+                                 : m.t0.c + ((cur_line % COOP_LINE_CHUNK) * 2 + (in.op == OP_MUL_LINE1 ? 1 : 0)) * 6;      // or five steps at a time (OP_LINE_EVAL)
             if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask, bs);
             continue;
         }
@@ -586,16 +639,19 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             case OP_CYC_SQR: coop_cyc_sqr(m, dst, a); break;
             case OP_LINE_EVAL: {
                 const int n = in.a;
-                if (pre) { cur_line = n; break; }          // evaluated ahead of the loop: the line products read them in place
-                COOP_LANES(lane) {                          // evaluate both lines at their points, scaled by Z^3: 12 products on 12 lanes,
-                    if (lane < 12) {                        // ONE product body for all of them (operands picked per lane, no divergent arms)
-                        const int q = lane / 6, e = lane % 6;
-                        const LineW &L = q == 0 ? lines1[n] : lines2[n];
+                cur_line = n;
+                if (pre) break;                             // evaluated ahead of the loop: the line products read them in place
+                if (n % COOP_LINE_CHUNK) break;             // this line is in the chunk evaluated COOP_LINE_CHUNK - 1 .. 1 steps ago
+                // Evaluate the lines of the next five steps of BOTH pairs at their points in one go, scaled by Z^3: 60 products on 60 lanes,
+                // ONE product body (operands picked per lane).  Line by line it was 12 lanes of 64 at work 68 times per check; now 14 times.
+                // The evaluations park in the slots t0 .. t4, which the program only uses after the Miller loop ([step][pair][6 coefficients]).
+                COOP_LANES(lane) {
+                    const int c = lane / 12, q = (lane % 12) / 6, e = lane % 6;
+                    if (c < COOP_LINE_CHUNK && n + c < N_LINES) {
+                        const LineW &L = q == 0 ? lines1[n + c] : lines2[n + c];
                         const Fp *coef = &L.l0 + e;                                         // l0, l6, l2, l8, l3, l9
                         const Fp *arg = e < 2 ? &m.pz[q] : e < 4 ? &m.px[q] : &m.py[q];     // * Z^3, Z^3, X Z, X Z, Y, Y
-                        const int dst_k = e == 0 ? 0 : e == 1 ? 6 : e == 2 ? 2 : e == 3 ? 8 : e == 4 ? 3 : 9;
-                        Fp v; fp_mul(v, *coef, *arg);
-                        m.line[q].c[dst_k] = v;
+                        fp_mul(m.t0.c[lane], *coef, *arg);                                  // straight into LDS: no temporary on the private stack
                     }
                 }
                 COOP_SYNC();
@@ -604,7 +660,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             case OP_CONJ: coop_conj(dst, a); break;
             case OP_FROB1: coop_frob(dst, a, ft.a1, ft.b1); break;
             case OP_FROB2: coop_frob2(dst, a, ft.a2); break;
-            case OP_FP6INV: coop_fp6_inv(dst); break;
+            case OP_FP6INV: coop_fp6_inv(m, dst, m.t2.c); break;        // (t2, t3: free at this point of the program -- build_pairing_program)
             default: coop_copy(dst, a); break;
         }
     }
@@ -612,14 +668,14 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
 // All 2 x 68 line evaluations at once, ahead of the Miller loop (they depend on the points only; inside the loop each one is a
 // dependent ~650-instruction step): item (q, n, e) = coefficient e of line n of pair q times its argument, items dealt to `nthreads`
 // threads.  out: [2][N_LINES][6].
-KZG_HD void coop_eval_lines_item(Fp *out, int item, const LineW *lines1, const LineW *lines2, const PairPt &p1, const PairPt &p2) {
+// pts: the two G1 arguments where they lie in memory (an address computed per lane into a by-value copy would put the copy on the private stack)
+KZG_HD void coop_eval_lines_item(Fp *out, int item, const LineW *lines1, const LineW *lines2, const PairPt *pts) {
     const int q = item / (N_LINES * 6), n = (item / 6) % N_LINES, e = item % 6;
     const LineW &L = q == 0 ? lines1[n] : lines2[n];
-    const PairPt &P = q == 0 ? p1 : p2;
+    const PairPt &P = pts[q];
     const Fp *coef = &L.l0 + e;                                         // l0, l6, l2, l8, l3, l9
     const Fp *arg = e < 2 ? &P.az : e < 4 ? &P.ax : &P.ay;              // * Z^3, Z^3, X Z, X Z, Y, Y
-    Fp v; fp_mul(v, *coef, *arg);
-    out[item] = v;
+    fp_mul(out[item], *coef, *arg);
 }
 // p1 / p2 = (0,0) (infinity) makes that pair contribute 1.
 KZG_HD bool coop_pairing_check(CoopMem &m, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, const LineW *lines1, const G1Affine &p1,

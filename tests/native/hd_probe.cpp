@@ -266,7 +266,8 @@ int hd_pairings_verify_coop_proj(int *ok, const uint8_t *p1, const uint8_t *q1, 
     coop_init(*m0, &sc, pa, pb); coop_init(*m1, &sc, pa, pb);
     // the line evaluations made ahead of the loops, as k_pairing_coop2 does (odd zsel: inside the loop, the single-wave kernel's way)
     std::vector<Fp> pre(2 * N_LINES * 6);
-    for (int item = 0; item < 2 * N_LINES * 6; item++) coop_eval_lines_item(pre.data(), item, w1.data(), w2.data(), pa, pb);
+    const PairPt pab[2] = {pa, pb};
+    for (int item = 0; item < 2 * N_LINES * 6; item++) coop_eval_lines_item(pre.data(), item, w1.data(), w2.data(), pab);
     const Fp *prep = (zsel & 1) ? nullptr : pre.data();
     coop_run(*m0, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), use1, false, ft, prep);
     coop_run(*m1, prog, 0, COOP_MILLER_INSNS, w1.data(), w2.data(), false, use2, ft, prep);
