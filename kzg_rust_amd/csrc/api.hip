@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -34,6 +35,13 @@ using namespace kzg;
             return _e == hipErrorOutOfMemory ? KZG355_NO_MEMORY : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? KZG355_NO_DEVICE : KZG355_DEVICE_ERROR; \
         }                                                                                              \
     } while (0)
+
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue run one
+// after the other.  A small call of this library is a chain on three streams, so the default lets one such call run at full speed and
+// serialises the streams of concurrent ones (threads of n = 64 calls on one handle, median ms per call at 1 / 2 / 4 / 8 threads: 2.2 / 3.0 / 5.0 / 6.9
+// with 4 queues, 2.2 / 2.3 / 2.9 / 3.3 with 24; profiles/r04/concurrent_small_calls.txt).  Unless the process has set the variable itself, ask
+// for 24 -- effective when this library is loaded before the process's first HIP call.
+__attribute__((constructor)) static void kzg355_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 namespace {
 
@@ -83,6 +91,7 @@ struct Workspace {
     hipEvent_t ev[32];
     bool ev_ok = false;
     bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
+    bool owns_side = false, owns_side2 = false;
     hipStream_t borrowed[2] = {nullptr, nullptr};   // the handle's pipeline streams while a submitted set of this workspace is on them
     // Wait for everything this workspace has in flight (a call that fails midway must not hand a busy workspace back to the pool).
     void quiesce() {
@@ -101,7 +110,9 @@ struct Workspace {
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift, ev_stage, ev_done, ev_fork2}) if (e) (void)hipEventDestroy(e);
-        if (own_stream) (void)hipStreamDestroy(own_stream);       // (side is the handle's shared stream: not owned)
+        if (own_stream) (void)hipStreamDestroy(own_stream);       // (side is the handle's shared stream unless owns_side)
+        if (owns_side && side) (void)hipStreamDestroy(side);
+        if (owns_side2 && side2) (void)hipStreamDestroy(side2);
     }
 };
 
@@ -110,42 +121,41 @@ struct Workspace {
 // Host worker threads of a handle.  Two users: the Fiat-Shamir hashing of small host-buffer calls (host_sha256.h; the blobs of such
 // a call are hashed here while its H2D copy and point kernels run) and the parallel copy into pinned staging buffers
 // (KZG355_STAGING=ring: a single memcpy stream moves ~10 GB/s, a PCIe 5 x16 link ~55 GB/s).  A job is a range of indices dealt out
-// through an atomic counter; the calling thread takes indices too.  One job at a time: try_begin() fails while another call's job is
-// running (the caller then takes its other route -- the device hash), begin() waits.
+// through an atomic counter; the thread that began it takes indices too.  Several jobs run at once (round 4: one job object per call on
+// the shared workers -- round 3 had one slot per handle, and the second of two simultaneous small calls fell back to the 3.7 ms
+// device hash): the workers drain the oldest job that still has indices to hand out, every caller works on its own.
 class HostPool {
+public:
     struct Job {
         std::function<void(size_t)> fn;
         size_t count = 0;
         std::atomic<size_t> next{0}, left{0};
     };
-public:
     explicit HostPool(int workers) {
         for (int i = 0; i < workers; i++) th_.emplace_back([this] { run(); });
     }
     ~HostPool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
     int workers() const { return (int)th_.size(); }
-    bool try_begin(size_t count, std::function<void(size_t)> fn) {
-        if (!call_mu_.try_lock()) return false;
-        start(count, std::move(fn));
-        return true;
-    }
-    void begin(size_t count, std::function<void(size_t)> fn) { call_mu_.lock(); start(count, std::move(fn)); }
-    // the caller works through what is left of the job it began, then waits for the indices still in other hands
-    void finish() {
-        std::shared_ptr<Job> j = cur_;
-        work(*j);
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            done_.wait(lk, [&] { return j->left.load() == 0; });
-            cur_.reset();
+    std::shared_ptr<Job> begin(size_t count, std::function<void(size_t)> fn) {
+        auto j = std::make_shared<Job>();
+        j->fn = std::move(fn); j->count = count; j->left = count;
+        if (count && !th_.empty()) {
+            { std::lock_guard<std::mutex> lk(mu_); open_.push_back(j); }
+            cv_.notify_all();
         }
-        call_mu_.unlock();
+        return j;
     }
-    void parallel_for(size_t count, std::function<void(size_t)> fn) { begin(count, std::move(fn)); finish(); }
+    // the caller works through what is left of the job it began, then waits for the indices still in other hands
+    void finish(const std::shared_ptr<Job> &j) {
+        work(*j);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return j->left.load() == 0; });
+    }
+    void parallel_for(size_t count, std::function<void(size_t)> fn) { finish(begin(count, std::move(fn))); }
     void copy(void *dst, const void *src, size_t bytes) {
         if (th_.empty() || bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
         const size_t parts = th_.size() + 1, per = ((bytes / parts) + 65535) & ~(size_t)65535;     // 64 KiB-granular slices
@@ -155,12 +165,6 @@ public:
         });
     }
 private:
-    void start(size_t count, std::function<void(size_t)> fn) {
-        auto j = std::make_shared<Job>();
-        j->fn = std::move(fn); j->count = count; j->left = count;
-        { std::lock_guard<std::mutex> lk(mu_); cur_ = j; gen_++; }
-        if (count) cv_.notify_all();
-    }
     void work(Job &j) {
         for (;;) {
             const size_t i = j.next.fetch_add(1);
@@ -170,24 +174,26 @@ private:
         }
     }
     void run() {
-        unsigned long seen = 0;
         for (;;) {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                for (;;) {
+                    while (!open_.empty() && open_.front()->next.load() >= open_.front()->count) open_.pop_front();   // every index handed out
+                    if (stop_ || !open_.empty()) break;
+                    cv_.wait(lk);
+                }
                 if (stop_) return;
-                j = cur_;
+                j = open_.front();
             }
-            if (j) work(*j);
+            work(*j);
         }
     }
     std::vector<std::thread> th_;
-    std::mutex mu_, call_mu_;
+    std::mutex mu_;
     std::condition_variable cv_, done_;
-    std::shared_ptr<Job> cur_;
-    unsigned long gen_ = 0; bool stop_ = false;
+    std::deque<std::shared_ptr<Job>> open_;      // jobs that may still have indices to hand out, oldest first
+    bool stop_ = false;
 };
 
 struct MultiDev;
@@ -211,6 +217,10 @@ struct kzg355_settings {
     hipStream_t pipe_main = nullptr, pipe_tail = nullptr;         // submit / collect: stage 1 of every submitted set in order on pipe_main, stage 2 on pipe_tail
     std::mutex pipe_mu;                                           // orders the submits / collects that queue work on the two
     struct kzg355_ticket *pending_tail = nullptr;                 // the submitted set whose stage 2 is not queued yet (it goes out behind the next set's hash)
+    bool own_side_streams = true;    // side streams per workspace (round 4; KZG355_SIDE=shared: one pair per handle, round 3's form) -- measured with
+                                     // 4 threads of n = 64 calls: median call 5.0-7.9 ms shared, 3.6-5.2 ms own (4 hardware queues), 2.5-3.9 ms own with 8 queues
+    std::atomic<int> calls_in_flight{0};   // host-buffer calls inside host_pipeline right now
+    int hw_queues = 4;                     // GPU_MAX_HW_QUEUES as the process has it (the runtime's default is 4; kzg355_runtime_defaults asks for 24)
     int submit_mode = 0;             // 0 by size; 1: every submitted set on its workspace's own stream; 2: two-stage software pipeline over pipe_main / pipe_tail (KZG355_SUBMIT=sets|pipeline)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
     int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v4.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
@@ -307,6 +317,11 @@ struct Timed {
 
 // the handle's shared side stream, created on first use
 bool ensure_side(kzg355_settings *s, Workspace *w) {
+    if (!w->side && s->own_side_streams) {
+        if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) { w->side = nullptr; (void)hipGetLastError(); }
+        else w->owns_side = true;
+        if (w->side) return true;                                  // (else: fall back to the handle's shared stream)
+    }
     if (!w->side) {
         std::lock_guard<std::mutex> lk(s->mu);
         if (!s->side_stream && hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking) != hipSuccess) { s->side_stream = nullptr; (void)hipGetLastError(); }
@@ -315,6 +330,15 @@ bool ensure_side(kzg355_settings *s, Workspace *w) {
     return w->side != nullptr;
 }
 bool ensure_side2(kzg355_settings *s, Workspace *w) {
+    // More calls in flight on the handle than a third of the runtime's hardware queues: the window shifts follow the decoding on the first
+    // side stream (enqueue_points_beside's one-side-stream form: +0.4 ms on the call's critical path) -- two streams that share a queue run
+    // one after the other whatever their calls are, and a call whose main chain waits behind another call's side work loses milliseconds.
+    if (!w->side2 && s->calls_in_flight.load() * 3 > s->hw_queues) return false;
+    if (!w->side2 && s->own_side_streams) {
+        if (hipStreamCreateWithFlags(&w->side2, hipStreamNonBlocking) != hipSuccess) { w->side2 = nullptr; (void)hipGetLastError(); }
+        else w->owns_side2 = true;
+        if (w->side2) return true;
+    }
     if (!w->side2) {
         std::lock_guard<std::mutex> lk(s->mu);
         if (!s->side2_stream && hipStreamCreateWithFlags(&s->side2_stream, hipStreamNonBlocking) != hipSuccess) { s->side2_stream = nullptr; (void)hipGetLastError(); }
@@ -348,10 +372,11 @@ int status_from_err(int err) {
 // thread takes what is left); the destructor does the same on every error path -- the job reads caller memory.
 struct HostFront {
     HostPool *pool = nullptr;
+    std::shared_ptr<HostPool::Job> job;
     const uint8_t *h_blobs = nullptr;   // the call's blobs in caller memory: copied to the device AFTER the point kernels are queued
     size_t bytes = 0;
     bool running = false;
-    void finish() { if (running) { running = false; pool->finish(); } }
+    void finish() { if (running) { running = false; pool->finish(job); job.reset(); } }
     ~HostFront() { finish(); }
 };
 
@@ -370,7 +395,7 @@ int enqueue_points_beside(kzg355_settings *s, Workspace *w, Timed &tm, const uin
     bool shift_on_side2 = false;
     if (pre) {
         if ((rc = w->shifts.ensure(lincomb_preshift_bytes(npg, n_total / npg)))) return rc;
-        if (ensure_side2(s, w)) {
+        if (s->calls_in_flight.load() * 3 <= s->hw_queues && ensure_side2(s, w)) {
             HIPCHK(hipStreamWaitEvent(w->side2, w->ev_fork, 0));
             w->shift_pending = true;
             tm.begin("lincomb_shift", w->side2); launch_lincomb_preshift_bytes(d_c, d_p, stride, npg, n_total / npg, w->shifts.as<G1Jac>(), w->side2); tm.end(w->side2);
@@ -759,6 +784,7 @@ struct HostCall {
 };
 int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
+    struct InFlight { std::atomic<int> &n; InFlight(std::atomic<int> &c) : n(c) { n++; } ~InFlight() { n--; } } in_flight(s->calls_in_flight);
     const size_t BB = blob_bytes_of(cs);
     const size_t unit_bytes = BB * hc.npg;
     size_t upc = s->chunk_bytes / unit_bytes;                                       // units per full-size chunk
@@ -833,7 +859,8 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
             const uint8_t *hb = hc.blobs + BB * off, *hcm = hc.commitments + 48 * off;
             const uint64_t n_fe = (uint64_t)s->t.n_fe; const int impl = s->sha_impl;
             auto job = [=](size_t k) { kzg_host::challenge_digests(dig + 64 * k, hb + BB * 2 * k, BB, hcm + 96 * k, nb - 2 * k < 2 ? nb - 2 * k : 2, n_fe, impl); };
-            if (s->host_pool && s->host_pool->try_begin((nb + 1) / 2, job)) {
+            if (s->host_pool) {                                  // (every call its own job object on the shared workers)
+                hf.job = s->host_pool->begin((nb + 1) / 2, job);
                 hf.pool = s->host_pool; hf.h_blobs = hb; hf.bytes = BB * nb; hf.running = true;
                 s->n_host_hashed++;
             }
@@ -1048,6 +1075,8 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (opt.split_streams >= 1 && opt.split_streams <= 8) s->split_streams = opt.split_streams;
     s->challenge_form = opt.challenge_form;
     s->lincomb_mode = opt.lincomb_form;
+    if (const char *e = getenv("KZG355_SIDE")) s->own_side_streams = strcmp(e, "shared") != 0;
+    if (const char *e = getenv("GPU_MAX_HW_QUEUES")) { const int q = atoi(e); if (q >= 1 && q <= 128) s->hw_queues = q; }
     s->submit_mode = opt.submit_sets >= 0 && opt.submit_sets <= 2 ? opt.submit_sets : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (hipMemcpy(g2b.p, g2_bytes, 96 * n2, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
