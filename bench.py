@@ -224,10 +224,10 @@ def main():
         else:
             dist.init_process_group(backend)
     if args.op != "verify":
-        # commit / proof are bound by the fixed-base MSM: 15-bit windows (17 full windows + a carry window, 154.6 GB table) instead of the handle's
-        # default 12-bit (22 windows, 23.6 GB) -- a deployment that serves commitments sets the same knob (kzg355_options.msm_bits); the
-        # verify path never reads the table.  Measured: 12 / 13 / 14 / 15 bits -> 75 / 79 / 88 / 92 k commitments per second.
-        os.environ.setdefault("KZG355_MSM_BITS", "15")
+        # commit / proof are bound by the fixed-base MSM: 16-bit windows over the GLV halves of the scalars (8 windows per half = 16 table rows per
+        # scalar, 143.5 GB table) -- a handle left to itself sizes the table from half of the free HBM (15-bit: 18 rows, 68.9 GB, on an empty
+        # card); a deployment that serves commitments sets the same knob (kzg355_options.msm_bits).  The verify path never reads the table.
+        os.environ.setdefault("KZG355_MSM_BITS", "16")
     import kzg_rust_amd as kz
     from synth import random_blob
     L = kz.kzg.lib()
@@ -445,12 +445,12 @@ def main():
         if args.op != "verify" and s.msm_form >= 10:
             # the memory-side bound of the fixed-base MSM is not streaming bandwidth but RANDOM 128-byte row gathers: one table row per (window, scalar).
             # Measured ceiling of that access pattern on MI355X: tools/ubench/gather_rate.hip, profiles/r03/gather_rate_random_128B.txt
-            bits = s.msm_form
-            windows = (256 + bits - 1) // bits
-            rows_per_blob = 4096 * (windows if bits != 15 else 17.45)      # 15 bits: 17 full windows and a carry window hit by 45 % of the scalars
+            bits, wins, glv, table_bytes = s.msm_shape()
+            rows_per_blob = 4096 * ((2 * wins) if glv else (wins if bits != 15 else 17.45))      # GLV: two halves per scalar; 256-bit 15-bit form: 17 full windows and a carry window hit by 45 % of the scalars
             rows_per_s = rows_per_blob * value / world
             roofline["gather"] = {"rows_per_blob": round(rows_per_blob), "achieved_rows_per_s": rows_per_s, "achieved_gbps": round(rows_per_s * 128 / 1e9, 1),
                                   "measured_random_128B_gather_peak_gbps": 1427.0, "frac_of_gather_peak": round(rows_per_s * 128 / 1427.0e9, 4),
+                                  "table": {"bits": bits, "windows_per_half_scalar" if glv else "windows": wins, "glv": bool(glv), "bytes": table_bytes},
                                   "source": "profiles/r03/gather_rate_random_128B.txt (11.1 G rows/s; streaming read of the same buffer: 5678 GB/s)"}
 
     host_inputs = None

@@ -58,9 +58,10 @@ typedef struct kzg355_settings kzg355_settings; /* opaque; replaces `KzgSettings
 /* Kzg::load_trusted_setup (kzg.rs:1005 -> 45-78 -> 833-899).  g1: n1*48 bytes, g2: n2*96 bytes, compressed,
  * Lagrange form, file order.  n1 not in {4096} + {4, 8, .., 64} or n2 != 65 -> INVALID_TRUSTED_SETUP; bad point / monomial form -> BADARGS.
  * Builds the device-resident tables (roots of unity, bit-reversed G1 table and its per-window multiples,
- * Miller-loop line tables of the two G2 points the verify path uses) -- including the 23.6 GB wide-window MSM table
- * (every multiple 1..2048 of 2^(12w) * g1[i]); if that allocation fails, or with KZG355_MSM=bucket in the environment,
- * only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results).  Takes the defaults of
+ * Miller-loop line tables of the two G2 points the verify path uses).  The wide-window MSM table of commitments / proofs (every multiple
+ * 1..2^(c-1) of 2^(c w) * g1[i] over 128 bits: 10.9 .. 143.5 GB, kzg355_options.msm_bits) is built by the FIRST commitment / proof call,
+ * sized from the HBM free at that moment -- a handle that only verifies never allocates it; if the allocation fails, or with
+ * KZG355_MSM=bucket, only the 15 MB 8-bit table is kept and commitments / proofs take the bucket path (same results).  Takes the defaults of
  * kzg355_options below with the KZG355_* environment overrides applied; kzg355_load_trusted_setup_ex is the explicit form. */
 int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, kzg355_settings **out);
 /* The same over several GPUs of one node: a full replica of the tables per device, and the host-buffer entry points below spread
@@ -82,8 +83,9 @@ int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const 
 typedef struct kzg355_options {
     size_t struct_size;        /* sizeof(kzg355_options) as the caller compiled it */
     int device;                /* device ordinal; -1: the calling thread's current device                                   KZG355_DEVICE */
-    int msm_bits;              /* fixed-base MSM table: 0 = 12-bit windows (23.6 GB); 13 / 14 / 15 = 42.9 / 81.6 / 154.6 GB (5 / 15 / 21 % more
-                                  commitments per second); 8 = the 15 MB 8-bit bucket form only                  KZG355_MSM_BITS, KZG355_MSM=bucket */
+    int msm_bits;              /* fixed-base MSM table (built on the first commitment / proof call): 0 = the widest form whose table fits half of
+                                  the HBM free at that moment; 12 / 13 / 15 / 16 = 10.9 / 20.1 / 68.9 / 143.5 GB at 22 / 20 / 18 / 16 table rows
+                                  per scalar; 8 = the 15 MB 8-bit bucket form only                                KZG355_MSM_BITS, KZG355_MSM=bucket */
     int msm_require_wide;      /* 1: failing to allocate / build the wide table fails the load (else: bucket form, noted on stderr)  KZG355_MSM=wide */
     int self_test;             /* 1 (default): known-answer self-test of the new handle (~10 ms); 0: skip                   KZG355_SELFTEST */
     int host_threads;          /* host worker threads of the handle (Fiat-Shamir hashing of small host-buffer calls, staging copies);
@@ -109,6 +111,9 @@ typedef struct kzg355_options {
     int exchange;              /* handles over several devices: 0 RCCL all-gather when available, 1 peer copies, 2 RCCL or fail   KZG355_EXCHANGE=peer|rccl */
     int verify_only;           /* 1: the handle serves verification: no wide-window MSM table is built or kept in HBM (the verify path never reads it;
                                   commitments / proofs still work, through the 15 MB bucket form)                          KZG355_VERIFY_ONLY=1 */
+    int msm_glv;               /* 0 (default): scalars are split k = a + b x^2 and the table spans 128 bits (half the memory per window width);
+                                  -1: round 3's form, windows over all 256 bits (12 .. 15 bits: 23.6 / 42.9 / 81.6 / 154.6 GB)     KZG355_MSM_GLV=off */
+    int msm_eager;             /* 1: build the table inside the load call instead of on first use                        KZG355_MSM_EAGER=1 */
     int submit_sets;           /* submit / collect: 0 by size (sets of <= 128 blobs per CU as 1, larger ones as 2); 1 = every submitted set on a stream of its
                                   own; 2 = two-stage pipeline: stage 1 of the submitted sets in order on one stream, stage 2 of a set on a second
                                   one, queued behind the NEXT set's Fiat-Shamir kernel                                   KZG355_SUBMIT=sets|pipeline */
@@ -233,10 +238,17 @@ int kzg355_settings_exchange_stats(const kzg355_settings *s, long *allgathers, l
  * [4, 64] -> the small-domain path (one lane per blob, naive lincomb as utils.rs:369-371 takes below 8 points).  Every `blob`
  * argument of this header is 32 * FIELD_ELEMENTS_PER_BLOB bytes for the handle it is passed with. */
 int kzg355_settings_field_elements_per_blob(const kzg355_settings *s);
-/* Which MSM form commitments / proofs take on this handle: 10 .. 15 = wide-window table of that digit width; 8 = the 8-bit
- * bucket form because KZG355_MSM=bucket asked for it; -8 = the bucket form because the wide table could NOT be allocated (also
- * reported once on stderr by the load function; KZG355_MSM=wide makes that a load error instead). */
+/* Which MSM form commitments / proofs take on this handle: 10 .. 16 = wide-window table of that digit width; 8 = the 8-bit
+ * bucket form because msm_bits = 8 / verify_only / KZG355_MSM=bucket asked for it; -8 = the bucket form because the wide table could NOT be
+ * allocated or built (also reported once on stderr; msm_require_wide / KZG355_MSM=wide makes that an error instead).  Before the table
+ * exists (it is built by the first commitment / proof call unless msm_eager): the width asked for, 0 = to be sized from the free HBM. */
 int kzg355_settings_msm_form(const kzg355_settings *s);
+/* The table as built: digit width, windows per (half-)scalar, 1 if the scalars are GLV-split, bytes of HBM; all 0 while it does not exist.
+ * Any pointer may be NULL. */
+int kzg355_settings_msm_shape(const kzg355_settings *s, int *bits, int *windows, int *glv, size_t *table_bytes);
+/* Build the table now (every device of the handle) instead of inside the first commitment / proof call.  OK if it exists afterwards or
+ * the handle is set to the bucket form. */
+int kzg355_settings_build_msm_table(const kzg355_settings *s);
 double kzg355_last_kernel_ms(const kzg355_settings *s, const char *kernel_family);
 /* Accumulated HIP-event time and launch count of a kernel family since timing was enabled / last reset. 0 on success. */
 int kzg355_kernel_ms_stats(const kzg355_settings *s, const char *kernel_family, double *total_ms, long *launches);

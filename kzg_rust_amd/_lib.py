@@ -17,7 +17,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_size_t)] + [(name, C.c_int) for name in (
         "device", "msm_bits", "msm_require_wide", "self_test", "host_threads", "host_hash", "host_hash_max_blobs", "host_sha", "host_rhash", "host_rhash_max_records", "challenge_form",
         "lincomb_form", "pairing_lane", "pairing_two_wave_upto", "lc_chain_from", "rhash_lanes_from", "beside_max_blobs", "split_parts",
-        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "submit_sets")]
+        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "msm_glv", "msm_eager", "submit_sets")]
 
 
 def load():
@@ -80,6 +80,8 @@ def load():
         "kzg355_debug_verify_sharded_intermediates": [u8p, bp, ip, u8p, u8p, u8p, sz, sz, vp],
         "kzg355_verify_blob_kzg_proof_batch_many_device_submit": [C.POINTER(vp), vp, vp, vp, sz, sz, vp],
         "kzg355_verify_collect": [vp, bp, ip],
+        "kzg355_settings_msm_shape": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
+        "kzg355_settings_build_msm_table": [vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -115,5 +117,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_verify_records_checked_device", "kzg355_debug_batch_intermediates", "kzg355_settings_msm_form", "kzg355_verify_shard_records_points_device", "kzg355_verify_records_points_device", "kzg355_load_trusted_setup_devices", "kzg355_settings_device_count", "kzg355_settings_exchange_stats", "kzg355_lagrange_setup_from_monomial", "kzg355_settings_field_elements_per_blob",
     "kzg355_settings_set_host_hash", "kzg355_settings_host_hashed_calls", "kzg355_host_sha256", "kzg355_host_challenge_digests", "kzg355_debug_verify_host_records",
     "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex", "kzg355_debug_verify_sharded_intermediates",
-    "kzg355_verify_blob_kzg_proof_batch_many_device_submit", "kzg355_verify_collect",
+    "kzg355_verify_blob_kzg_proof_batch_many_device_submit", "kzg355_verify_collect", "kzg355_settings_msm_shape", "kzg355_settings_build_msm_table",
 ]

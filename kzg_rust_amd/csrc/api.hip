@@ -236,6 +236,12 @@ struct kzg355_settings {
     bool pinned_ring = false;                 // KZG355_STAGING=ring: stage caller memory through the workspaces' pinned slots; default: let the
                                               // runtime lock the caller's pages and DMA from them (measured on MI355X hosts: 56 GB/s, no CPU copy)
     bool wide_table_failed = false;           // the wide-window MSM table was wanted but could not be allocated / built
+    // The table is built on the first commitment / proof call (or at load: kzg355_options.msm_eager, msm_require_wide) -- a handle that
+    // only ever verifies never pays for it.  msm_bits_wanted: 0 = sized from the free HBM at that moment, 8 = never, else the digit width.
+    int msm_bits_wanted = 0, msm_glv = 1;
+    bool msm_required = false;
+    std::once_flag wide_once;
+    int wide_rc = KZG355_OK;                  // what building it returned (msm_require_wide: a failure fails the calls that need it)
     bool timing = false;
     struct KStat { double last = -1, total = 0; long count = 0; };
     std::map<std::string, KStat> last_ms;
@@ -659,10 +665,76 @@ int stage_via_pinned(kzg355_settings *s, Workspace *w, PinBuf &pin, size_t pin_o
     return KZG355_OK;
 }
 
+int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs);
+// The fixed-base MSM table of the handle, built the first time a commitment or proof is asked for.  Width: the explicit msm_bits, else
+// the widest GLV form whose table (plus the ~7.5 GB the build parks its Jacobian runs in) fits HALF of the HBM that is free at that
+// moment: 16-bit windows 143.5 GB (16 rows per scalar), 15: 68.9 GB (18), 13: 20.1 GB (20), 12: 10.9 GB (22).  Then a check of the new
+// table against the bucket form on two known blobs; a table that fails it is dropped (bucket form from then on, said on stderr).
+thread_local bool tl_msm_inner = false;      // this thread is inside the build (or the load-time self-test): its MSM calls take the handle as it is
+int ensure_wide_table(kzg355_settings *s) {
+    if (s->msm_bits_wanted == 8 || tl_msm_inner || is_small(s)) return KZG355_OK;
+    std::call_once(s->wide_once, [s] {
+        DeviceScope scope;
+        if (!scope.enter(s->device)) { s->wide_rc = KZG355_NO_DEVICE; s->wide_table_failed = true; return; }
+        int bits = s->msm_bits_wanted;
+        if (bits == 0) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            const size_t scratch = (size_t)15 << 29;
+            for (int c : {16, 15, 13, 12}) {
+                const WideShape ws = wide_shape(c, s->msm_glv != 0 || c == 16);
+                if (!s->msm_glv && c == 16) continue;
+                if (wide_table_bytes(ws) + scratch <= free_b / 2) { bits = c; break; }
+            }
+            if (bits == 0) { s->wide_table_failed = true; s->wide_rc = KZG355_NO_MEMORY; }
+        }
+        if (bits) {
+            s->t.wide = wide_shape(bits, s->msm_glv != 0);
+            if (s->wide.ensure(wide_table_bytes(s->t.wide)) != KZG355_OK) { s->wide_table_failed = true; s->wide_rc = KZG355_NO_MEMORY; }
+            else {
+                DeviceTables t = s->t;
+                t.wide_table = s->wide.as<WideRow>();
+                if (build_wide_table(t, nullptr)) { s->wide.release(); s->wide_table_failed = true; s->wide_rc = KZG355_DEVICE_ERROR; }
+                else {
+                    // the new table against the bucket form: the all-ones blob and the blob (w_0, .., w_{N-1}), bit for bit
+                    const size_t BB = blob_bytes_of(s);
+                    DevBuf blobs;
+                    uint8_t c_wide[96], c_bucket[96]; int st[2] = {0, 0};
+                    int rc = blobs.ensure(2 * BB);
+                    if (rc == KZG355_OK) {
+                        std::vector<uint8_t> ones(BB, 0);
+                        for (size_t i = 0; i < (size_t)s->t.n_fe; i++) ones[32 * i + 31] = 1;
+                        if (hipMemcpy(blobs.p, ones.data(), BB, hipMemcpyHostToDevice) != hipSuccess) rc = KZG355_DEVICE_ERROR;
+                        launch_fr_to_bytes(s->t.roots, s->t.n_fe, blobs.as<uint8_t>() + BB, nullptr);
+                        if (hipDeviceSynchronize() != hipSuccess) rc = KZG355_DEVICE_ERROR;
+                    }
+                    tl_msm_inner = true;                      // (the two commitments below must not come back here)
+                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_bucket, st, blobs.as<uint8_t>(), nullptr, 2, s);
+                    s->t.wide_table = t.wide_table;
+                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_wide, st, blobs.as<uint8_t>(), nullptr, 2, s);
+                    tl_msm_inner = false;
+                    blobs.release();
+                    if (rc != KZG355_OK || memcmp(c_wide, c_bucket, 96) != 0) {
+                        fprintf(stderr, "kzg355: the wide-window MSM table failed its check against the bucket form (status %d): dropped\n", rc);
+                        s->t.wide_table = nullptr; s->wide.release(); s->wide_table_failed = true; s->wide_rc = rc != KZG355_OK ? rc : KZG355_INTERNAL;
+                    }
+                }
+            }
+        }
+        if (s->wide_table_failed) {
+            (void)hipGetLastError();
+            fprintf(stderr, "kzg355: the wide-window MSM table could not be %s; commitments / proofs take the 8-bit bucket form (about 3x slower, same results)\n",
+                    s->wide_rc == KZG355_NO_MEMORY ? "allocated" : "built");
+        }
+    });
+    return s->msm_required ? s->wide_rc : KZG355_OK;
+}
+
 // MSM -> 48-byte outputs on the host.  Wide-window table form if the handle has the table (scalars straight from the blobs,
 // or from Montgomery field elements for the quotient), else the 8-bit bucket form over a digit buffer.
 int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_t *d_blobs, const Fr *d_scalars) {
     int rc;
+    if ((rc = ensure_wide_table(s))) return rc;
     if ((rc = w->partials.ensure(sizeof(G1Jac) * (size_t)n * MSM_WINDOWS))) return rc;
     if ((rc = w->out48.ensure(48 * (size_t)n))) return rc;
     if ((rc = w->h_out.ensure(48 * (size_t)n))) return rc;
@@ -942,7 +1014,9 @@ void kzg355_options_from_env(kzg355_options *o) {
     auto num = [](const char *name, long lo, long hi, int *dst) { if (const char *e = getenv(name)) { const long v = atol(e); if (v >= lo && v <= hi) *dst = (int)v; } };
     num("KZG355_DEVICE", 0, 1023, &o->device);
     if (const char *e = getenv("KZG355_MSM")) { if (strcmp(e, "bucket") == 0) o->msm_bits = 8; else if (strcmp(e, "wide") == 0) o->msm_require_wide = 1; }
-    if (o->msm_bits != 8) num("KZG355_MSM_BITS", 10, 15, &o->msm_bits);
+    if (o->msm_bits != 8) num("KZG355_MSM_BITS", 10, 16, &o->msm_bits);
+    if (const char *e = getenv("KZG355_MSM_GLV")) o->msm_glv = strcmp(e, "off") == 0 ? -1 : 0;
+    num("KZG355_MSM_EAGER", 0, 1, &o->msm_eager);
     num("KZG355_SELFTEST", 0, 1, &o->self_test);
     num("KZG355_COPY_THREADS", 1, 64, &o->host_threads);
     num("KZG355_HOST_THREADS", 1, 64, &o->host_threads);
@@ -1089,22 +1163,20 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     if (hipMemcpy(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
     if (herr) return fail(KZG355_BADARGS);                       // kzg.rs:863, 878, 823-826
     g1b.release(); g2b.release(); err.release();
-    {   // the 23.6 GB wide-window MSM table (msm_bits = 8 keeps the 15 MB 8-bit form only; so does a failed allocation)
-        if (!small && opt.msm_bits != 8 && !opt.verify_only) {
-            const int bits = opt.msm_bits >= 10 && opt.msm_bits <= 15 ? opt.msm_bits : 12;
-            const bool required = opt.msm_require_wide != 0;
-            s->t.wide = wide_shape(bits);
-            if (s->wide.ensure(wide_table_bytes(s->t.wide)) == KZG355_OK) {
-                s->t.wide_table = s->wide.as<WideRow>();
-                if (build_wide_table(s->t, nullptr)) { s->wide.release(); s->t.wide_table = nullptr; s->wide_table_failed = true; if (required) { kzg355_free_trusted_setup(s); return KZG355_DEVICE_ERROR; } }
-            } else { s->wide_table_failed = true; if (required) { kzg355_free_trusted_setup(s); return KZG355_NO_MEMORY; } }
-            if (s->wide_table_failed) fprintf(stderr, "kzg355: the %.1f GB wide-window MSM table could not be allocated; commitments / proofs take the 8-bit bucket form (about 3x slower, same results)\n", wide_table_bytes(s->t.wide) / 1e9);
-            (void)hipGetLastError();
-        }
-    }
-    if (opt.self_test) {   // known-answer self-test of the freshly built handle
+    // the wide-window MSM table: built on first use (ensure_wide_table) unless asked for at load
+    s->msm_bits_wanted = (small || opt.msm_bits == 8 || opt.verify_only) ? 8 : (opt.msm_bits >= 10 && opt.msm_bits <= 16 ? opt.msm_bits : 0);
+    s->msm_glv = opt.msm_glv < 0 ? 0 : 1;
+    if (!s->msm_glv && s->msm_bits_wanted == 16) s->msm_bits_wanted = 15;            // (the 256-bit form stops at 15-bit windows: 155 GB)
+    s->msm_required = opt.msm_require_wide != 0 && s->msm_bits_wanted != 8;
+    if (opt.self_test) {   // known-answer self-test of the freshly built handle (MSM through the bucket form: the wide table has its own check when it is built)
+        tl_msm_inner = true;
         const int rc = device_self_test(s);
+        tl_msm_inner = false;
         if (rc != KZG355_OK) { kzg355_free_trusted_setup(s); return rc; }
+    }
+    if (opt.msm_eager || s->msm_required) {
+        const int rc = ensure_wide_table(s);
+        if (rc != KZG355_OK && s->msm_required) { kzg355_free_trusted_setup(s); return rc; }
     }
     *out = s;
     return KZG355_OK;
@@ -1395,7 +1467,23 @@ int kzg355_settings_field_elements_per_blob(const kzg355_settings *s) { return s
 int kzg355_settings_msm_form(const kzg355_settings *s) {
     if (!s) return 0;
     if (s->t.wide_table) return s->t.wide.bits;
-    return s->wide_table_failed ? -8 : 8;
+    if (s->wide_table_failed) return -8;
+    return s->msm_bits_wanted == 8 ? 8 : s->msm_bits_wanted;     // not built yet: the width asked for, 0 = to be sized from the free HBM
+}
+int kzg355_settings_msm_shape(const kzg355_settings *s, int *bits, int *windows, int *glv, size_t *table_bytes) {
+    if (!s) return KZG355_BADARGS;
+    const bool built = s->t.wide_table != nullptr;
+    if (bits) *bits = built ? s->t.wide.bits : 0;
+    if (windows) *windows = built ? s->t.wide.windows : 0;
+    if (glv) *glv = built ? s->t.wide.glv : 0;
+    if (table_bytes) *table_bytes = built ? wide_table_bytes(s->t.wide) : 0;
+    return KZG355_OK;
+}
+int kzg355_settings_build_msm_table(const kzg355_settings *cs) {
+    if (!cs) return KZG355_BADARGS;
+    kzg355_settings *s = const_cast<kzg355_settings *>(cs);
+    for (kzg355_settings *r : replicas_of(s)) { const int rc = ensure_wide_table(r); if (rc) return rc; }
+    return s->t.wide_table ? KZG355_OK : (s->msm_bits_wanted == 8 ? KZG355_OK : s->wide_rc == KZG355_OK ? KZG355_NO_MEMORY : s->wide_rc);
 }
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s) { return s ? s->n_host_hashed.load() : 0L; }

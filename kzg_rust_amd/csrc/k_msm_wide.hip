@@ -32,12 +32,13 @@ __device__ __forceinline__ G1Jac g1_shfl_xor_w(const G1Jac &v, int mask) {
 }
 
 // ------------------------------------------------------------------------------------------------ setup
-// row 1 of every (w, i): 2^(c w) P_i = 2^r * table8[(c w) >> 3][i], r = (c w) & 7
-__global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRow *wide, WideShape ws, int w_lo, int w_n) {
+// row 1 of (w, i) for the points i_lo .. i_lo + i_n - 1 of ONE window: 2^(c w) P_i = 2^r * table8[(c w) >> 3][i], r = (c w) & 7.
+// wbase: the window's block of the table, rows_w rows per point.
+__global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRow *wbase, int bits_total, int rows_w, int i_lo, int i_n) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= w_n * N_FE) return;
-    const int w = w_lo + id / N_FE, i = id % N_FE;
-    const int bits = ws.bits * w, w8 = bits >> 3, r = bits & 7;
+    if (id >= i_n) return;
+    const int i = i_lo + id;
+    const int w8 = bits_total >> 3, r = bits_total & 7;
     G1Affine q = table8[(size_t)w8 * N_FE + i];
     if (r) {
         G1Jac j; g1_from_affine(j, q);
@@ -46,18 +47,17 @@ __global__ void __launch_bounds__(64) k_wide_base(const G1Affine *table8, WideRo
     }
     WideRow row; row.x = q.x; row.y = q.y;
     for (int k = 0; k < 4; k++) row.pad[k] = 0;
-    wide[((size_t)w * N_FE + i) * ws.rows] = row;
+    wbase[(size_t)i * rows_w] = row;
 }
-// rows m = 256 seg + 1 .. 256 seg + 256 of (w, i), one lane per (w, i, seg):  Jacobian run acc += Q (parked in `jac`, with
+// rows m = 256 seg + 1 .. 256 seg + 256 of (w, i), one lane per (i, seg):  Jacobian run acc += Q (parked in `jac`, with
 // the running product of the z's in `pre`), ONE inversion, then backwards: z_k^-1 = inv * pre_{k-1}, inv *= z_k.
 constexpr int WIDE_SEG = 256;
-__global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp *pre, WideShape ws, int w_lo, int w_n) {
+__global__ void __launch_bounds__(64) k_wide_rows(WideRow *wbase, G1Jac *jac, Fp *pre, int rows_w, int i_lo, int i_n) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const int SEGS = ws.rows / WIDE_SEG;
-    if (id >= w_n * N_FE * SEGS) return;
-    const int seg = id % SEGS, pi = id / SEGS;
-    const int w = w_lo + pi / N_FE, i = pi % N_FE;
-    WideRow *rows = wide + ((size_t)w * N_FE + i) * ws.rows;
+    const int SEGS = rows_w / WIDE_SEG;
+    if (id >= i_n * SEGS) return;
+    const int seg = id % SEGS, i = i_lo + id / SEGS;
+    WideRow *rows = wbase + (size_t)i * rows_w;
     G1Affine q; q.x = rows[0].x; q.y = rows[0].y;
     G1Jac *myj = jac + (size_t)id * WIDE_SEG;
     Fp *myp = pre + (size_t)id * WIDE_SEG;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) k_wide_rows(WideRow *wide, G1Jac *jac, Fp 
     if (seg) {
         G1Jac b; g1_from_affine(b, q);
         for (int k = 0; k < 8; k++) g1_dbl(b, b);                 // 256 Q
-        for (int bit = 5; bit >= 0; bit--) { g1_dbl(acc, acc); if ((seg >> bit) & 1) g1_add(acc, acc, b); }      // seg < 64
+        for (int bit = 8; bit >= 0; bit--) { g1_dbl(acc, acc); if ((seg >> bit) & 1) g1_add(acc, acc, b); }      // seg < 512
     }
     Fp run = fp_one();
     for (int k = 0; k < WIDE_SEG; k++) {
@@ -158,20 +158,108 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
     }
 }
 
+// The GLV form (WideShape.glv): every scalar is split k = a + b x^2 and the table spans 128 bits.  Waves 0 and 1 of the workgroup walk the
+// halves a, waves 2 and 3 the halves b, of the same 256 * spl scalars (2 * spl halves per lane: as many additions per lane as before per
+// 17.45 / 16 rows), every lane into ONE accumulator; the sums of the two wave pairs meet at the end as  T_a + (-phi)(T_b),
+// -phi(X, Y, Z) = (beta X, -Y, Z): the endomorphism once per workgroup instead of once per gathered row.
+__device__ __forceinline__ int wide_raw_digit128(const uint32_t s[4], int w, int bits) {
+    const int bit = bits * w, wi = bit >> 5, sh = bit & 31;
+    if (wi >= 4) return 0;
+    uint32_t v = s[wi] >> sh;
+    if (sh > 32 - bits && wi + 1 < 4) v |= s[wi + 1] << (32 - sh);
+    return (int)(v & ((1u << bits) - 1));
+}
+template <bool FROM_FR>
+__global__ void __launch_bounds__(256) k_msm_wide_glv(const uint8_t *blobs, const Fr *scalars, const WideRow *wide, WideShape ws, G1Jac *partials, int *err,
+                                                       int spl /* scalars per lane */, int parts /* window parts */) {
+    __shared__ G1Jac red[4];
+    const int chunks = N_FE / (256 * spl), wgpb = chunks * parts;
+    const int blob = blockIdx.x / wgpb, wg = blockIdx.x % wgpb, chunk = wg / parts, part = wg % parts;
+    const int tid = threadIdx.x, hsel = tid >> 7, j = tid & 127;
+    const int W = ws.windows, w_lo = (W * part) / parts, w_hi = (W * (part + 1)) / parts;
+    const int half = ws.rows;                                    // 2^(c-1): digits below the top window run over [-half, half - 1]
+    const size_t top_base = (size_t)(W - 1) * N_FE * ws.rows;     // the top window's block: rows_top rows per point, unsigned digit
+    G1X accx = g1x_inf(); bool started = false;
+    WideRow cur; bool have = false; bool cur_neg = false;
+    bool bad = false;
+#pragma unroll 1
+    for (int k = 0; k < 2 * spl; k++) {
+        const int i = chunk * 256 * spl + k * 128 + j;
+        uint32_t s[8], ha[4], hb[4], v[4];
+        bool canon = true;
+        if (FROM_FR) fr_to_words(s, scalars[(size_t)blob * N_FE + i]);
+        else { load_blob_element_words(s, blobs + (size_t)BLOB_BYTES * blob, i); canon = fr_words_canonical(s); bad = bad || !canon; }
+        glv_split_fast(ha, hb, s);
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = canon ? (hsel ? hb[q] : ha[q]) : 0u;      // a non-canonical element (the blob is an Err anyway) must not index past the table
+        int carry = 0;
+        for (int w = 0; w < w_lo; w++) { const int raw = wide_raw_digit128(v, w, ws.bits) + carry; carry = raw >= half; }
+#pragma unroll 1
+        for (int w = w_lo; w < w_hi; w++) {
+            int d = wide_raw_digit128(v, w, ws.bits) + carry;
+            carry = (w < W - 1) && d >= half;
+            if (carry) d -= 2 * half;
+            if (d == 0) continue;
+            const int m = d < 0 ? -d : d;
+            const size_t off = w < W - 1 ? ((size_t)w * N_FE + i) * ws.rows : top_base + (size_t)i * ws.rows_top;
+            const WideRow nxt = wide[off + (m - 1)];              // in flight during the addition below
+            if (have) {
+                G1Affine p; p.x = cur.x; p.y = cur.y;
+                if (cur_neg) fp_neg(p.y, p.y);
+                g1x_add_mixed_lazy(accx, started, p);
+            }
+            cur = nxt; cur_neg = d < 0; have = true;
+        }
+    }
+    if (have) {
+        G1Affine p; p.x = cur.x; p.y = cur.y;
+        if (cur_neg) fp_neg(p.y, p.y);
+        g1x_add_mixed_lazy(accx, started, p);
+    }
+    G1Jac acc;
+    { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
+    if (!FROM_FR && bad && part == 0) atomicOr(&err[blob], ERR_NONCANONICAL_FR);          // blob_to_polynomial (kzg.rs:282-291)
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        G1Jac ta = red[0], tb = red[2];
+        { G1Jac o = red[1]; g1_add(ta, ta, o); }
+        { G1Jac o = red[3]; g1_add(tb, tb, o); }
+        if (!g1_is_inf(tb)) {                                     // (-phi)(X, Y, Z) = (beta X, -Y, Z)
+            const uint32_t bc[NFP] = FP_BETA_INIT;
+            Fp beta; for (int q = 0; q < NFP; q++) beta.l[q] = bc[q];
+            fp_mul(tb.x, tb.x, beta);
+            fp_neg(tb.y, tb.y);
+        }
+        g1_add(ta, ta, tb);
+        partials[(size_t)blob * wgpb + wg] = ta;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
-size_t wide_table_bytes(WideShape ws) { return sizeof(WideRow) * (size_t)ws.windows * N_FE * ws.rows; }
-// Builds the table one or two windows at a time; the scratch is freed afterwards.
+size_t wide_table_bytes(WideShape ws) { return sizeof(WideRow) * (size_t)N_FE * wide_rows_per_point(ws); }
+// Builds the table window by window, a slice of the points at a time (the Jacobian runs and their z products are parked in a scratch
+// of <= 2^17 runs of 256 rows: 7.5 GB); the scratch is freed afterwards.
 int build_wide_table(DeviceTables t, hipStream_t st) {
     const WideShape ws = t.wide;
-    const int SLAB = ws.rows <= 2048 ? 2 : 1;                      // scratch: SLAB x 4096 x rows Jacobian points + z products (3.8 GB at c = 12)
-    const size_t runs = (size_t)SLAB * N_FE * (ws.rows / WIDE_SEG);
+    const int rows_max = ws.rows > ws.rows_top ? ws.rows : ws.rows_top;
+    int slice = (1 << 17) / (rows_max / WIDE_SEG);                 // points per launch
+    if (slice > N_FE) slice = N_FE;
+    if (slice < 64) slice = 64;
+    const size_t runs = (size_t)slice * (rows_max / WIDE_SEG);
     G1Jac *jac = nullptr; Fp *pre = nullptr;
-    if (hipMalloc(&jac, sizeof(G1Jac) * runs * WIDE_SEG) != hipSuccess) return 1;
-    if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { (void)hipFree(jac); return 1; }
-    for (int w = 0; w < ws.windows; w += SLAB) {
-        const int wn = w + SLAB <= ws.windows ? SLAB : ws.windows - w;
-        hipLaunchKernelGGL(k_wide_base, dim3((wn * N_FE + 63) / 64), dim3(64), 0, st, t.msm_table, t.wide_table, ws, w, wn);
-        hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)wn * N_FE * (ws.rows / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, t.wide_table, jac, pre, ws, w, wn);
+    if (hipMalloc(&jac, sizeof(G1Jac) * runs * WIDE_SEG) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    if (hipMalloc(&pre, sizeof(Fp) * runs * WIDE_SEG) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(jac); return 1; }
+    for (int w = 0; w < ws.windows; w++) {
+        const int rows_w = w < ws.windows - 1 ? ws.rows : ws.rows_top;
+        WideRow *wbase = t.wide_table + (size_t)w * N_FE * ws.rows;      // (the top window's block starts where a full one would)
+        for (int i_lo = 0; i_lo < N_FE; i_lo += slice) {
+            const int i_n = i_lo + slice <= N_FE ? slice : N_FE - i_lo;
+            hipLaunchKernelGGL(k_wide_base, dim3((i_n + 63) / 64), dim3(64), 0, st, t.msm_table, wbase, ws.bits * w, rows_w, i_lo, i_n);
+            hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)i_n * (rows_w / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, wbase, jac, pre, rows_w, i_lo, i_n);
+        }
     }
     const hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(jac); (void)hipFree(pre);
@@ -189,6 +277,11 @@ void launch_msm_wide(const uint8_t *d_blobs, const Fr *d_scalars, DeviceTables t
     if (n <= 0) return;
     int spl, parts; msm_wide_shape(n, &spl, &parts);
     const int wgpb = N_FE / (256 * spl) * parts;
+    if (t.wide.glv) {
+        if (d_scalars) hipLaunchKernelGGL(k_msm_wide_glv<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
+        else hipLaunchKernelGGL(k_msm_wide_glv<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
+        return;
+    }
     if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
     else hipLaunchKernelGGL(k_msm_wide<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
 }

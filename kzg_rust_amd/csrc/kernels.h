@@ -22,8 +22,24 @@ constexpr int MSM_WINDOWS = 32;            // 32 x 8 bits cover the 255-bit scal
 constexpr int MSM_BUCKETS = 128;           // signed digits in [-127, 128]
 // wide-window form of the same MSM (k_msm_wide.hip): signed c-bit digits, every multiple 1..2^(c-1) tabulated; c is chosen when
 // the handle is created (12: 22 windows, 23.6 GB; 13: 20 windows, 42.9 GB; 14: 19 windows, 81.6 GB)
-struct WideShape { int bits, windows, rows; };
-inline WideShape wide_shape(int bits) { WideShape w; w.bits = bits; w.windows = (256 + bits - 1) / bits; w.rows = 1 << (bits - 1); return w; }
+// Shape of the fixed-base MSM table (k_msm_wide.hip): `windows` signed `bits`-bit windows of `rows` = 2^(bits-1) multiples each, except the
+// top window, which takes an unsigned digit (no carry leaves it) and has rows_top rows.  glv = 0: the windows span the 256 bits of the scalar.
+// glv = 1 (round 4): the scalar is split k = a + b x^2 (g1.h glv_split_fast; a, b < x^2 < 2^127.5) and the windows span 128 bits -- the
+// SAME table serves both halves, because sum_i [b_i](-phi P_i) = -phi(sum_i [b_i] P_i): the rows of the b halves are added up as they
+// are and the endomorphism is applied once, to their sum.  Half the table at the same number of rows per scalar, or (16-bit windows: 8
+// windows per half) 16 rows per scalar in 143 GB where the 256-bit form took 17.45 rows in 155 GB.
+struct WideShape { int bits, windows, rows, glv, rows_top; };
+inline WideShape wide_shape(int bits, bool glv = false) {
+    WideShape w; w.bits = bits; w.rows = 1 << (bits - 1); w.glv = glv ? 1 : 0;
+    if (!glv) { w.windows = (256 + bits - 1) / bits; w.rows_top = w.rows; return w; }
+    w.windows = (128 + bits - 1) / bits;
+    // largest top digit: the top bits of x^2 - 1 = 0xac45a4010001a40200000000ffffffff (both halves are below x^2), plus the carry coming in
+    const int shift = bits * (w.windows - 1);                     // >= 96 for every supported width
+    const unsigned top = (unsigned)(0xac45a401u >> (shift - 96)) + 1u;
+    w.rows_top = (int)((top + 256u) & ~255u);                     // (segments of 256 rows: k_wide_rows)
+    return w;
+}
+inline size_t wide_rows_per_point(WideShape w) { return (size_t)(w.windows - 1) * w.rows + w.rows_top; }
 constexpr int N_G2 = 65;
 
 // error bits accumulated on the device; any bit => the call returns Err (reference: `?` on each step)

@@ -227,6 +227,16 @@ class KzgSettings:
         """4096 (mainnet) or 4 (minimal preset): fixed by the number of G1 points the handle was loaded from."""
         return lib().kzg355_settings_field_elements_per_blob(self.handle)
 
+    def msm_shape(self):
+        """(digit width, windows per half-scalar, GLV split 0 / 1, table bytes) of the fixed-base MSM table; all 0 while it has not been built."""
+        b, w, g, n = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+        _check(lib().kzg355_settings_msm_shape(self.handle, C.byref(b), C.byref(w), C.byref(g), C.byref(n)), "msm_shape")
+        return b.value, w.value, g.value, n.value
+
+    def build_msm_table(self):
+        """Build the fixed-base MSM table now instead of inside the first commitment / proof call."""
+        _check(lib().kzg355_settings_build_msm_table(self.handle), "build_msm_table")
+
     @property
     def msm_form(self):
         """12 / 13 / 14: wide-window table of that digit width; 8: bucket form by request; -8: bucket form because the table

@@ -47,6 +47,8 @@ pub struct kzg355_options {
     pub staging_ring: c_int,
     pub exchange: c_int,
     pub verify_only: c_int,
+    pub msm_glv: c_int,
+    pub msm_eager: c_int,
     pub submit_sets: c_int,
 }
 
@@ -80,6 +82,8 @@ extern "C" {
     pub fn kzg355_settings_device_count(s: *const kzg355_settings) -> c_int;
     pub fn kzg355_settings_field_elements_per_blob(s: *const kzg355_settings) -> c_int;
     pub fn kzg355_settings_msm_form(s: *const kzg355_settings) -> c_int;
+    pub fn kzg355_settings_msm_shape(s: *const kzg355_settings, bits: *mut c_int, windows: *mut c_int, glv: *mut c_int, table_bytes: *mut usize) -> c_int;
+    pub fn kzg355_settings_build_msm_table(s: *const kzg355_settings) -> c_int;
     pub fn kzg355_settings_exchange_stats(s: *const kzg355_settings, allgathers: *mut c_long, peer_exchanges: *mut c_long) -> c_int;
     pub fn kzg355_settings_set_host_hash(s: *mut kzg355_settings, mode: c_int, max_blobs: c_int) -> c_int;
     pub fn kzg355_settings_host_hashed_calls(s: *const kzg355_settings) -> c_long;

@@ -9,6 +9,7 @@
 #include "../../kzg_rust_amd/csrc/pairing_coop.h"
 #include "../../kzg_rust_amd/csrc/eval_core.h"
 #include <vector>
+#include <cstring>
 using namespace kzg;
 extern "C" {
 int hd_fp_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
@@ -157,6 +158,15 @@ int hd_g1_add_jac(uint8_t *out, const uint8_t *p, const uint8_t *q) {
     g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
 }
 // [k]P through the GLV split: [k mod x^2]P + [k div x^2](-phi P)
+// both GLV splits of a 256-bit big-endian k: out = a (16 bytes, little-endian words) | b | a_fast | b_fast
+int hd_glv_splits(uint8_t *out, const uint8_t *k_be) {
+    uint32_t k[8], a[4], b[4], af[4], bf[4];
+    be32_to_words(k, k_be);
+    glv_split(a, b, k);
+    glv_split_fast(af, bf, k);
+    memcpy(out, a, 16); memcpy(out + 16, b, 16); memcpy(out + 32, af, 16); memcpy(out + 48, bf, 16);
+    return 0;
+}
 int hd_glv_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be) {
     G1Affine pa, qa, ra; G1Jac r1, r2; uint32_t w[8], a[4], b[4];
     if (g1_decompress(pa, p)) return 1;

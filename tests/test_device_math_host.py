@@ -165,6 +165,22 @@ def test_g1_mul_add(hd, oracle, setup_bytes):
         assert hd.hd_g1_add_jac(out, p, q) == 0 and out.raw == want
 
 
+def test_glv_split_by_barrett_division_matches_the_restoring_division(hd):
+    """g1.h glv_split_fast (the fixed-base MSM's split, ~150 instructions) against glv_split (bit-serial) and Python: k = a + b x^2,
+    0 <= a < x^2, for random scalars below r and the values where a Barrett estimate is off by one."""
+    rng = random.Random(355)
+    x2 = 0xd201000000010000 ** 2
+    edge = [0, 1, x2 - 1, x2, x2 + 1, 2 * x2 - 1, 2 * x2, R - 1, R - 2, (x2 - 1) * x2, (x2 - 1) * x2 - 1, (x2 - 2) * x2 + x2 - 1,
+            (1 << 255) - 1, (1 << 254), (1 << 127), (1 << 127) - 1, (1 << 128) - 1, (1 << 128), 3 * x2 - 1, 3 * x2]
+    edge += [m * x2 + d for m in (1, 2, 12345, x2 // 2, x2 - 2) for d in (-1, 0, 1)]
+    out = C.create_string_buffer(64)
+    for k in edge + [rng.randrange(R) for _ in range(20000)]:
+        assert hd.hd_glv_splits(out, k.to_bytes(32, "big")) == 0
+        a, b, af, bf = (int.from_bytes(out.raw[16 * i:16 * i + 16], "little") for i in range(4))
+        assert (a, b) == (k % x2, k // x2), hex(k)
+        assert (af, bf) == (a, b), hex(k)
+
+
 def test_g2_decompress_and_pairing(hd, oracle, setup_bytes):
     g1, g2 = setup_bytes
     for i in range(65):

@@ -262,8 +262,9 @@ def test_explicit_options_ignore_the_environment(kz, setup_bytes, batch, monkeyp
     s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)],
                                              host_hash=1, host_threads=3, lincomb_form=1, self_test=0)
     try:
-        assert s.msm_form == 12
+        assert s.msm_form == 0 and s.msm_shape() == (0, 0, 0, 0)      # default: the MSM table is built by the first commitment / proof call, sized then
         assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, s) is True and s.host_hashed_calls == 1
+        assert s.msm_shape() == (0, 0, 0, 0)                          # verifying never builds it
         assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, [Pr[1]] + Pr[1:], s) is False
     finally:
         s.free()

@@ -441,31 +441,83 @@ def test_challenge_kernel_forms_match_oracle(form, kz, setup_bytes, random_set, 
 
 
 def test_msm_bucket_form_matches_wide_table_form(kz, setup_bytes, settings, random_set, oracle, oracle_settings):
-    """Commitments and proofs through the 8-bit bucket MSM (KZG355_MSM=bucket: the form a handle falls back to when the 23.6 GB
-    wide-window table cannot be allocated) equal the default form's and the oracle's, for 1, 5 and all blobs per call (the
-    launch shapes differ with the count)."""
-    g1, g2 = setup_bytes
-    os.environ["KZG355_MSM"] = "bucket"
-    try:
-        sb = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
-    finally:
-        del os.environ["KZG355_MSM"]
-    os.environ["KZG355_MSM_BITS"] = "13"                 # a wider window of the table form (20 windows, 42.9 GB)
-    try:
-        s13 = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
-    finally:
-        del os.environ["KZG355_MSM_BITS"]
-    try:
-        blobs, cs, ps = random_set
-        B = [kz.Blob(b) for b in blobs]
+    """Commitments and proofs through every form of the fixed-base MSM equal the oracle's, for 1, 5 and all blobs per call (the launch shapes
+    differ with the count): the 8-bit bucket form (what a handle falls back to when the table cannot be allocated), the GLV tables of 12-, 13-,
+    15- and 16-bit windows (11 / 10 / 9 / 8 windows per 128-bit half; 16 bits: the unsigned 44,288-row top window, 143.5 GB), round 3's 256-bit
+    windows (KZG355_MSM_GLV=off), and the module's default handle (table sized from the free HBM on its first commitment)."""
+    import torch
+    blobs, cs, ps = random_set
+    B = [kz.Blob(b) for b in blobs]
+
+    def check(s):
         for n in (1, 5, len(blobs)):
-            for s in (sb, settings, s13):
-                got = kz.Kzg.blob_to_kzg_commitment_many(B[:n], s)
-                assert [c.to_bytes() for c in got] == cs[:n]
-                gp = kz.Kzg.compute_blob_kzg_proof_many(B[:n], [kz.KzgCommitment(c) for c in cs[:n]], s)
-                assert [p.to_bytes() for p in gp] == ps[:n]
+            got = kz.Kzg.blob_to_kzg_commitment_many(B[:n], s)
+            assert [c.to_bytes() for c in got] == cs[:n]
+            gp = kz.Kzg.compute_blob_kzg_proof_many(B[:n], [kz.KzgCommitment(c) for c in cs[:n]], s)
+            assert [p.to_bytes() for p in gp] == ps[:n]
+    check(settings)
+    bits, windows, glv, nbytes = settings.msm_shape()
+    assert glv == 1 and bits in (12, 13, 15, 16) and windows == -(-128 // bits) and settings.msm_form == bits and nbytes > 10e9
+    want = {"bucket": (0, 0, 0), "12": (12, 11, 1), "13": (13, 10, 1), "15": (15, 9, 1), "16": (16, 8, 1), "glv-off-12": (12, 22, 0), "glv-off-14": (14, 19, 0)}
+    free_b = torch.cuda.mem_get_info(settings.device)[0]
+    for name, shape in want.items():
+        if name == "16" and free_b < 165e9:
+            continue                                              # (143.5 GB + the build's scratch: only on an otherwise empty card)
+        env = {"KZG355_MSM": "bucket"} if name == "bucket" else {"KZG355_MSM_BITS": name.split("-")[-1]}
+        if name.startswith("glv-off"):
+            env["KZG355_MSM_GLV"] = "off"
+        s = _handle_with_env(kz, setup_bytes, **env)
+        try:
+            assert s.msm_shape() == (0, 0, 0, 0)                  # not built by the load
+            check(s)
+            assert s.msm_shape()[:3] == shape, (name, s.msm_shape())
+            assert s.msm_form == (8 if name == "bucket" else shape[0])
+        finally:
+            s.free()
+
+
+@pytest.mark.parametrize("bits", [12, 13, 15, 16])
+def test_glv_table_digit_extremes(bits, kz, setup_bytes, oracle, oracle_settings):
+    """Scalars k = a + b x^2 whose HALVES hit the corners of the signed recoding of the GLV tables: every window of a half at 2^(bits-1)
+    (digit -2^(bits-1) and a carry chain into the unsigned top window), at 2^(bits-1) - 1, alternating all-ones / 1, the largest top digit
+    with a carry on top of it (a = 0xac45a400ffff...: top window 0xac45 + 1 of the 16-bit form), a = x^2 - 1, b = x^2 - 1 (k = r - 1), halves 0
+    and 1 -- commitments and proofs must be the oracle's."""
+    import torch
+    X2 = 0xd201000000010000 ** 2
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    W = -(-128 // bits)
+    half = 1 << (bits - 1)
+
+    def halfval(vals):                       # little-endian window values -> a value below x^2
+        v = sum(x << (bits * i) for i, x in enumerate(vals))
+        return v % X2
+    hs = [halfval([half] * W), halfval([half - 1] * W), halfval([2 * half - 1, 1] * W), X2 - 1, 0, 1, 0xAC45A400FFFF << 80, (0xAC45A400FFFF << 80) | ((1 << 80) - 1),
+          halfval([half] * (W - 1)), halfval([0] * (W - 1) + [1]), 1 << 127, (1 << 127) - 1, halfval([half, half - 1] * W)]
+    hs = [h for h in hs if h < X2]
+    pats = []
+    for i, a in enumerate(hs):
+        for b in (hs[(i + 3) % len(hs)], hs[(2 * i + 1) % len(hs)], 0):
+            k = a + b * X2
+            if k < R:
+                pats.append(k)
+    pats += [R - 1, (X2 - 1) * X2, X2 - 1, X2, 0, 1]
+    assert all(0 <= p < R for p in pats) and len(pats) > 30
+    blobs = [b"".join(pats[(i + s) % len(pats)].to_bytes(32, "big") for i in range(4096)) for s in (0, 5)]
+    if bits == 16 and torch.cuda.mem_get_info(0)[0] < 165e9:
+        pytest.skip("143.5 GB table: only on an otherwise empty card")
+    s = _handle_with_env(kz, setup_bytes, KZG355_MSM_BITS=str(bits))
+    try:
+        cs = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], s)
+        assert s.msm_shape()[:3] == (bits, W, 1)
+        for b, c in zip(blobs, cs):
+            assert c.to_bytes() == oracle.blob_to_kzg_commitment(b, oracle_settings)
+        ps = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], cs, s)
+        for b, c, p in zip(blobs, cs, ps):
+            assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
+        one = kz.Kzg.blob_to_kzg_commitment(kz.Blob(blobs[0]), s)              # the lone-blob launch shape (two window parts)
+        assert one.to_bytes() == cs[0].to_bytes()
     finally:
-        sb.free(); s13.free()
+        s.free()
 
 
 @pytest.mark.parametrize("n", [64, 512])
@@ -566,6 +618,7 @@ def test_msm_launch_shapes_agree(kz, settings, random_set, setup_bytes):
     noise = torch.randint(0, 256, (n * 131072,), dtype=torch.uint8, generator=g).to(dev)
     noise.view(n * 4096, 32)[:, 0] = 0                          # keep every element canonical
     tb[len(blobs) * 131072:] = noise[len(blobs) * 131072:]      # first len(blobs) blobs stay the oracle-checked ones
+    torch.cuda.synchronize()                                    # torch's stream is not ordered against the library's own streams
     L = kz.kzg.lib()
 
     def commit(lo, hi):
@@ -574,7 +627,7 @@ def test_msm_launch_shapes_agree(kz, settings, random_set, setup_bytes):
         return out.raw
 
     def prove(lo, hi, c):
-        tc = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev); torch.cuda.synchronize()
         out = C.create_string_buffer(48 * (hi - lo)); st = (C.c_int * (hi - lo))()
         assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr() + lo * 131072, tc.data_ptr(), hi - lo, settings.handle) == 0
         return out.raw
@@ -596,14 +649,14 @@ def test_msm_launch_shapes_agree(kz, settings, random_set, setup_bytes):
     try:
         out = C.create_string_buffer(48 * n); st = (C.c_int * n)()
         assert L.kzg355_blob_to_kzg_commitment_many_device(out, st, tb.data_ptr(), n, sb.handle) == 0 and out.raw == c_all
-        tc = torch.frombuffer(bytearray(c_all), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(c_all), dtype=torch.uint8).to(dev); torch.cuda.synchronize()
         assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr(), tc.data_ptr(), n, sb.handle) == 0 and out.raw == p_all
     finally:
         sb.free()
 
 
-def test_wide_table_digit_extremes(kz, settings, oracle, oracle_settings):
-    """Scalars built to hit the corners of the signed 12-bit recoding of the wide-table MSM: every window 0x800 (digit -2048 with a
+def test_wide_table_digit_extremes(kz, setup_bytes, oracle, oracle_settings):
+    """(Round 3's table form, KZG355_MSM_GLV=off: windows over the 256 bits of the scalar.)  Scalars built to hit the corners of the signed 12-bit recoding of the wide-table MSM: every window 0x800 (digit -2048 with a
     carry chain through all 22 windows), 0x7ff (largest positive digit), 0xfff / 0x001 alternating, a lone top-window bit, and
     r - 1 next to 0 and 1 -- commitments and proofs must be the oracle's."""
     R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -614,14 +667,19 @@ def test_wide_table_digit_extremes(kz, settings, oracle, oracle_settings):
     assert all(0 <= p < R for p in pats)
     blobs = [b"".join(pats[(i + s) % len(pats)].to_bytes(32, "big") for i in range(4096)) for s in (0, 3)]
     blobs.append(pats[0].to_bytes(32, "big") * 4096)
-    cs = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], settings)
-    for b, c in zip(blobs, cs):
-        assert c.to_bytes() == oracle.blob_to_kzg_commitment(b, oracle_settings)
-    ps = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], cs, settings)
-    for b, c, p in zip(blobs, cs, ps):
-        assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
-    one = kz.Kzg.blob_to_kzg_commitment(kz.Blob(blobs[0]), settings)          # the lone-blob launch shape (two window parts)
-    assert one.to_bytes() == cs[0].to_bytes()
+    settings = _handle_with_env(kz, setup_bytes, KZG355_MSM_BITS="12", KZG355_MSM_GLV="off")
+    try:
+        cs = kz.Kzg.blob_to_kzg_commitment_many([kz.Blob(b) for b in blobs], settings)
+        assert settings.msm_shape()[:3] == (12, 22, 0)
+        for b, c in zip(blobs, cs):
+            assert c.to_bytes() == oracle.blob_to_kzg_commitment(b, oracle_settings)
+        ps = kz.Kzg.compute_blob_kzg_proof_many([kz.Blob(b) for b in blobs], cs, settings)
+        for b, c, p in zip(blobs, cs, ps):
+            assert p.to_bytes() == oracle.compute_blob_kzg_proof(b, c.to_bytes(), oracle_settings)
+        one = kz.Kzg.blob_to_kzg_commitment(kz.Blob(blobs[0]), settings)          # the lone-blob launch shape (two window parts)
+        assert one.to_bytes() == cs[0].to_bytes()
+    finally:
+        settings.free()
 
 
 def test_launch_shape_sweep(kz, settings):
@@ -634,11 +692,12 @@ def test_launch_shape_sweep(kz, settings):
     gen = torch.Generator(device=dev); gen.manual_seed(99)
     tb = torch.randint(0, 256, (NB, 4096, 32), dtype=torch.uint8, device=dev, generator=gen); tb[:, :, 0] = 0
     tb = tb.reshape(-1).contiguous()
+    torch.cuda.synchronize()                                    # (torch's stream is not ordered against the library's own streams: here and below)
     out = C.create_string_buffer(48 * NB); st = (C.c_int * NB)()
     assert L.kzg355_blob_to_kzg_commitment_many_device(out, st, tb.data_ptr(), NB, settings.handle) == 0
-    cs = out.raw; tc = torch.frombuffer(bytearray(cs), dtype=torch.uint8).to(dev)
+    cs = out.raw; tc = torch.frombuffer(bytearray(cs), dtype=torch.uint8).to(dev); torch.cuda.synchronize()
     assert L.kzg355_compute_blob_kzg_proof_many_device(out, st, tb.data_ptr(), tc.data_ptr(), NB, settings.handle) == 0
-    ps = out.raw; tp = torch.frombuffer(bytearray(ps), dtype=torch.uint8).to(dev)
+    ps = out.raw; tp = torch.frombuffer(bytearray(ps), dtype=torch.uint8).to(dev); torch.cuda.synchronize()
     for n in (1, 2, 15, 16, 17, 127, 128, 129, 1023, 1024, 1025):
         o2 = C.create_string_buffer(48 * n)
         assert L.kzg355_blob_to_kzg_commitment_many_device(o2, st, tb.data_ptr(), n, settings.handle) == 0 and o2.raw == cs[:48 * n], n
@@ -651,6 +710,7 @@ def test_launch_shape_sweep(kz, settings):
         if npg > 1:
             bad = tp.clone(); j = (npg * G - 1) * 48; k = (npg * (G - 1)) * 48
             tmp = bad[j:j + 48].clone(); bad[j:j + 48] = bad[k:k + 48]; bad[k:k + 48] = tmp
+            torch.cuda.synchronize()
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, tb.data_ptr(), tc.data_ptr(), bad.data_ptr(), npg, G, settings.handle)
             assert rc == 0 and [ok[i] for i in range(G)] == [True] * (G - 1) + [False], (npg, G)
 
@@ -965,6 +1025,7 @@ def test_device_entry_points_refuse_misaligned_pointers(kz, settings, random_set
     L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
     tb = torch.zeros(131072 * n + 64, dtype=torch.uint8, device=dev)
     tc = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev); tp = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
     ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
     assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr() + 4, tc.data_ptr(), tp.data_ptr(), n, 1, settings.handle) == 1
     out = C.create_string_buffer(48 * n); sts = (C.c_int * n)()
