@@ -206,6 +206,14 @@ int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_poi
                                               const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *s);
 int kzg355_verify_records_points_device(bool *ok, int *status, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups,
                                         const kzg355_settings *s);
+/* The same two calls with the per-batch results left ON THE DEVICE (int32 words, device memory, 4-byte aligned), for a caller that merges them
+ * across ranks with a collective and reads them back once (kzg_rust_amd/sharded.py): stage 1 writes d_status_words[g] = the KZG355 status of
+ * batch g on this rank's shard; stage 2 writes d_words[g] = 1 + ok + 256 * status.  Both return after their stream has been synchronised (the
+ * words may be read from any stream), and return only whole-call failures (KZG355_BADARGS for bad pointers, device errors). */
+int kzg355_verify_shard_records_points_words_device(uint8_t *d_records, uint8_t *d_points, int32_t *d_status_words, const uint8_t *d_blobs,
+                                                    const uint8_t *d_commitments, const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *s);
+int kzg355_verify_records_points_words_device(int32_t *d_words, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups,
+                                              const kzg355_settings *s);
 /* PRECONDITION: the records come from kzg355_verify_shard_records_device (here or on another rank) and every rank's stage-1
  * status has been merged into the verdict by the caller (kzg_rust_amd/sharded.py does): this entry point decompresses C_i and
  * proof_i WITHOUT the subgroup test and does not re-check that z_i, y_i are canonical -- stage 1 already did both.  A caller

@@ -82,6 +82,8 @@ def load():
         "kzg355_verify_collect": [vp, bp, ip],
         "kzg355_settings_msm_shape": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "kzg355_settings_build_msm_table": [vp],
+        "kzg355_verify_shard_records_points_words_device": [vp, vp, vp, vp, vp, vp, sz, sz, vp],
+        "kzg355_verify_records_points_words_device": [vp, vp, vp, sz, sz, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -118,4 +120,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_settings_set_host_hash", "kzg355_settings_host_hashed_calls", "kzg355_host_sha256", "kzg355_host_challenge_digests", "kzg355_debug_verify_host_records",
     "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex", "kzg355_debug_verify_sharded_intermediates",
     "kzg355_verify_blob_kzg_proof_batch_many_device_submit", "kzg355_verify_collect", "kzg355_settings_msm_shape", "kzg355_settings_build_msm_table",
+    "kzg355_verify_shard_records_points_words_device", "kzg355_verify_records_points_words_device",
 ]

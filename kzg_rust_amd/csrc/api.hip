@@ -1663,9 +1663,12 @@ int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out, int *status, const u
     return msm_op_many_device_impl(out, status, d_blobs, d_commitments, n, s);
 }
 
+// d_words (device, or null): the per-batch statuses are left on the device instead of being copied to `status` (host, then null)
 static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
-                              const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
-    if (!cs || !status) return KZG355_BADARGS;
+                              const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs, int32_t *d_words = nullptr) {
+    if (!cs || (!status && !d_words)) return KZG355_BADARGS;
+    std::vector<int> unused;
+    if (!status) { unused.assign(groups ? groups : 1, KZG355_OK); status = unused.data(); }
     for (size_t i = 0; i < groups; i++) status[i] = KZG355_OK;
     if (n_local == 0 || groups == 0) return KZG355_OK;
     // a refusal of the call as a whole writes nothing to d_records / d_points: every batch carries the status, so that a caller that
@@ -1686,6 +1689,14 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     // (no window shifts here: stage 2 runs on the gathered batch, on whichever rank gets it)
     if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, reinterpret_cast<G1Affine *>(d_points), w->err.as<int>(), false))) return rc;
     if ((rc = join_side(w))) return rc;
+    if (d_words) {                                                // statuses stay on the device: no copy back, the caller reads them after its merge
+        if ((uintptr_t)d_words & 3) return KZG355_BADARGS;
+        launch_status_words(w->err.as<int>(), nullptr, d_words, (int)groups, w->stream);
+        HIPCHK(hipStreamSynchronize(w->stream));
+        w->in_flight = false;
+        tm.collect();
+        return KZG355_OK;
+    }
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
     w->in_flight = false;
@@ -1702,6 +1713,11 @@ int kzg355_verify_shard_records_device(uint8_t *d_records, int *status, const ui
                                        const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
     return shard_records_impl(d_records, nullptr, status, d_blobs, d_commitments, d_proofs, n_local, groups, cs);
 }
+int kzg355_verify_shard_records_points_words_device(uint8_t *d_records, uint8_t *d_points, int32_t *d_status_words, const uint8_t *d_blobs,
+                                                    const uint8_t *d_commitments, const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
+    if (!d_points || !d_status_words) return KZG355_BADARGS;
+    return shard_records_impl(d_records, d_points, nullptr, d_blobs, d_commitments, d_proofs, n_local, groups, cs, d_status_words);
+}
 int kzg355_verify_shard_records_points_device(uint8_t *d_records, uint8_t *d_points, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
                                               const uint8_t *d_proofs, size_t n_local, size_t groups, const kzg355_settings *cs) {
     if (!d_points) return KZG355_BADARGS;
@@ -1712,8 +1728,8 @@ namespace {
 // stage 2 over gathered records; `dump` (host, groups*128 bytes or null) receives r | proof_lincomb | rhs per batch; d_points (or
 // null): the validated affine points of the records as stage 1 produced them ([batch][commitments, proofs]), sparing their decompression
 static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8_t *d_records, size_t n, size_t groups, int validate, const kzg355_settings *cs,
-                        const uint8_t *d_points = nullptr) {
-    if (!cs || !ok) return KZG355_BADARGS;
+                        const uint8_t *d_points = nullptr, int32_t *d_words = nullptr) {
+    if (!cs || (!ok && !d_words)) return KZG355_BADARGS;
     if (groups == 0) return KZG355_OK;
     auto refuse = [&](int code) { if (status) for (size_t i = 0; i < groups; i++) status[i] = code; return code; };      // whole-call refusals mark every batch
     if (n == 0) return refuse(KZG355_BADARGS);                   // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
@@ -1748,6 +1764,14 @@ static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8
         launch_dump_intermediates(w->scal_a.as<uint32_t>(), w->pair_pts.as<PairPt>(), (int)n, G, w->out48.as<uint8_t>(), w->stream);
         HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 128 * groups, hipMemcpyDeviceToHost, w->stream));
     }
+    if (d_words) {                                                // 1 + ok + 256 * status per batch, left on the device (the sharded path's all-reduce takes them from there)
+        if ((uintptr_t)d_words & 3) return KZG355_BADARGS;
+        launch_status_words(w->err.as<int>(), w->ok.as<int>(), d_words, G, w->stream);
+        HIPCHK(hipStreamSynchronize(w->stream));
+        w->in_flight = false;
+        tm.collect();
+        return KZG355_OK;
+    }
     HIPCHK(hipMemcpyAsync(w->h_ok.p, w->ok.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * groups, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
@@ -1771,6 +1795,10 @@ int kzg355_verify_records_device(bool *ok, int *status, const uint8_t *d_records
 int kzg355_verify_records_points_device(bool *ok, int *status, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups, const kzg355_settings *cs) {
     if (!d_points) return KZG355_BADARGS;
     return verify_records_impl(ok, status, nullptr, d_records, n, groups, 0, cs, d_points);
+}
+int kzg355_verify_records_points_words_device(int32_t *d_words, const uint8_t *d_records, const uint8_t *d_points, size_t n, size_t groups, const kzg355_settings *cs) {
+    if (!d_points || !d_words) return KZG355_BADARGS;
+    return verify_records_impl(nullptr, nullptr, nullptr, d_records, n, groups, 0, cs, d_points, d_words);
 }
 int kzg355_verify_records_checked_device(bool *ok, int *status, const uint8_t *d_records, size_t n, size_t groups, const kzg355_settings *cs) {
     return verify_records_impl(ok, status, nullptr, d_records, n, groups, 1, cs);

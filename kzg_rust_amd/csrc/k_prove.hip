@@ -161,6 +161,19 @@ __global__ void __launch_bounds__(64) k_fr_to_bytes(const Fr *in, int n, uint8_t
     for (int k = 0; k < 32; k++) out32[32 * (size_t)i + k] = b[k];
 }
 
+// Per-batch result words left ON the device for the sharded path (kzg_rust_amd/sharded.py merges them with one all-reduce and reads them back
+// once): ok == null: words[g] = status of batch g (KZG355_BADARGS if any error bit is set, else 0); else words[g] = 1 + ok + 256 * status.
+__global__ void __launch_bounds__(256) k_status_words(const int *err, const int *ok, int32_t *words, int groups) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const int st = err[g] ? 1 /* KZG355_BADARGS */ : 0;
+    words[g] = ok ? 1 + (ok[g] != 0 && st == 0 ? 1 : 0) + 256 * st : st;
+}
+void launch_status_words(const int *d_err, const int *d_ok, int32_t *d_words, int groups, hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_status_words, dim3((groups + 255) / 256), dim3(256), 0, st, d_err, d_ok, d_words, groups);
+}
+
 void launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, Fr *d_q, int *d_err, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_quotient, dim3(n), dim3(1024), 0, st, d_blobs, d_z, t.roots, d_y, d_q, d_err);

@@ -149,5 +149,6 @@ void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_
 void launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, Fr *d_q /* [n][4096] */, int *d_err, hipStream_t st);
 void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err /* per element, ERR_NONCANONICAL_FR */, hipStream_t st);
 void launch_fr_to_bytes(const Fr *d_in, int n, uint8_t *d_out32, hipStream_t st);
+void launch_status_words(const int *d_err, const int *d_ok /* or null */, int32_t *d_words, int groups, hipStream_t st);
 
 }  // namespace kzg

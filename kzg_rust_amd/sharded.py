@@ -58,6 +58,26 @@ class HipEngine:
             raise RuntimeError(f"kzg355_verify_shard_records_points_device: status {rc}")
         return rec, pts, st
 
+    # The same two stages with the per-batch results left on the device (int32 tensors): nothing is copied back between the stages and the
+    # collectives; a whole-call failure (a refused call, a device error) is folded into EVERY batch's word instead of being raised, so that
+    # all ranks go through the same collectives and see the failure together.
+    def shard_records_words(self, blobs, commitments, proofs, n_local, groups, words):
+        """stage 1; words (int32[groups], device): the KZG355 status of every batch on this rank's shard"""
+        import torch
+        rec = torch.empty(groups * n_local * RECORD, dtype=torch.uint8, device=blobs.device)
+        pts = torch.empty(groups * 2 * n_local * POINT, dtype=torch.uint8, device=blobs.device)
+        rc = self.L.kzg355_verify_shard_records_points_words_device(rec.data_ptr(), pts.data_ptr(), words.data_ptr(), blobs.data_ptr(), commitments.data_ptr(),
+                                                                    proofs.data_ptr(), n_local, groups, self.s.handle)
+        if rc != 0:
+            words.fill_(rc)
+        return rec, pts
+
+    def verify_records_words(self, records, points, n, groups, words):
+        """stage 2; words (int32[groups], device): 1 + ok + 256 * status of every batch"""
+        rc = self.L.kzg355_verify_records_points_words_device(words.data_ptr(), records.data_ptr(), points.data_ptr(), n, groups, self.s.handle)
+        if rc != 0:
+            words.fill_(1 + 256 * rc)
+
     def verify_records(self, records, points, n, groups):
         ok = (C.c_bool * max(groups, 1))()
         st = (C.c_int * max(groups, 1))()
@@ -134,6 +154,8 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         raise ValueError(f"exchange must be alltoall or allgather, not {mode!r}")
     dev = local_blobs.device
     t0 = time.perf_counter()
+    if hasattr(engine, "shard_records_words") and local_blobs.is_cuda and (world > 1 or (force_exchange and dist.is_initialized())):
+        return _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world)
     rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
     t0 = _tick(timings, "stage1_ms", t0)
     if world == 1 and not (force_exchange and dist.is_initialized()):      # (force_exchange: run the collectives of a one-rank group too -- test hook)
@@ -225,4 +247,79 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     st1, enc = code[:groups], code[groups:]
     status = np.where(st1 != 0, st1, enc >> 8)
     _tick(timings, "merge_ms", t0)
+    return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()
+
+
+def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world):
+    """The N > 1 path over an engine that leaves its per-batch results on the device (HipEngine): statuses and verdicts travel as int32 words in
+    device memory -- through the all-gather's buffer or the all-reduce -- and are read back ONCE, at the end; a failure of a whole engine call is
+    a status on every batch of that rank, seen by all ranks after the merge (nobody raises in the middle of a collective sequence).
+    Raises RuntimeError on every rank together when a merged status is a device-level failure (KZG355_NO_DEVICE and above)."""
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dev = local_blobs.device
+    rank = dist.get_rank(group)
+    on_host = _on_host(group)
+    rec_b, pts_b = n_local * RECORD, 2 * n_local * POINT
+    t0 = time.perf_counter()
+    # [0:G] stage-1 status of this rank's shard, [G:2G] 1 + ok + 256 * stage-2 status of this rank's share of the batches (0 elsewhere)
+    code = torch.zeros(2 * groups, dtype=torch.int32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()                   # the fill is on torch's stream, the engine writes on its own
+    rec, pts = engine.shard_records_words(local_blobs, local_commitments, local_proofs, n_local, groups, code[:groups])
+    t0 = _tick(timings, "stage1_ms", t0)
+
+    def collective(fn, out_numel, send, *splits):
+        if on_host:                                                # gloo: staged through host memory (CPU tests, rehearsals on one GPU)
+            host = torch.empty(out_numel, dtype=send.dtype)
+            fn(host, send.cpu(), *splits, group=group)
+            return host.to(dev)
+        got = torch.empty(out_numel, dtype=send.dtype, device=dev)
+        fn(got, send, *splits, group=group)
+        return got
+
+    if mode == "allgather":
+        send = torch.cat([rec, pts, code[:groups].view(torch.uint8)])
+        per = send.numel()
+        per_src = collective(dist.all_gather_into_tensor, world * per, send).view(world, per)
+        recs = per_src[:, :groups * rec_b].reshape(world, groups, rec_b).permute(1, 0, 2).contiguous().view(-1)
+        points = per_src[:, groups * rec_b:groups * (rec_b + pts_b)].reshape(world, groups, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
+        st1 = per_src[:, groups * (rec_b + pts_b):].contiguous().view(torch.int32).view(world, groups).max(dim=0).values
+        torch.cuda.synchronize(dev)                                # the permutes ran on torch's stream, the engine has its own
+        t0 = _tick(timings, "exchange_ms", t0)
+        engine.verify_records_words(recs, points, n_local * world, groups, code[groups:])      # every rank: all the batches
+        t0 = _tick(timings, "stage2_ms", t0)
+        merged = torch.cat([st1, code[groups:]]).cpu().numpy().astype(np.int64)                # the one read-back
+    else:
+        shares = [((groups * r) // world, (groups * (r + 1)) // world) for r in range(world)]
+        g_lo, g_hi = shares[rank]
+        mine = g_hi - g_lo
+        rec2, pts2 = rec.view(groups, rec_b), pts.view(groups, pts_b)
+        send = torch.cat([t for lo, hi in shares for t in (rec2[lo:hi].reshape(-1), pts2[lo:hi].reshape(-1))])
+        in_splits = [(hi - lo) * (rec_b + pts_b) for lo, hi in shares]
+        out_splits = [mine * (rec_b + pts_b)] * world
+        got = collective(dist.all_to_all_single, sum(out_splits), send, out_splits, in_splits)
+        if mine > 0:
+            per_src = got.view(world, mine * (rec_b + pts_b))      # from rank i: [records of my batches | points of my batches]
+            recs = per_src[:, :mine * rec_b].reshape(world, mine, rec_b).permute(1, 0, 2).contiguous().view(-1)
+            points = per_src[:, mine * rec_b:].reshape(world, mine, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
+            torch.cuda.synchronize(dev)
+            t0 = _tick(timings, "exchange_ms", t0)
+            engine.verify_records_words(recs, points, n_local * world, mine, code[groups + g_lo:groups + g_hi])
+            t0 = _tick(timings, "stage2_ms", t0)
+        else:
+            t0 = _tick(timings, "exchange_ms", t0, dev)
+        if on_host:
+            host = code.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+            merged = host.numpy().astype(np.int64)
+        else:
+            dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)    # verdicts of every share + status merge, one small collective on the device
+            merged = code.cpu().numpy().astype(np.int64)                # the one read-back
+    st1, enc = merged[:groups], merged[groups:]
+    status = np.where(st1 != 0, st1, enc >> 8)
+    _tick(timings, "merge_ms", t0)
+    if (status >= 6).any():                                        # KZG355_NO_DEVICE / NO_MEMORY / DEVICE_ERROR on some rank: every rank has the same merged words
+        raise RuntimeError(f"sharded verification: engine failure on a rank, merged per-batch statuses {sorted(set(status[status >= 6].tolist()))}")
     return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()

@@ -8,9 +8,9 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-C_SCALARS = {"int": "c_int", "long": "c_long", "size_t": "usize", "uint8_t": "u8", "bool": "bool", "char": "c_char", "double": "f64", "void": "void",
+C_SCALARS = {"int": "c_int", "long": "c_long", "size_t": "usize", "uint8_t": "u8", "int32_t": "i32", "bool": "bool", "char": "c_char", "double": "f64", "void": "void",
              "kzg355_settings": "kzg355_settings", "kzg355_options": "kzg355_options", "kzg355_ticket": "kzg355_ticket"}
-RUST_SCALARS = {"c_int", "c_long", "usize", "u8", "bool", "c_char", "f64", "kzg355_settings", "kzg355_options", "kzg355_ticket"}
+RUST_SCALARS = {"i32", "c_int", "c_long", "usize", "u8", "bool", "c_char", "f64", "kzg355_settings", "kzg355_options", "kzg355_ticket"}
 
 
 def strip_c_comments(text):
