@@ -74,7 +74,7 @@ OP_METRIC = {"verify": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, 
 KERNEL_NAMES = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets", "k_lc_carry"], "lincomb_prep": ["k_lc_prep"],
                 "lincomb_horner": ["k_lc_wsum", "k_lc_hchain_quad", "k_lc_horner"], "lincomb_shift": ["k_ps_shift"], "pairing": ["k_pairing_coop"], "validate_points": ["k_validate_points"], "rpowers": ["k_rhash_lanes", "k_rpowers"],
                 "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"],
-                "msm_wide": ["k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"], "msm_finalize": ["k_msm_finalize"]}
+                "msm_wide": ["k_msm_wide_glv<false>", "k_msm_wide_glv<true>", "k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"], "msm_finalize": ["k_msm_finalize"]}
 ALTERNATIVE_FORMS = ("challenge", "msm_bucket", "msm_wide")     # lists of alternative forms of one kernel, not sequences
 
 
@@ -454,8 +454,11 @@ def main():
                                   "source": "profiles/r03/gather_rate_random_128B.txt (11.1 G rows/s; streaming read of the same buffer: 5678 GB/s)"}
 
     host_inputs = None
+    mid_size = None
     if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
         host_inputs = host_leg(L, s, t_blobs, commitments, proofs, n_local, min(Cc, 1024))
+        if pipeline == 1 and Cc >= 1024 and not args.sharded_path:
+            mid_size = mid_size_leg(L, s, t_blobs, t_c, t_p, n_local)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
@@ -474,7 +477,7 @@ def main():
                        "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
-                       "host_inputs": host_inputs, "power": power},
+                       "host_inputs": host_inputs, "mid_size_sets": mid_size, "power": power},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if host_inputs:
@@ -483,6 +486,8 @@ def main():
             line["value_host_single_call"] = host_inputs["single_call_blobs_per_s"]      # one verify_blob_kzg_proof_batch(n = 64) on host slices (benches/kzg_benches.rs:113-120)
             line["single_call_ms"] = host_inputs["single_call_ms"]
             line["value_host_stream"] = host_inputs["stream_blobs_per_s"]               # many batches streamed from pageable host memory by one *_many call
+        if mid_size:
+            line["value_mid_size_sets_in_flight"] = mid_size["blobs_per_s"]              # 1024-batch sets, three in flight (config.mid_size_sets)
         if exchange_stats:
             line["config"]["exchange"] = exchange_stats
         print(json.dumps(line), flush=True)
@@ -553,6 +558,41 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
             "stream_h2d_gbps": round(statistics.median(rates) * (BLOB + 96) / 1e9, 2), "stream_blobs_per_call": nb,
             "note": "pageable caller memory -> HBM inside the call (the runtime locks the caller's pages and DMAs from them, 1 GiB chunks over 3 streams); never `value`.  "
                     "single_call = one verify_blob_kzg_proof_batch(n = 64) on host slices, the reference bench's own shape (benches/kzg_benches.rs:113-120)"}
+
+
+def mid_size_leg(L, s, t_blobs, t_c, t_p, n_local, g=1024, depth=3, steps=24):
+    """What a caller gets WITHOUT 69 GB resident per call: launch sets of 1024 batches (8.6 GB of blobs), three kept in flight by one host thread
+    through kzg355_verify_blob_kzg_proof_batch_many_device_submit / kzg355_verify_collect (stage 2 of a set runs beside the evaluation and point
+    kernels of the next one), next to the same sets one at a time through the synchronous call.  Reported in config.mid_size_sets; never `value`."""
+    slots = [((C.c_bool * g)(), (C.c_int * g)()) for _ in range(depth)]
+
+    def run(d, n_steps):
+        pending, free = [], list(slots)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            if d == 1:
+                ok, st = free[0]
+                rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
+                assert rc == 0 and bytes(ok)[:g] == b"\x01" * g
+                continue
+            tk = C.c_void_p()
+            rc = L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
+            assert rc == 0, rc
+            pending.append((tk, free.pop()))
+            if len(pending) >= d:
+                tk0, slot = pending.pop(0)
+                assert L.kzg355_verify_collect(tk0, slot[0], slot[1]) == 0 and bytes(slot[0])[:g] == b"\x01" * g
+                free.append(slot)
+        while pending:
+            tk0, slot = pending.pop(0)
+            assert L.kzg355_verify_collect(tk0, slot[0], slot[1]) == 0 and bytes(slot[0])[:g] == b"\x01" * g
+            free.append(slot)
+        return n_steps * g * n_local / (time.perf_counter() - t0)
+    run(1, 3); run(depth, 6)
+    one = run(1, steps)
+    piped = run(depth, steps)
+    return {"batches_per_set": g, "sets_in_flight": depth, "blobs_per_s": round(piped, 1), "blobs_per_s_one_set_at_a_time": round(one, 1), "steps": steps,
+            "note": "device-resident, 1024-batch launch sets (8.6 GB of blobs each) submitted and collected by one host thread; profiles/r04/pipeline_sweep.txt"}
 
 
 def newest_profile(stem, key, tag=None):
@@ -715,20 +755,33 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
     blobs = [bytes(host_blobs[i * BLOB:(i + 1) * BLOB]) for i in range(n)]
     cs = [commitments[48 * i:48 * i + 48] for i in range(n)]
     ps = [proofs[48 * i:48 * i + 48] for i in range(n)]
-    reps, t_total, units = 0, 0.0, 0
-    while t_total < 10.0 and reps < 200:
-        t0 = time.perf_counter()
-        if op == "verify":
-            assert o.verify_blob_kzg_proof_batch(blobs, cs, ps, so) is True
-            units += n
-        elif op == "commit":
-            assert o.blob_to_kzg_commitment(blobs[reps % n], so) == cs[reps % n]
-            units += 1
-        else:
-            assert o.compute_blob_kzg_proof(blobs[reps % n], cs[reps % n], so) == ps[reps % n]
-            units += 1
-        t_total += time.perf_counter() - t0
-        reps += 1
+    def one_core(seconds):
+        reps, t_total, units = 0, 0.0, 0
+        while t_total < seconds and reps < 200:
+            t0 = time.perf_counter()
+            if op == "verify":
+                assert o.verify_blob_kzg_proof_batch(blobs, cs, ps, so) is True
+                units += n
+            elif op == "commit":
+                assert o.blob_to_kzg_commitment(blobs[reps % n], so) == cs[reps % n]
+                units += 1
+            else:
+                assert o.compute_blob_kzg_proof(blobs[reps % n], cs[reps % n], so) == ps[reps % n]
+                units += 1
+            t_total += time.perf_counter() - t0
+            reps += 1
+        return reps, t_total, units
+    # Two forms of the port's hot primitives (oracle/bls12_381.c): portable C (__int128 products, C SHA-256) and -- when the -march=native build found
+    # BMI2 + ADX (+ SHA) on this host -- mulx / adcx / adox Montgomery products with SHA-extension hashing, the instruction mix of blst's assembly.
+    # `value` is the faster one: the stronger baseline is the honest one to quote.
+    fast = bool(getattr(o, "has_fast_primitives", False))
+    portable = None
+    if fast:
+        o.set_fast_primitives(False)
+        r0, t0_, u0 = one_core(5.0)
+        portable = u0 / t0_
+        o.set_fast_primitives(True)
+    reps, t_total, units = one_core(10.0)
     # the stronger baseline SURVEY 8(d) asks for: every core of this box's share, one batch (or blob) per thread
     # (ctypes releases the GIL; the oracle holds no mutable state in its settings)
     import threading
@@ -764,8 +817,10 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
     what = {"verify": "verify_blob_kzg_proof_batch(n=64) on the bench's first batch", "commit": "blob_to_kzg_commitment on blobs of the first batch",
             "proof": "compute_blob_kzg_proof on blobs of the first batch"}[op]
     return {"value": units / t_total, "unit": "blobs/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; restatement in portable C, not blst "
-                      f"(blst's asm is likely 1.5-3x faster per core)",
+            "sample": f"{reps} x {what}, oracle -O3 -march=native, {t_total:.1f} s; the builder's restatement of the reference's algorithm, not blst"
+                      + (": Montgomery products with mulx / adcx / adox, SHA-256 with the SHA extensions (the portable-C form of the same code: portable_c_value)" if fast else
+                         " (portable C: this host has no BMI2 + ADX; blst's asm is likely 1.5-3x faster per core)"),
+            "primitives": "mulx/adcx/adox + sha-ni" if fast else "portable C", "portable_c_value": portable,
             "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
                           "note": "same work, one call per thread, ~5 s per trial; best of the trials"}}
 

@@ -59,9 +59,85 @@ AINLINE void mod_sub(uint64_t *r, const uint64_t *a, const uint64_t *b, const ui
     uint64_t br = limbs_sub(r, a, b, n);
     if (br) limbs_add(r, r, m, n);
 }
+/* The same CIOS product with the multiplier kept in rdx (mulx) and two carry chains (adcx / adox): what hand-written field arithmetic of the blst class
+   does on CPUs with BMI2 + ADX.  Compiled in when the build machine has both (-march=native builds of liboracle_native.so: bench.py's cpu_baseline
+   leg) unless OKZG_NO_ADX is defined; bench.py reports both figures, so that "a port, not blst" becomes a measured bracket.
+   a: any n-limb value, b < m, as mont_mul. */
+#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__) && !defined(OKZG_NO_ADX)
+#define OKZG_HAVE_ADX 1
+#define OKZG_MAC_ROW4(ptr_, mult_, t0, t1, t2, t3, t4, t5) do { uint64_t lo_, hi_, z_; \
+    __asm__("xorq %[z], %[z]\n\t" \
+            "mulxq 0(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a0]\n\t adoxq %[hi], %[a1]\n\t" \
+            "mulxq 8(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a1]\n\t adoxq %[hi], %[a2]\n\t" \
+            "mulxq 16(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a2]\n\t adoxq %[hi], %[a3]\n\t" \
+            "mulxq 24(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a3]\n\t adoxq %[hi], %[a4]\n\t" \
+            "adcxq %[z], %[a4]\n\t adoxq %[z], %[a5]\n\t adcxq %[z], %[a5]" \
+            : [a0] "+r"(t0), [a1] "+r"(t1), [a2] "+r"(t2), [a3] "+r"(t3), [a4] "+r"(t4), [a5] "+r"(t5), [lo] "=&r"(lo_), [hi] "=&r"(hi_), [z] "=&r"(z_) \
+            : [p] "r"(ptr_), "d"(mult_) : "cc", "memory"); } while (0)
+static void mont_mul_adx4(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *m, const uint64_t inv) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, q;
+    OKZG_MAC_ROW4(a, b[0], t0, t1, t2, t3, t4, t5);
+    q = t0 * inv;
+    OKZG_MAC_ROW4(m, q, t0, t1, t2, t3, t4, t5);
+    OKZG_MAC_ROW4(a, b[1], t1, t2, t3, t4, t5, t0);
+    q = t1 * inv;
+    OKZG_MAC_ROW4(m, q, t1, t2, t3, t4, t5, t0);
+    OKZG_MAC_ROW4(a, b[2], t2, t3, t4, t5, t0, t1);
+    q = t2 * inv;
+    OKZG_MAC_ROW4(m, q, t2, t3, t4, t5, t0, t1);
+    OKZG_MAC_ROW4(a, b[3], t3, t4, t5, t0, t1, t2);
+    q = t3 * inv;
+    OKZG_MAC_ROW4(m, q, t3, t4, t5, t0, t1, t2);
+    uint64_t t[5] = {t4, t5, t0, t1, t2}, s[4];
+    uint64_t br = limbs_sub(s, t, m, 4);
+    if (t[4] || !br) memcpy(r, s, 8 * 4); else memcpy(r, t, 8 * 4);
+}
+#define OKZG_MAC_ROW6(ptr_, mult_, t0, t1, t2, t3, t4, t5, t6, t7) do { uint64_t lo_, hi_, z_; \
+    __asm__("xorq %[z], %[z]\n\t" \
+            "mulxq 0(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a0]\n\t adoxq %[hi], %[a1]\n\t" \
+            "mulxq 8(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a1]\n\t adoxq %[hi], %[a2]\n\t" \
+            "mulxq 16(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a2]\n\t adoxq %[hi], %[a3]\n\t" \
+            "mulxq 24(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a3]\n\t adoxq %[hi], %[a4]\n\t" \
+            "mulxq 32(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a4]\n\t adoxq %[hi], %[a5]\n\t" \
+            "mulxq 40(%[p]), %[lo], %[hi]\n\t adcxq %[lo], %[a5]\n\t adoxq %[hi], %[a6]\n\t" \
+            "adcxq %[z], %[a6]\n\t adoxq %[z], %[a7]\n\t adcxq %[z], %[a7]" \
+            : [a0] "+r"(t0), [a1] "+r"(t1), [a2] "+r"(t2), [a3] "+r"(t3), [a4] "+r"(t4), [a5] "+r"(t5), [a6] "+r"(t6), [a7] "+r"(t7), [lo] "=&r"(lo_), [hi] "=&r"(hi_), [z] "=&r"(z_) \
+            : [p] "r"(ptr_), "d"(mult_) : "cc", "memory"); } while (0)
+static void mont_mul_adx6(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *m, const uint64_t inv) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, q;
+    OKZG_MAC_ROW6(a, b[0], t0, t1, t2, t3, t4, t5, t6, t7);
+    q = t0 * inv;
+    OKZG_MAC_ROW6(m, q, t0, t1, t2, t3, t4, t5, t6, t7);
+    OKZG_MAC_ROW6(a, b[1], t1, t2, t3, t4, t5, t6, t7, t0);
+    q = t1 * inv;
+    OKZG_MAC_ROW6(m, q, t1, t2, t3, t4, t5, t6, t7, t0);
+    OKZG_MAC_ROW6(a, b[2], t2, t3, t4, t5, t6, t7, t0, t1);
+    q = t2 * inv;
+    OKZG_MAC_ROW6(m, q, t2, t3, t4, t5, t6, t7, t0, t1);
+    OKZG_MAC_ROW6(a, b[3], t3, t4, t5, t6, t7, t0, t1, t2);
+    q = t3 * inv;
+    OKZG_MAC_ROW6(m, q, t3, t4, t5, t6, t7, t0, t1, t2);
+    OKZG_MAC_ROW6(a, b[4], t4, t5, t6, t7, t0, t1, t2, t3);
+    q = t4 * inv;
+    OKZG_MAC_ROW6(m, q, t4, t5, t6, t7, t0, t1, t2, t3);
+    OKZG_MAC_ROW6(a, b[5], t5, t6, t7, t0, t1, t2, t3, t4);
+    q = t5 * inv;
+    OKZG_MAC_ROW6(m, q, t5, t6, t7, t0, t1, t2, t3, t4);
+    uint64_t t[7] = {t6, t7, t0, t1, t2, t3, t4}, s[6];
+    uint64_t br = limbs_sub(s, t, m, 6);
+    if (t[6] || !br) memcpy(r, s, 8 * 6); else memcpy(r, t, 8 * 6);
+}
+#endif
+int okzg_use_adx = 1;     /* run-time switch between the two forms (okzg_set_adx): bench.py times both */
 /* CIOS Montgomery multiplication: r = a*b/2^(64n) mod m.  a may be any n-limb value, b < m. */
 AINLINE void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *m,
                       const uint64_t inv, const int n) {
+#ifdef OKZG_HAVE_ADX
+    if (okzg_use_adx) {
+        if (n == 4) { mont_mul_adx4(r, a, b, m, inv); return; }
+        if (n == 6) { mont_mul_adx6(r, a, b, m, inv); return; }
+    }
+#endif
     uint64_t t[8] = {0};
     for (int i = 0; i < n; i++) {
         u128 c = 0;
@@ -618,10 +694,59 @@ static void sha256_block(uint32_t st[8], const uint8_t *blk) {
     }
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
+#if defined(__x86_64__) && defined(__SHA__) && defined(__SSE4_1__) && defined(__SSSE3__) && !defined(OKZG_NO_ADX)
+#include <immintrin.h>
+#define OKZG_HAVE_SHANI 1
+/* The same compression with the SHA extensions (one message; part of the "blst-class" form of the baseline: blst hashes with them too).
+   sha256rnds2 works on the state as (A,B,E,F) / (C,D,G,H); W_G = msg2(msg1(W_{G-4}, W_{G-3}) + alignr(W_{G-1}, W_{G-2}, 4), W_{G-1}). */
+static void sha256_blocks_shani(uint32_t st[8], const uint8_t *p, size_t nblocks) {
+    const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i abcd = _mm_loadu_si128((const __m128i *)&st[0]), efgh = _mm_loadu_si128((const __m128i *)&st[4]);
+    abcd = _mm_shuffle_epi32(abcd, 0xB1);                       /* b a d c */
+    efgh = _mm_shuffle_epi32(efgh, 0x1B);                       /* h g f e */
+    __m128i s0 = _mm_alignr_epi8(abcd, efgh, 8);                /* (A,B,E,F) */
+    __m128i s1 = _mm_blend_epi16(efgh, abcd, 0xF0);             /* (C,D,G,H) */
+    for (size_t b = 0; b < nblocks; b++, p += 64) {
+        const __m128i k0 = s0, k1 = s1;
+        __m128i w[4];
+        for (int q = 0; q < 4; q++) w[q] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * q)), bswap);
+        for (int g = 0; g < 16; g++) {
+            if (g >= 4) {
+                __m128i x = _mm_sha256msg1_epu32(w[g & 3], w[(g + 1) & 3]);
+                x = _mm_add_epi32(x, _mm_alignr_epi8(w[(g + 3) & 3], w[(g + 2) & 3], 4));
+                w[g & 3] = _mm_sha256msg2_epu32(x, w[(g + 3) & 3]);
+            }
+            __m128i m = _mm_add_epi32(w[g & 3], _mm_loadu_si128((const __m128i *)&K256[4 * g]));
+            s1 = _mm_sha256rnds2_epu32(s1, s0, m);
+            m = _mm_shuffle_epi32(m, 0x0E);
+            s0 = _mm_sha256rnds2_epu32(s0, s1, m);
+        }
+        s0 = _mm_add_epi32(s0, k0); s1 = _mm_add_epi32(s1, k1);
+    }
+    const __m128i t = _mm_shuffle_epi32(s0, 0x1B), u = _mm_shuffle_epi32(s1, 0xB1);
+    _mm_storeu_si128((__m128i *)&st[0], _mm_blend_epi16(t, u, 0xF0));
+    _mm_storeu_si128((__m128i *)&st[4], _mm_alignr_epi8(u, t, 8));
+}
+#endif
+/* 1 if this build has the mulx / adcx / adox field products (and the SHA extensions): okzg_set_adx switches them on and off at run time */
+int okzg_have_adx(void) {
+#ifdef OKZG_HAVE_ADX
+    return 1;
+#else
+    return 0;
+#endif
+}
+void okzg_set_adx(int on) { okzg_use_adx = on != 0; }
+static void sha256_blocks(uint32_t st[8], const uint8_t *p, size_t nblocks) {
+#ifdef OKZG_HAVE_SHANI
+    if (okzg_use_adx) { sha256_blocks_shani(st, p, nblocks); return; }
+#endif
+    for (size_t i = 0; i < nblocks; i++) sha256_block(st, p + 64 * i);
+}
 void sha256(uint8_t out[32], const uint8_t *msg, size_t len) {
     uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     size_t full = len / 64;
-    for (size_t i = 0; i < full; i++) sha256_block(st, msg + 64 * i);
+    sha256_blocks(st, msg, full);
     uint8_t tail[128] = {0};
     size_t rem = len - 64 * full;
     memcpy(tail, msg + 64 * full, rem);
@@ -629,8 +754,7 @@ void sha256(uint8_t out[32], const uint8_t *msg, size_t len) {
     size_t tl = rem + 9 <= 64 ? 64 : 128;
     uint64_t bits = (uint64_t)len * 8;
     for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
-    sha256_block(st, tail);
-    if (tl == 128) sha256_block(st, tail + 64);
+    sha256_blocks(st, tail, tl / 64);
     for (int i = 0; i < 8; i++) { out[4 * i] = st[i] >> 24; out[4 * i + 1] = st[i] >> 16; out[4 * i + 2] = st[i] >> 8; out[4 * i + 3] = st[i]; }
 }
 

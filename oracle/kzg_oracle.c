@@ -471,6 +471,12 @@ EXPORT void okzg_get_g1_values(uint8_t *out, const okzg_settings *s) { for (int 
 EXPORT void okzg_init(void) { bls_init(); }
 EXPORT int okzg_field_elements_per_blob(void) { return N_FE; }
 EXPORT void okzg_sha256(uint8_t out[32], const uint8_t *msg, size_t len) { sha256(out, msg, len); }
+/* The -march=native build on a CPU with BMI2 + ADX (+ SHA) carries a second form of the hot primitives: mulx / adcx / adox Montgomery products and
+   SHA-256 with the SHA extensions (bls12_381.c).  have: is it in this build; set: switch it at run time (bench.py's cpu_baseline times both). */
+int okzg_have_adx(void);
+void okzg_set_adx(int on);
+EXPORT int okzg_have_fast_primitives(void) { return okzg_have_adx(); }
+EXPORT void okzg_set_fast_primitives(int on) { okzg_set_adx(on); }
 EXPORT int okzg_fp_op(int op, uint8_t out[48], const uint8_t a[48], const uint8_t b[48]) {
     bls_init(); fp_t x, y, r;
     if (!fp_from_be(&x, a) || !fp_from_be(&y, b)) return BADARGS;

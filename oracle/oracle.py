@@ -34,6 +34,14 @@ def _load(native=False, preset="mainnet"):
 
 
 class Oracle:
+    @property
+    def has_fast_primitives(self):
+        """the loaded build carries the mulx / adcx / adox field products and SHA-extension hash (liboracle_native.so on a CPU that has them)"""
+        return bool(self.lib.okzg_have_fast_primitives())
+
+    def set_fast_primitives(self, on):
+        self.lib.okzg_set_fast_primitives(1 if on else 0)
+
     def __init__(self, native=False, preset="mainnet"):
         """preset "mainnet": FIELD_ELEMENTS_PER_BLOB = 4096; "minimal": 4 (the same source built with -DN_FE=4)."""
         self.lib = _load(native, preset)

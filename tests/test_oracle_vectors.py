@@ -37,3 +37,22 @@ def test_batch64_fixture_consistent_with_oracle(oracle, oracle_settings):
     a, b = fx["swapped_pair"]
     ps[a], ps[b] = ps[b], ps[a]
     assert oracle.verify_blob_kzg_proof_batch(blobs, cs, ps, oracle_settings) is False
+
+
+def test_fast_primitive_form_of_the_port_is_pinned_by_the_same_vectors(golden_vectors, golden_blobs, setup_bytes):
+    """The -march=native build of the oracle (bench.py's cpu_baseline) carries a second form of its hot primitives on CPUs with BMI2 + ADX (+ SHA):
+    mulx / adcx / adox Montgomery products and SHA-extension hashing (oracle/bls12_381.c).  Whatever this host's build contains, it passes the
+    reference's 208 vectors with the fast form switched on and again with it switched off."""
+    from oracle.oracle import Oracle, build
+    build(native=True)
+    o = Oracle(native=True)
+    s = o.load_trusted_setup(*setup_bytes)
+    try:
+        for on in ([True, False] if o.has_fast_primitives else [False]):
+            o.set_fast_primitives(on)
+            for fn, want in EXPECTED_COUNTS.items():
+                n, failures = run_function(fn, golden_vectors, o, s, golden_blobs)
+                assert n == want and not failures, (on, fn, failures[:3])
+    finally:
+        o.set_fast_primitives(True)
+        o.free_trusted_setup(s)

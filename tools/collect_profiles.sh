@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence of a round on the GPU box: kernel-trace stats and the three counter passes (separately, as
 # MI355X_MICROARCH.md prescribes) over the same bench.py command, plus the secondary bench lines.  usage: collect_profiles.sh rNN vK
 set -u
-R=${1:-r02}; V=${2:-v1}
+R=${1:-r04}; V=${2:-v1}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
