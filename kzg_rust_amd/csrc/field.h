@@ -200,10 +200,13 @@ template <int N> KZG_HD void mont_mul_lazy(uint32_t *r, const uint32_t *a, const
     }
 }
 // r = (a*b + c*d) / R, lazily: two products share one Montgomery reduction (2N^2 + N^2 limb products instead of 4N^2).
-// Operands as for mont_mul_lazy with (a*b + c*d) < ~5 m^2; the column sums stay below 2^64 for N <= 9 limbs of 29 bits.
+// Operands as for mont_mul_lazy with (a*b + c*d) < ~5 m^2 (N = 9) / < 2^6 m * 2^6 m in all (N = 14).  Column sums: an accumulator collects at most
+// N rounds of three limb products (a_j b_i, c_j d_i, q m_j), each below 2^58 for limbs below 2^29 (the top limb of a lazy value is smaller still),
+// plus carries below 2^36: 3 * 14 * 2^58 < 2^63.4 -- inside 64 bits up to N = 14 PROVIDED every limb below the top one is normalised (< 2^29),
+// which is what fp_sub_lz / fp_add_lz / the lazy products leave.
 template <int N> KZG_HD void mont_mul2_lazy(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d,
                                             const uint32_t *m, const uint32_t inv) {
-    static_assert(N <= 9, "column accumulators sized for at most 9 limbs");
+    static_assert(N <= 14, "column accumulators: 3 N limb products of < 2^58 must stay below 2^64");
     uint64_t acc[N];
 #pragma unroll
     for (int j = 0; j < N; j++) acc[j] = 0;
@@ -307,6 +310,9 @@ KZG_HD void fp_sqr(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP>(r.l, a.l, F
 // MSM / bucket kernels (g1x_add_mixed_lazy), which spend ~15 % of a canonical addition in those subtractions and selects.
 KZG_HD void fp_mul_lz(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul_lazy<NFP>(r.l, a.l, b.l, FP_MOD, FP_INVW); }
 KZG_HD void fp_sqr_lz(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP, true>(r.l, a.l, FP_MOD, FP_INVW); }
+// r = (a b + c d) / R, lazily, ONE Montgomery reduction for the two products (588 limb products instead of 784).  Operands normalised lazy values
+// with a b + c d < 2^12 p^2 (e.g. a < 6p, b < 10p, c < 4p, d < 2p in the point additions); result < p (1 + 2^-13).
+KZG_HD void fp_mul2_lz(Fp &r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) { KZG_FP_CONSTS mont_mul2_lazy<NFP>(r.l, a.l, b.l, c.l, d.l, FP_MOD, FP_INVW); }
 // r = a + (kp - b), kp a multiple of p above b: limbs normalised (signed carries), the top limb keeps the excess
 KZG_HD void fp_sub_lz(Fp &r, const Fp &a, const Fp &b, const uint32_t *kp) {
     int32_t c = 0;

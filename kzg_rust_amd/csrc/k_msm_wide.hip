@@ -17,6 +17,7 @@
 //                               flight, then shuffle butterfly + LDS sum of the workgroup
 // The result is the same group element blst's Pippenger returns, hence the same 48 bytes (utils.rs:221-227).
 #define KZG_MID_INLINE 1
+#define KZG_G1_ADD_MUL2 1       // the accumulation's Y3 as two products under one reduction (g1.h g1x_add_mixed_lazy)
 #include "kernels.h"
 #include "fr_block.h"
 

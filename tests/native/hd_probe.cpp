@@ -1,6 +1,7 @@
 // Host build (g++) of the DEVICE math headers under kzg_rust_amd/csrc, exposed through a tiny C ABI so
 // that tests/test_device_math_host.py can compare them with the CPU oracle on the build box (no GPU).
 // Test infrastructure only: this file is never part of libkzg355.so.
+#define KZG_G1_ADD_MUL2 1      // the fixed-base MSM's form of the lazy mixed addition (two products under one reduction); the other form is the batch linear combination's, checked on the GPU
 #include "../../kzg_rust_amd/csrc/field.h"
 #include "../../kzg_rust_amd/csrc/tower.h"
 #include "../../kzg_rust_amd/csrc/g1.h"
