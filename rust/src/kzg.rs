@@ -92,6 +92,8 @@ impl KzgSettings {
         Ok(Self { raw })
     }
 
+    /// Defaults of every engine knob (`kzg355_options_default`).  E.g. `o.verify_only = 1` for a handle that never builds the MSM table,
+    /// `o.msm_bits = 16` for the widest one (143.5 GB), `o.msm_eager = 1` to build it inside the load instead of on the first commitment.
     pub fn default_options() -> ffi::kzg355_options {
         let mut o = std::mem::MaybeUninit::<ffi::kzg355_options>::zeroed();
         unsafe {

@@ -476,6 +476,51 @@ def test_msm_bucket_form_matches_wide_table_form(kz, setup_bytes, settings, rand
             s.free()
 
 
+def test_first_commitments_from_several_threads_build_the_table_once(kz, setup_bytes, random_set):
+    """The MSM table is built by the first commitment / proof call on a handle (std::call_once): four threads making their first calls together on
+    a fresh handle all get the oracle's bytes, the table exists afterwards, a handle that only verified has none, and kzg355_settings_build_msm_table
+    builds it ahead of any call."""
+    import threading
+    blobs, cs, ps = random_set
+    B = [kz.Blob(b) for b in blobs]
+    s = _handle_with_env(kz, setup_bytes, KZG355_MSM_BITS="12")
+    try:
+        assert s.msm_shape() == (0, 0, 0, 0) and s.msm_form == 12
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, [kz.KzgCommitment(c) for c in cs], [kz.KzgProof(p) for p in ps], s) is True
+        assert s.msm_shape() == (0, 0, 0, 0)
+        out, gate = [None] * 4, threading.Barrier(4)
+
+        def work(k):
+            gate.wait()
+            if k % 2:
+                out[k] = kz.Kzg.compute_blob_kzg_proof(B[k], kz.KzgCommitment(cs[k]), s).to_bytes()
+            else:
+                out[k] = kz.Kzg.blob_to_kzg_commitment(B[k], s).to_bytes()
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert out == [cs[0], ps[1], cs[2], ps[3]]
+        assert s.msm_shape()[:3] == (12, 11, 1) and s.msm_shape()[3] == 128 * 4096 * (10 * 2048 + 256)
+    finally:
+        s.free()
+    s = _handle_with_env(kz, setup_bytes, KZG355_MSM_BITS="13")
+    try:
+        s.build_msm_table()
+        assert s.msm_shape()[:3] == (13, 10, 1)
+        assert kz.Kzg.blob_to_kzg_commitment(B[5], s).to_bytes() == cs[5]
+    finally:
+        s.free()
+    s = _handle_with_env(kz, setup_bytes, KZG355_VERIFY_ONLY="1")
+    try:
+        s.build_msm_table()                                       # nothing to build: the bucket form by request
+        assert s.msm_form == 8 and s.msm_shape() == (0, 0, 0, 0)
+        assert kz.Kzg.blob_to_kzg_commitment(B[6], s).to_bytes() == cs[6]
+    finally:
+        s.free()
+
+
 @pytest.mark.parametrize("bits", [12, 13, 15, 16])
 def test_glv_table_digit_extremes(bits, kz, setup_bytes, oracle, oracle_settings):
     """Scalars k = a + b x^2 whose HALVES hit the corners of the signed recoding of the GLV tables: every window of a half at 2^(bits-1)
