@@ -471,7 +471,9 @@ def main():
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
             "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
-                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, all-to-all of 160-B records"),
+                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
+                                      + ("all-to-all of the 160-B records + decoded points (stage 2 split by batch)" if args.exchange == "alltoall" else
+                                         "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)")),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
                        "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
