@@ -1005,7 +1005,8 @@ def test_overlapped_launch_sets_keep_order(kz, setup_bytes, random_set):
         s.free()
 
 
-def test_submit_collect_keeps_sets_apart(kz, settings, random_set):
+@pytest.mark.parametrize("mode", ["by-size", "pipeline", "sets"])
+def test_submit_collect_keeps_sets_apart(mode, kz, setup_bytes, random_set):
     """kzg355_verify_blob_kzg_proof_batch_many_device_submit / kzg355_verify_collect: one thread keeps four launch sets in flight on four
     streams of the handle (sets of 5, 3, 1 and 4 batches with a false verdict, an Err and an honest set among them) and collects them out of
     order: every verdict and status lands at its set's batch index; an empty set and a zero-blob set answer without a device; a misaligned
@@ -1013,6 +1014,17 @@ def test_submit_collect_keeps_sets_apart(kz, settings, random_set):
     import torch
     blobs, cs, ps = random_set
     n = len(blobs)
+    # by-size: these small sets go each to the stream of its own workspace; pipeline: the two-stage software pipeline large sets take (stage 2 of a
+    # set queued behind the next set's hash, or by its collect), forced here on small ones; sets: form 1 forced
+    settings = _handle_with_env(kz, setup_bytes, KZG355_VERIFY_ONLY="1", **({} if mode == "by-size" else {"KZG355_SUBMIT": mode}))
+    try:
+        _submit_collect_body(kz, settings, blobs, cs, ps, n)
+    finally:
+        settings.free()
+
+
+def _submit_collect_body(kz, settings, blobs, cs, ps, n):
+    import torch
     L = kz.kzg.lib(); dev = torch.device("cuda", settings.device)
     sizes = [5, 3, 1, 4]
     sets = []
