@@ -217,6 +217,7 @@ struct kzg355_settings {
     hipStream_t pipe_main = nullptr, pipe_tail = nullptr;         // submit / collect: stage 1 of every submitted set in order on pipe_main, stage 2 on pipe_tail
     std::mutex pipe_mu;                                           // orders the submits / collects that queue work on the two
     struct kzg355_ticket *pending_tail = nullptr;                 // the submitted set whose stage 2 is not queued yet (it goes out behind the next set's hash)
+    std::atomic<int> tickets_out{0};                              // submitted and not yet collected (freeing the handle then is the caller's bug: the device is drained first)
     bool own_side_streams = true;    // side streams per workspace (round 4; KZG355_SIDE=shared: one pair per handle, round 3's form) -- measured with
                                      // 4 threads of n = 64 calls: median call 5.0-7.9 ms shared, 3.6-5.2 ms own (4 hardware queues), 2.5-3.9 ms own with 8 queues
     std::atomic<int> calls_in_flight{0};   // host-buffer calls inside host_pipeline right now
@@ -1440,6 +1441,10 @@ static void free_single(kzg355_settings *s) {
     if (!s) return;
     DeviceScope scope;
     (void)scope.enter(s->device);
+    if (s->tickets_out.load() > 0) {          // a caller's bug (kzg355.h: collect every ticket first); at least nothing may still be running on what is freed below
+        fprintf(stderr, "kzg355: handle freed with %d submitted launch set(s) not collected: their tickets are now invalid\n", s->tickets_out.load());
+        (void)hipDeviceSynchronize();
+    }
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
     if (s->side_stream) { (void)hipStreamDestroy(s->side_stream); s->side_stream = nullptr; }
@@ -1582,6 +1587,7 @@ int kzg355_verify_blob_kzg_proof_batch_many_device_submit(kzg355_ticket **ticket
         if (rc == KZG355_OK && hipEventRecord(w->ev_done, w->stream) != hipSuccess) rc = KZG355_DEVICE_ERROR;
         if (rc) return fail(rc);
         t->tail_queued = true;
+        s->tickets_out++;
         *ticket = t.release();
         return KZG355_OK;
     }
@@ -1612,6 +1618,7 @@ int kzg355_verify_blob_kzg_proof_batch_many_device_submit(kzg355_ticket **ticket
         return fail(rc);
     }
     s->pending_tail = t.get();
+    s->tickets_out++;
     *ticket = t.release();
     return KZG355_OK;
 }
@@ -1625,6 +1632,7 @@ int kzg355_verify_collect(kzg355_ticket *ticket, bool *ok, int *status) {
         return KZG355_OK;
     }
     kzg355_settings *s = t->s; Workspace *w = t->w;
+    s->tickets_out--;
     DeviceScope scope;
     const bool entered = scope.enter(s->device);
     int rc = !entered ? KZG355_NO_DEVICE : KZG355_OK;
