@@ -114,6 +114,8 @@ typedef struct kzg355_options {
     int msm_glv;               /* 0 (default): scalars are split k = a + b x^2 and the table spans 128 bits (half the memory per window width);
                                   -1: round 3's form, windows over all 256 bits (12 .. 15 bits: 23.6 / 42.9 / 81.6 / 154.6 GB)     KZG355_MSM_GLV=off */
     int msm_eager;             /* 1: build the table inside the load call instead of on first use                        KZG355_MSM_EAGER=1 */
+    int pairing_hard12_from;   /* batches per launch set from which the hard part of the final exponentiation runs twelve lanes per check, five checks per
+                                  wave (throughput) instead of one wave per check (latency); 0 = 16 per CU; -1 never                KZG355_PAIRING_HARD12_FROM */
     int submit_sets;           /* submit / collect: 0 by size (sets of <= 128 blobs per CU as 1, larger ones as 2); 1 = every submitted set on a stream of its
                                   own; 2 = two-stage pipeline: stage 1 of the submitted sets in order on one stream, stage 2 of a set on a second
                                   one, queued behind the NEXT set's Fiat-Shamir kernel                                   KZG355_SUBMIT=sets|pipeline */

@@ -84,7 +84,7 @@ struct Workspace {
     // work on the side streams that the main stream has not waited for yet: everything (ev_join: the validation verdicts are in the error
     // words), the decoded points alone (ev_pts; recorded only when they are ready before the verdicts), the window shifts (ev_shift)
     bool side_pending = false, pts_pending = false, shift_pending = false;
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests, zpow;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, pair_f, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests, zpow;
     bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
     PinBuf h_ok, h_err, h_out, h_digests, h_records, h_rdig;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
@@ -106,7 +106,7 @@ struct Workspace {
         in_flight = false; side_pending = false; pts_pending = false; shift_pending = false; shift_ready = false;
     }
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow}) b->release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &pair_f, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift, ev_stage, ev_done, ev_fork2}) if (e) (void)hipEventDestroy(e);
@@ -211,6 +211,7 @@ struct kzg355_settings {
     int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
     int cu_count = 256;            // compute units of the device: the thresholds above and below are multiples of it (load_on_device)
     int pairing_two_wave_upto = 256;     // batches per launch set up to which a pairing runs its two Miller loops on two waves (1 per CU)
+    int pairing_hard12_from = 4096;      // batches per launch set from which the final exponentiation's hard part runs twelve lanes per check (16 per CU; KZG355_PAIRING_HARD12_FROM, 0: never)
     int challenge_two_wave_upto = 32768; // blobs per launch set up to which the Fiat-Shamir hash runs as producer / consumer wave pairs (2 workgroups per CU)
     std::mutex mu;
     hipStream_t side_stream = nullptr, side2_stream = nullptr;   // shared by the workspaces (point validation / window shifts of small calls next to the main chain)
@@ -540,7 +541,11 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     tm.end();
     tm.begin("pairing");
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
-    else launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream, s->pairing_two_wave_upto);
+    else {
+        Fp *f12 = nullptr;
+        if (s->pairing_hard12_from > 0 && groups >= s->pairing_hard12_from && w->pair_f.ensure(pairing_f12_bytes(groups)) == KZG355_OK) f12 = w->pair_f.as<Fp>();
+        launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream, s->pairing_two_wave_upto, f12, s->pairing_hard12_from);
+    }
     tm.end();
     return KZG355_OK;
 }
@@ -1038,6 +1043,8 @@ void kzg355_options_from_env(kzg355_options *o) {
         if (got >= 1 && a >= 1 && a <= 64) o->split_parts = a;
         if (got >= 2 && b >= 1 && b <= 8) o->split_streams = b;
     }
+    num("KZG355_PAIRING_HARD12_FROM", 0, 1 << 24, &o->pairing_hard12_from);
+    if (getenv("KZG355_PAIRING_HARD12_FROM") && o->pairing_hard12_from == 0) o->pairing_hard12_from = -1;      // "0": never
     num("KZG355_LC_CHAIN_FROM", 1, 1 << 24, &o->lc_chain_from);
     num("KZG355_RHASH_LANES_FROM", 1, 1 << 24, &o->rhash_lanes_from);
     if (const char *e = getenv("KZG355_CHALLENGE")) o->challenge_form = strcmp(e, "1w") == 0 ? 1 : strcmp(e, "2w") == 0 ? 2 : 0;
@@ -1106,7 +1113,9 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
     }
     {
         static CoopInsn prog[COOP_PROGRAM_MAX];
-        const int n = build_pairing_program(prog);
+        int hard_start = 0;
+        const int n = build_pairing_program(prog, &hard_start);
+        s->t.pairing_hard_start = hard_start;
         if (n > COOP_PROGRAM_MAX || s->prog.ensure(sizeof(CoopInsn) * n)) return fail(KZG355_INTERNAL);
         if (hipMemcpy(s->prog.p, prog, sizeof(CoopInsn) * n, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
         s->t.pairing_prog = s->prog.as<CoopInsn>();
@@ -1143,6 +1152,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         s->rhash_lanes_from = opt.rhash_lanes_from > 0 ? opt.rhash_lanes_from : 4 * cus;     // transcript hash with a lane per batch from one wave per SIMD on (1024)
         s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
         s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;     // two waves per pairing up to 256 batches
+        s->pairing_hard12_from = opt.pairing_hard12_from < 0 ? 0 : opt.pairing_hard12_from > 0 ? opt.pairing_hard12_from : 16 * cus;   // hard part twelve lanes per check from 4096 batches on
         s->challenge_two_wave_upto = 2 * cus * 64;                                           // two-wave hash while every wave has a SIMD to itself (512 workgroups of 64 blobs)
     }
     s->lane_pairing = opt.pairing_lane != 0;

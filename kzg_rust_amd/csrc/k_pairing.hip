@@ -3,6 +3,7 @@
 // (pairing_coop.h).  ~20x shorter dependent chain than the one-lane-per-batch kernel in k_verify.hip.
 #define KZG_FP_MUL_NOINLINE 1   // tower routines out of line: the interpreter bodies stay small (fully inlined, the kernel was ~6x larger and 25 % slower: 6.4 vs 4.85 ms per 2048 batches)
 #include "kernels.h"
+#include "pairing_lanes.h"
 
 namespace kzg {
 
@@ -11,9 +12,11 @@ namespace kzg {
 // latency-bound kernel gets a SIMD to itself as long as groups <= 1024.  (With one-wave workgroups the placement was left
 // to the dispatcher: 4.1 ms on a good day, 6.1 ms when two waves shared a SIMD -- same wave-cycles, same clocks.)
 constexpr int PAIRING_WAVES = 4;
+// f_out (or null): stop after instruction n_insn - 1 and hand slot F over (12 coefficients per batch) instead of deciding the verdict: with many
+// batches per launch set the hard part of the final exponentiation runs in k_pairing_hard12, twelve lanes per check.
 __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairPt *pair_pts, int groups,
                                                                       const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
-                                                                      const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok) {
+                                                                      const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok, Fp *f_out) {
     __shared__ CoopMem mems[PAIRING_WAVES];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g_raw = blockIdx.x * PAIRING_WAVES + wid;
@@ -25,8 +28,29 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairP
     // ML([tau]G2, -proof_lincomb) * ML(G2, rhs): lines_w[2] = setup g2[1] = [tau]G2, lines_w[0] = G2 generator
     coop_init(mem, scheds, p1, p2);
     coop_run(mem, prog, 0, n_insn, lines_w + 2 * N_LINES, lines_w, use1, use2, *frob);
+    if (f_out) {
+        if (lane < 12) { Fp c; fp_norm_lz(c, mem.f.c[lane]); fp_canon64(c, c); f_out[12 * (size_t)g + lane] = c; }      // canonical: within the next kernel's invariant
+        return;
+    }
     const bool r = coop_is_one(mem, mem.t0);
     if (lane == 0) ok[g] = r ? 1 : 0;
+}
+
+// The hard part of the final exponentiation for many batches: twelve lanes per check, five checks per wave (pairing_lanes.h).  f_in: slot F of
+// every batch as k_pairing_coop left it; prog[pc0 .. pc1): the tail of the pairing program; verdict = (slot T0 == 1).
+constexpr int HARD12_WAVES = 4;
+__global__ void __launch_bounds__(64 * HARD12_WAVES) k_pairing_hard12(const Fp *f_in, int groups, const FrobTables *frob, const CoopInsn *prog, int pc0, int pc1, int *ok) {
+    __shared__ L12Mem mems[HARD12_WAVES * L12_BATCHES];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / 12, k = lane % 12;
+    const int g_raw = (blockIdx.x * HARD12_WAVES + wid) * L12_BATCHES + grp;
+    const int g = g_raw < groups ? g_raw : groups - 1;               // a tail group redoes the last batch (no out-of-range loads) and reports nothing
+    L12Mem &m = mems[wid * L12_BATCHES + (grp < L12_BATCHES ? grp : 0)];
+    if (lane < 60) m.s[S_F].c[k] = f_in[12 * (size_t)g + k];
+    L12_SYNC();
+    l12_run(m, prog, pc0, pc1, *frob);
+    const bool one = lane < 60 ? l12_coeff_is_one(m.s[S_T0], k) : true;
+    const unsigned long long all = __ballot(one);
+    if (lane < 60 && k == 0 && g_raw < groups) ok[g] = (((all >> (12 * grp)) & 0xfffull) == 0xfffull) ? 1 : 0;
 }
 
 // Few batches (latency): the two Miller loops of a check on TWO waves of one workgroup, each with its own f and only its own pair's
@@ -64,13 +88,16 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
     lines_w[i] = o;
 }
 
-void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st, int two_wave_upto) {
+// d_f12 (or null): groups * 12 Fp of scratch; with it and at least hard12_from batches the check is two kernels -- Miller loops and easy part wave-
+// cooperatively, then the hard part twelve lanes per check (k_pairing_hard12)
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st, int two_wave_upto, Fp *d_f12, int hard12_from) {
     if (groups <= 0) return;
     if (groups <= two_wave_upto) {          // two waves per batch while that still leaves most SIMDs a single wave
         hipLaunchKernelGGL(k_pairing_coop2, dim3(groups), dim3(128), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog,
                            t.pairing_prog_len, t.coop_scheds, d_ok);
         return;
     }
+    const bool split = d_f12 && hard12_from > 0 && groups >= hard12_from && t.pairing_hard_start > 0;
     const int wgs = (groups + PAIRING_WAVES - 1) / PAIRING_WAVES;
     // pad the LDS request so that no more than ceil(wgs / 256) workgroups fit on a CU: an even spread by construction
     const int per_cu = (wgs + 255) / 256;
@@ -80,8 +107,14 @@ void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d
     if (want > fixed && want - fixed < 64 * 1024) pad = want - fixed;
     else if (want > fixed) pad = 64 * 1024 - 1024;
     hipLaunchKernelGGL(k_pairing_coop, dim3(wgs), dim3(64 * PAIRING_WAVES), pad, st, d_pair_pts, groups, t.lines_w, t.lines_inf,
-                       t.frob, t.pairing_prog, t.pairing_prog_len, t.coop_scheds, d_ok);
+                       t.frob, t.pairing_prog, split ? t.pairing_hard_start : t.pairing_prog_len, t.coop_scheds, d_ok, split ? d_f12 : nullptr);
+    if (split) {
+        const int per_wg = HARD12_WAVES * L12_BATCHES;
+        hipLaunchKernelGGL(k_pairing_hard12, dim3((groups + per_wg - 1) / per_wg), dim3(64 * HARD12_WAVES), 0, st, d_f12, groups, t.frob, t.pairing_prog,
+                           t.pairing_hard_start, t.pairing_prog_len, d_ok);
+    }
 }
+size_t pairing_f12_bytes(int groups) { return sizeof(Fp) * 12 * (size_t)(groups > 0 ? groups : 1); }
 void launch_lines_to_w(DeviceTables t, hipStream_t st) {
     hipLaunchKernelGGL(k_lines_to_w, dim3(1), dim3(256), 0, st, t.lines, t.lines_w, 3 * N_LINES);
 }

@@ -64,6 +64,7 @@ struct DeviceTables {
     FrobTables *frob;        // w-basis Frobenius tables
     CoopInsn *pairing_prog;  // the pairing check as an instruction list (pairing_coop.h)
     int pairing_prog_len;
+    int pairing_hard_start;  // index of the first instruction of the final exponentiation's hard part (k_pairing_hard12 runs the tail)
     CoopScheds *coop_scheds; // product, square, line-product and cyclotomic-square work schedules
 };
 
@@ -115,7 +116,9 @@ void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                                int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st);
 void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st,
-                    int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */);        // wave-cooperative (default)
+                    int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */,
+                    Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */, int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */);
+size_t pairing_f12_bytes(int groups);
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 
 // ---- k_pairing.hip

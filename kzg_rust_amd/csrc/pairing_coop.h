@@ -546,7 +546,9 @@ enum : uint8_t { S_F = 0, S_T0 = 1, S_T1 = 2, S_T2 = 3, S_T3 = 4, S_T4 = 5, S_L0
 constexpr int COOP_PROGRAM_MAX = 1024;
 constexpr int COOP_LINE_CHUNK = 5;       // line steps evaluated at once inside the Miller loop: 5 steps x 2 pairs x 6 coefficients = 60 lanes, 60 Fp = the slots t0 .. t4
 
-inline int build_pairing_program(CoopInsn *p) {
+// hard_start (or null): receives the index of the first instruction of the hard part of the final exponentiation -- from there on the program only
+// uses the slots F, T0, T1, T2 and the operations COPY, CYC_SQR, MUL, CONJ, FROB1, FROB2 (pairing_lanes.h runs that tail twelve lanes per check)
+inline int build_pairing_program(CoopInsn *p, int *hard_start = nullptr) {
     int n = 0;
     auto emit = [&](uint8_t op, uint8_t d, uint8_t a, uint8_t b) { p[n].op = op; p[n].dst = d; p[n].a = a; p[n].b = b; n++; };
     auto cyc_exp_x = [&](uint8_t d, uint8_t a) {           // d = a^x (x < 0), a in the cyclotomic subgroup: square-and-multiply over |x|, then conjugate
@@ -572,6 +574,7 @@ inline int build_pairing_program(CoopInsn *p) {
     emit(OP_MUL, S_T4, S_F, S_T0); emit(OP_FP6INV, S_T4, S_T4, 0); emit(OP_MUL_EVEN, S_T1, S_T0, S_T4);
     emit(OP_MUL, S_F, S_T0, S_T1);                                                    // ^(p^6-1)
     emit(OP_FROB2, S_T0, S_F, 0); emit(OP_MUL, S_F, S_T0, S_F);                               // ^(p^2+1)
+    if (hard_start) *hard_start = n;
     cyc_exp_x(S_T1, S_F); emit(OP_CONJ, S_T0, S_F, 0); emit(OP_MUL, S_T1, S_T1, S_T0);        // a = f^(x-1)
     cyc_exp_x(S_T2, S_T1); emit(OP_CONJ, S_T0, S_T1, 0); emit(OP_MUL, S_T1, S_T2, S_T0);      // a = a^(x-1)
     cyc_exp_x(S_T2, S_T1); emit(OP_FROB1, S_T0, S_T1, 0); emit(OP_MUL, S_T2, S_T2, S_T0);     // b = a^(x+p)

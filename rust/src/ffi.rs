@@ -49,6 +49,7 @@ pub struct kzg355_options {
     pub verify_only: c_int,
     pub msm_glv: c_int,
     pub msm_eager: c_int,
+    pub pairing_hard12_from: c_int,
     pub submit_sets: c_int,
 }
 

@@ -8,6 +8,7 @@
 #include "../../kzg_rust_amd/csrc/pairing.h"
 #include "../../kzg_rust_amd/csrc/sha256.h"
 #include "../../kzg_rust_amd/csrc/pairing_coop.h"
+#include "../../kzg_rust_amd/csrc/pairing_lanes.h"
 #include "../../kzg_rust_amd/csrc/eval_core.h"
 #include <vector>
 #include <cstring>
@@ -288,6 +289,46 @@ int hd_pairings_verify_coop_proj(int *ok, const uint8_t *p1, const uint8_t *q1, 
     *ok = coop_is_one(*m0, m0->t0) ? 1 : 0;
     delete m0; delete m1;
     return 0;
+}
+// The pairing check with the hard part of the final exponentiation run twelve lanes per check (pairing_lanes.h) behind the cooperative Miller loops
+// and easy part.  Returns 0 and the verdict; 4 if any coefficient of the hard part's result differs (as a field element) from the cooperative run's.
+int hd_pairings_verify_lanes12(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {
+    G1Affine a, b; G2Affine qa, qb;
+    if (g1_decompress(a, p1) || g1_decompress(b, p2) || g2_decompress(qa, q1) || g2_decompress(qb, q2)) return 1;
+    std::vector<LineCoeff> l1(N_LINES), l2(N_LINES);
+    std::vector<LineW> w1(N_LINES), w2(N_LINES);
+    if (!g2a_is_inf(qa)) precompute_lines(l1.data(), qa);
+    if (!g2a_is_inf(qb)) precompute_lines(l2.data(), qb);
+    for (int i = 0; i < N_LINES; i++) { line_to_w(w1[i], l1[i]); line_to_w(w2[i], l2[i]); }
+    PairPt pa, pb; pairpt_from_affine(pa, a); pairpt_from_affine(pb, b);
+    { Fp ny; fp_neg(ny, pa.ay); pa.ay = ny; }                         // e(a, qa) e(b, qb) == 1 with the first point negated, as the other probes do
+    const bool use1 = !fp_is_zero(pa.az) && !g2a_is_inf(qa), use2 = !fp_is_zero(pb.az) && !g2a_is_inf(qb);
+    static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
+    FrobTables ft;
+    for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
+    static CoopInsn prog[COOP_PROGRAM_MAX];
+    int hard = 0;
+    const int n_insn = build_pairing_program(prog, &hard);
+    static CoopScheds sc;
+    if (!build_coop_schedules(sc) || hard <= 0 || hard >= n_insn) return 3;
+    CoopMem *m = new CoopMem();
+    coop_init(*m, &sc, pa, pb);
+    coop_run(*m, prog, 0, hard, w1.data(), w2.data(), use1, use2, ft);
+    L12Mem *lm = new L12Mem();
+    for (int k = 0; k < 12; k++) { Fp c; fp_norm_lz(c, m->f.c[k]); fp_canon64(c, c); lm->s[0].c[k] = c; }      // the hand-over: canonical coefficients
+    l12_run(*lm, prog, hard, n_insn, ft);
+    coop_run(*m, prog, hard, n_insn, w1.data(), w2.data(), use1, use2, ft);
+    int rc = 0;
+    bool one = true;
+    for (int k = 0; k < 12; k++) {
+        Fp x, y; fp_norm_lz(x, m->t0.c[k]); fp_canon64(x, x); fp_norm_lz(y, lm->s[1].c[k]); fp_canon64(y, y);
+        if (!fp_eq(x, y)) rc = 4;
+        one = one && l12_coeff_is_one(lm->s[1], k);
+    }
+    *ok = one ? 1 : 0;
+    if (rc == 0 && one != coop_is_one(*m, m->t0)) rc = 5;
+    delete m; delete lm;
+    return rc;
 }
 // W = sum_b b * B_b over 16 buckets the way k_lc_wsum does it: every bucket sum B_b = P_{2(b-1)} + P_{2(b-1)+1} accumulated in lazy
 // extended-Jacobian coordinates (g1x_add_mixed_lazy), then acc += B_b; W += acc for b = 16 .. 1 with the lazy XYZZ + XYZZ addition.

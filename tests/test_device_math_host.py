@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
@@ -202,10 +202,14 @@ def test_g2_decompress_and_pairing(hd, oracle, setup_bytes):
         assert bool(ok.value) == want
         assert hd.hd_pairings_verify_coop(C.byref(ok), p1, qa, p2, qb) == 0      # wave-cooperative variant
         assert bool(ok.value) == want
+        rc = hd.hd_pairings_verify_lanes12(C.byref(ok), p1, qa, p2, qb)          # hard part of the final exponentiation twelve lanes per check (pairing_lanes.h):
+        assert rc == 0, rc                                                       # every coefficient of its result equals the cooperative run's
+        assert bool(ok.value) == want
     # bilinearity: e([a]G, [tau]G2) == e([a][tau]... ) cannot be formed without tau; use e(aG, Q) == e(G, Q)^a via
     # e([a]G, Q) == e([a]G, Q) (true) and e([a]G, Q) == e([a+1]G, Q) (false)
     a1G = oracle.g1_mul_add(G1_GEN, ((a + 1) % R).to_bytes(32, "big"))
     assert hd.hd_pairings_verify(C.byref(ok), aG, q1, a1G, q1) == 0 and ok.value == 0
+    assert hd.hd_pairings_verify_lanes12(C.byref(ok), aG, q1, a1G, q1) == 0 and ok.value == 0
 
 
 def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_blobs):
