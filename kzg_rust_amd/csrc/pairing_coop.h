@@ -586,6 +586,8 @@ inline int build_pairing_program(CoopInsn *p, int *hard_start = nullptr) {
     return n;
 }
 
+// the slots t0 .. t4 as one row of 60 field elements (the Miller loop parks its line evaluations there; f, t0 .. t4 are laid out contiguously)
+KZG_HD Fp *coop_line_buf(CoopMem &m) { return reinterpret_cast<Fp *>(&m.t0); }
 KZG_HD Fp12W &coop_slot(CoopMem &m, int s) {
     Fp12W *base = &m.f;                          // f, t0..t4, line[0], line[1] are laid out contiguously
     return base[s];
@@ -632,7 +634,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
             const Fp *bs = mask != LINE_MASK ? nullptr                                     // the line as its six evaluated coefficients:
                            : pre ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6      // all made ahead of the loop (two-wave kernel)
-                                 : m.t0.c + ((cur_line % COOP_LINE_CHUNK) * 2 + (in.op == OP_MUL_LINE1 ? 1 : 0)) * 6;      // or five steps at a time (OP_LINE_EVAL)
+                                 : coop_line_buf(m) + ((cur_line % COOP_LINE_CHUNK) * 2 + (in.op == OP_MUL_LINE1 ? 1 : 0)) * 6;      // or five steps at a time (OP_LINE_EVAL)
             if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask, bs);
             continue;
         }
@@ -654,7 +656,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
                         const LineW &L = q == 0 ? lines1[n + c] : lines2[n + c];
                         const Fp *coef = &L.l0 + e;                                         // l0, l6, l2, l8, l3, l9
                         const Fp *arg = e < 2 ? &m.pz[q] : e < 4 ? &m.px[q] : &m.py[q];     // * Z^3, Z^3, X Z, X Z, Y, Y
-                        fp_mul(m.t0.c[lane], *coef, *arg);                                  // straight into LDS: no temporary on the private stack
+                        fp_mul(coop_line_buf(m)[lane], *coef, *arg);                        // straight into LDS: no temporary on the private stack
                     }
                 }
                 COOP_SYNC();
