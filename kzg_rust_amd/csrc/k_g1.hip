@@ -553,6 +553,32 @@ __device__ __forceinline__ int ps_point_of_item(int j, int n) {
     const int t = j >> 1;
     return t < n ? n + t : t < 2 * n ? n + (t - n) : t < 3 * n ? t - 2 * n : 2 * n;
 }
+// Sums with "no term yet" as a flag instead of the point at infinity (see k_ps_buckets): acc (+)= o where `have` / `ho` say which of the two
+// hold a sum.  The quad addition always runs (every lane takes part in its DPP moves) -- on fixed stand-ins for an absent operand, G and
+// phi(G) = (beta x_G, y_G): two points that differ and are not each other's negatives, so the stand-in addition never takes the rare path.
+struct PsDummies { G1Jac a, b; };
+__device__ __forceinline__ PsDummies ps_dummies() {
+    const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT, bc[NFP] = FP_BETA_INIT;
+    PsDummies d;
+    Fp beta;
+    for (int i = 0; i < NFP; i++) { d.a.x.l[i] = gx[i]; d.a.y.l[i] = gy[i]; beta.l[i] = bc[i]; }
+    d.a.z = fp_one();
+    d.b = d.a;
+    fp_mul(d.b.x, d.a.x, beta);
+    return d;
+}
+__device__ __forceinline__ void g1_select(G1Jac &r, bool take_b, const G1Jac &a, const G1Jac &b) {
+    fp_select(r.x, take_b, a.x, b.x); fp_select(r.y, take_b, a.y, b.y); fp_select(r.z, take_b, a.z, b.z);
+}
+__device__ __forceinline__ void ps_add_present(G1Jac &acc, bool &have, const G1Jac &o, bool ho, const PsDummies &dum, int role) {
+    G1Jac a2, b2, t;
+    g1_select(a2, have, dum.a, acc);
+    g1_select(b2, ho, dum.b, o);
+    g1_add_quad(t, a2, b2, role);
+    g1_select(t, !ho, t, acc);                                    // both present: the sum; only acc: acc
+    g1_select(acc, have, o, t);                                   // acc absent: o (itself absent -- the point at infinity -- when ho is false)
+    have = have || ho;
+}
 // One 256-thread workgroup per (batch, class, bucket): 64 DPP quads, each an accumulator of its own (g1_add_quad: an addition five
 // products deep instead of sixteen).  A quad takes entries q, q + 64, ... of the bucket's list (~6.5 at n = 64), the 16 quads of a wave
 // are summed by a shuffle butterfly (4 levels), the four waves through LDS (2 levels): ~13 quad additions in a row where the
@@ -562,6 +588,7 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
     __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15 of this bucket; sized for every pair of the class landing here (27 KB)
     __shared__ int cnt;
     __shared__ G1Jac wsum[4];
+    __shared__ int whave[4];
     const int bk = blockIdx.x % LC_BUCKETS, gc = blockIdx.x / LC_BUCKETS, g = gc >> 1, cls = gc & 1, tid = threadIdx.x;
     const int role = tid & 3, quad = tid >> 2, lane = tid & 63, wid = tid >> 6;
     const int ni = lc_items(n), lo = cls == 0 ? 0 : 2 * n, hi = cls == 0 ? 2 * n : ni;      // the class's items (terms t < n are class 0)
@@ -594,43 +621,53 @@ __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, 
     };
     // ONE loop with ONE inlined instance of the addition (hipcc 7.2 has miscompiled kernels with several inlined instances of the G1
     // routines in a row): the operand of a step is, in turn, the quad's next list entry (steps 0 .. rounds - 1;
-    // infinity once its share is used up), the partner quad's sum in the wave (4 butterfly steps), and -- behind a workgroup barrier --
+    // none once its share is used up), the partner quad's sum in the wave (4 butterfly steps), and -- behind a workgroup barrier --
     // the wave sums: quads 0, 1 of every wave add (w0 + w1), (w2 + w3), then their sum.
+    // A sum that has no term yet (every accumulator at step 0, a quad whose share is used up, ...) is NOT carried as the point at infinity:
+    // g1_add_quad sends an operand at infinity through the complete addition on the whole wave (~3x an addition; at n = 64 that was step 0 and
+    // the last list step of every workgroup: 40 of the kernel's 144 us).  `have` / `ho` say whether acc / o hold a sum; an absent operand is
+    // replaced by a fixed point (G, phi(G)) and the result of that addition is dropped.
     const int rounds = (c + PS_QUADS - 1) / PS_QUADS;             // the same for every thread of the workgroup
+    const PsDummies dum = ps_dummies();
     G1Jac acc = g1_inf();
+    bool have = false;
 #pragma unroll 1
     for (int step = 0; step < rounds + 6; step++) {
         G1Jac o = g1_inf();
+        bool ho = false;
         if (step < rounds) {
             const int q = quad + step * PS_QUADS;
-            if (q < c) { const uint32_t v = list[q]; o = fetch(lo + (int)(v & 0x3ff), (int)((v >> 10) & 31), (v & 0x8000) != 0); }
+            if (q < c) { const uint32_t v = list[q]; o = fetch(lo + (int)(v & 0x3ff), (int)((v >> 10) & 31), (v & 0x8000) != 0); ho = true; }
         } else if (step < rounds + 4) {
-            o = g1_shfl_xor(acc, 4 << (step - rounds));
+            o = g1_shfl_xor(acc, 4 << (step - rounds)); ho = __shfl_xor((int)have, 4 << (step - rounds)) != 0;
         } else if (step == rounds + 4) {
-            if (lane == 0) wsum[wid] = acc;
+            if (lane == 0) { wsum[wid] = acc; whave[wid] = have ? 1 : 0; }
             __syncthreads();                                      // (uniform: every thread reaches this step)
-            acc = wsum[2 * (quad & 1)]; o = wsum[2 * (quad & 1) + 1];
+            acc = wsum[2 * (quad & 1)]; have = whave[2 * (quad & 1)] != 0; o = wsum[2 * (quad & 1) + 1]; ho = whave[2 * (quad & 1) + 1] != 0;
         } else {
-            o = g1_shfl_xor(acc, 4);
+            o = g1_shfl_xor(acc, 4); ho = __shfl_xor((int)have, 4) != 0;
         }
-        g1_add_quad(acc, acc, o, role);
+        ps_add_present(acc, have, o, ho, dum, role);
     }
-    if (tid == 0) { g1_canon_lazy(acc, acc); S[(size_t)gc * LC_BUCKETS + bk].jac = acc; }
+    if (tid == 0) { g1_canon_lazy(acc, acc); S[(size_t)gc * LC_BUCKETS + bk].jac = acc; }      // (no term at all: acc is still the point at infinity)
 }
 // The weights of the bucket sums, one wave per (batch, class): quad b of the wave holds S_{b+1};  sum_b b * S_b = sum_k T_k with the suffix
 // sums T_k = sum_{b >= k} S_b (as in k_lc_horner): 4-step suffix scan + 4-step butterfly of quad additions, to the pairing's form.
 __global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, PairPt *pair_pts) {
     const int gc = blockIdx.x, lane = threadIdx.x, role = lane & 3, bi = lane >> 2;
     G1Jac r = S[(size_t)gc * LC_BUCKETS + bi].jac;
-    // one loop, one inlined addition (see k_ps_buckets): steps 0..3 the suffix scan (a quad keeps the sum only while a partner exists),
-    // steps 4..7 the butterfly
+    bool hr = !fp_is_zero(r.z);                                   // (canonical: an empty bucket is the point at infinity)
+    const PsDummies dum = ps_dummies();
+    // one loop, one inlined addition (see k_ps_buckets): steps 0..3 the suffix scan (a quad adds only while a partner exists: without one the
+    // shuffle hands it its own sum, and P + P went through the complete addition on the whole wave -- 80 of the kernel's 161 us), steps 4..7
+    // the butterfly
 #pragma unroll 1
     for (int step = 0; step < 8; step++) {
         const int off = 1 << (step & 3);
         const G1Jac o = step < 4 ? g1_shfl_down_w(r, 4 * off) : g1_shfl_xor(r, 4 * off);
-        G1Jac t;
-        g1_add_quad(t, r, o, role);
-        if (step >= 4 || bi + off < LC_BUCKETS) r = t;
+        bool ho = (step < 4 ? __shfl_down((int)hr, 4 * off, 64) : __shfl_xor((int)hr, 4 * off)) != 0;
+        if (step < 4 && bi + off >= LC_BUCKETS) ho = false;
+        ps_add_present(r, hr, o, ho, dum, role);
     }
     if (lane != 0) return;
     g1_canon_lazy(r, r);
@@ -730,15 +767,17 @@ void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *
     const int total = ps_points(n_per_group) * groups;
     hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, (const G1Affine *)nullptr, d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
 }
+// stage 0: everything; 1: the digits only (needs the decoded points and the r powers, not the shift table); 2: the sums
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
-                               int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st) {
+                               int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
     G1Affine *items = reinterpret_cast<G1Affine *>(d_scratch);          // same scratch layout as the bucket form (lincomb_buckets_scratch_bytes)
     LcSlot *S = reinterpret_cast<LcSlot *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
-    hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    if (stage == 1) return;
     hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * LC_BUCKETS), dim3(PS_THREADS), 0, st, d_shifts, d_pts, digits, n_per_group, S);
     hipLaunchKernelGGL(k_ps_weights, dim3(2 * groups), dim3(64), 0, st, S, groups, d_pair_pts);
 }

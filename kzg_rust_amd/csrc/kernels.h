@@ -114,7 +114,7 @@ void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups,
 // the same chains straight from the compressed inputs (x only: they do not wait for the square root of the decompression)
 void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                               int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st);
+                               int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage = 0 /* 1: digits only; 2: sums only */);
 void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st,
                     int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */,
                     Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */, int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */);
