@@ -268,12 +268,11 @@ union LcSlot { G1X raw; G1Jac jac; };
 // One 256-thread workgroup per batch -- one wave per SIMD of the CU (one-wave workgroups of long chains get placed unevenly, see
 // k_pairing.hip), each with its own slice of the LDS arrays; the waves only meet at workgroup barriers that all four reach
 // the same number of times.
-__global__ void __launch_bounds__(256, 2) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, LcSlot *S, uint16_t *glists, int keep_raw) {
+__global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const int8_t *digits, int n, LcSlot *S, uint16_t *glists, int keep_raw) {
     __shared__ uint16_t lists_all[4][LC_TASKS * LC_LDS_LIST];
     __shared__ int cnt_all[4][LC_TASKS][LC_BUCKETS + 1], cursor_all[4][LC_TASKS][LC_BUCKETS + 1];
     __shared__ uint8_t order_all[4][LC_BUCKETS * LC_TASKS];
     __shared__ uint8_t seq_all[4][64][LC_MAX_LISTS];
-    __shared__ uint4 stash_all[4][7][64];            // one point (112 bytes) per lane, 16-byte pieces lane-major: the operand of the lane's next addition
     const int g = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n1 = lc_wave_n1(wid), c1w0 = lc_wave_c1w0(wid), c0w0 = lc_wave_c0w0(wid);
     constexpr int ntasks = LC_TASKS, nlists = LC_BUCKETS * LC_TASKS;
@@ -309,20 +308,19 @@ __global__ void __launch_bounds__(256, 2) k_lc_buckets(const G1Affine *items, co
     }
     __syncthreads();
     // deal: rank i to lane i, then every further list to the least loaded lane (ties: lowest lane)
-    // (a list of len entries costs its lane len - 1 additions: its first entry only sets the accumulator, see the walk below)
-    int total = 0, load = 0, nmine = 0;
+    int total = 0, nmine = 0;
     {
         const int L = order[lane], len = len_of(L);
-        if (len > 0) { seq[lane][0] = (uint8_t)L; total = len; load = len > 1 ? len - 1 : 1; nmine = 1; }
+        if (len > 0) { seq[lane][0] = (uint8_t)L; total = len; nmine = 1; }
     }
 #pragma unroll 1
     for (int r = 64; r < nlists; r++) {
         const int L = order[r], len = len_of(L);                 // the same for every lane
         if (len == 0) break;
-        int key = nmine >= LC_MAX_LISTS ? 0x7fffffff : (load << 6) | lane;
+        int key = nmine >= LC_MAX_LISTS ? 0x7fffffff : (total << 6) | lane;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(key, off); key = v < key ? v : key; }
-        if (lane == (key & 63) && nmine < LC_MAX_LISTS) { seq[lane][nmine++] = (uint8_t)L; total += len; load += len > 1 ? len - 1 : 1; }
+        if (lane == (key & 63) && nmine < LC_MAX_LISTS) { seq[lane][nmine++] = (uint8_t)L; total += len; }
     }
     int lane_start = total;                           // exclusive prefix sum over the lanes
 #pragma unroll
@@ -344,72 +342,34 @@ __global__ void __launch_bounds__(256, 2) k_lc_buckets(const G1Affine *items, co
     }
     __threadfence_block();                       // the global-slab form of the lists is read back by other lanes of this wave
     __syncthreads();
-    int kmax = nmine;
+    int tmax = total, kmax = nmine;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int u = __shfl_xor(kmax, off); kmax = u > kmax ? u : kmax; }
+    for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(tmax, off), u = __shfl_xor(kmax, off); tmax = v > tmax ? v : tmax; kmax = u > kmax ? u : kmax; }
     {
         G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
-        // One ADDITION per step and lane.  The first entry of a list only sets the accumulator, which costs nothing -- but in lockstep it used to
-        // cost the lane a whole step (3.25 lists per lane on ~39 entries).  Now the step in which a list ends also takes the first entry of the
-        // next one: its point is loaded into registers during the addition, and the operand of the NEXT step -- two entries ahead -- comes through
-        // a one-point LDS stash filled by global -> LDS loads (no registers: the kernel sits at its 256).  Every step's operand goes that way.
+        // the list entry two steps ahead and the point one step ahead are in flight during an addition (with the lists in the
+        // global slab each step would otherwise wait for two dependent loads)
         const uint16_t *lst = lists + lane_start;
         auto entry = [&](int q) -> uint32_t { return q < total ? (in_lds ? (uint32_t)lst[q] : (uint32_t)__builtin_nontemporal_load(lst + q)) : 0u; };
-        uint4 (*stash)[64] = stash_all[wid];
-        auto stash_fetch = [&](uint32_t v) {         // the point of entry v on its way to this lane's stash slot (index 0 past the end: a harmless in-range load)
-            const char *src = reinterpret_cast<const char *>(it + (v & 0x7fff));
-#pragma unroll
-            for (int c = 0; c < 7; c++)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + 16 * c), (void __attribute__((address_space(3))) *)&stash[c][0], 16, 0, 0);
-        };
-        auto begin_list = [&](G1Affine &pi, uint32_t v) {      // accumulator := the list's first point
-            if (v & 0x8000) fp_neg(pi.y, pi.y);
-            if (!g1a_is_inf(pi)) { accx.x = pi.x; accx.y = pi.y; accx.zz = fp_one(); accx.zzz = fp_one(); started = true; }
-        };
+        uint32_t v0 = entry(0), v1 = entry(1);
+        G1Affine pn = it[v0 & 0x7fff];
         int k = 0, cur = nmine ? (int)seq[lane][0] : 0, end = nmine ? len_of(cur) : 0;      // current list and the position after its last entry
-        auto park = [&]() {                          // the current list is complete: park the raw accumulator, move on to the next list
-            if (!started) accx = g1x_inf();          // (nothing added, or the items cancelled out: all-zero limbs, which g1x_is_inf sees after canonicalisation)
-            out[slot_of(cur)].raw = accx;
-            started = false;
-            k++;
-            if (k < nmine) { cur = seq[lane][k]; end += len_of(cur); }
-        };
-        int q = 0;                                   // this lane's next entry
-        uint32_t v0 = entry(0), v1 = entry(1), v2 = entry(2);
-        if (end >= 2) {                              // the lane's first list starts for free as well (a list of ONE entry is left to the loop: its
-            G1Affine p0 = it[v0 & 0x7fff];           // first entry is its last, and the accumulator is parked in one place only, behind an addition step)
-            begin_list(p0, v0);
-            v0 = v1; v1 = v2; v2 = entry(3); q = 1;
-        }
-        stash_fetch(v0);
 #pragma unroll 1
-        for (;;) {
-            const bool active = q < total;
-            if (!__any(active)) break;
-            __builtin_amdgcn_s_waitcnt(0);           // the stash has landed
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (active) {
-                G1Affine p;
-                {
-                    uint32_t w[28];
-#pragma unroll
-                    for (int c = 0; c < 7; c++) { const uint4 x = stash[c][lane]; w[4 * c] = x.x; w[4 * c + 1] = x.y; w[4 * c + 2] = x.z; w[4 * c + 3] = x.w; }
-#pragma unroll
-                    for (int i = 0; i < NFP; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[NFP + i]; }
-                }
-                const bool ends = q + 1 == end;
-                const bool fold = ends && k + 1 < nmine && len_of(seq[lane][k + 1]) >= 2;      // the next list starts in this step, unless its first entry is its only one
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // this step's operand is out of the stash before the next one is sent there
-                stash_fetch(fold ? v2 : v1);
-                G1Affine pinit;
-                if (fold) pinit = it[v1 & 0x7fff];   // the next list's first point: in flight during the addition
-                if (v0 & 0x8000) fp_neg(p.y, p.y);
+        for (int q = 0; q < tmax; q++) {
+            if (q < total) {
+                G1Affine p = pn;
+                const uint32_t v = v0;
+                v0 = v1; v1 = entry(q + 2);
+                pn = it[v0 & 0x7fff];                // next point (index 0 when past the end: a harmless in-range load)
+                if (v & 0x8000) fp_neg(p.y, p.y);
                 g1x_add_mixed_lazy(accx, started, p);
-                if (ends) park();
-                if (fold) {
-                    begin_list(pinit, v1);
-                    v0 = v2; v1 = entry(q + 3); v2 = entry(q + 4); q += 2;
-                } else { v0 = v1; v1 = v2; v2 = entry(q + 3); q += 1; }
+                if (q + 1 == end) {                  // the list ends here: park the raw accumulator, start the next list
+                    if (!started) accx = g1x_inf();  // (the items cancelled out: all-zero limbs, which g1x_is_inf sees after canonicalisation)
+                    out[slot_of(cur)].raw = accx;
+                    started = false;
+                    k++;
+                    if (k < nmine) { cur = seq[lane][k]; end += len_of(cur); }
+                }
             }
         }
     }
