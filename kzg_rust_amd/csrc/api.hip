@@ -134,6 +134,7 @@ struct kzg355_settings {
     int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
     int cu_count = 256;            // compute units of the device: the thresholds above and below are multiples of it (load_on_device)
     int pairing_two_wave_upto = 256;     // batches per launch set up to which a pairing runs its two Miller loops on two waves (1 per CU)
+    int miller_segments = 0;             // ... and on how many segments per loop (k_pairing_coop_split; 0: launch_pairing's default; KZG355_MILLER_SEGMENTS=1..4)
     int pairing_hard12_from = 4096;      // batches per launch set from which the final exponentiation's hard part runs twelve lanes per check (16 per CU; KZG355_PAIRING_HARD12_FROM, 0: never)
     int challenge_two_wave_upto = 32768; // blobs per launch set up to which the Fiat-Shamir hash runs as producer / consumer wave pairs (2 workgroups per CU)
     std::mutex mu;
@@ -475,8 +476,10 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
     if (s->lane_pairing) launch_pairing_lane(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream);
     else {
         Fp *f12 = nullptr;
-        if (s->pairing_hard12_from > 0 && groups >= s->pairing_hard12_from && w->pair_f.ensure(pairing_f12_bytes(groups)) == KZG355_OK) f12 = w->pair_f.as<Fp>();
-        launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream, s->pairing_two_wave_upto, f12, s->pairing_hard12_from);
+        // f between the two kernels of a check: many batches (hard part twelve lanes per check) and few (Miller loops in segments on several waves)
+        if (((s->pairing_hard12_from > 0 && groups >= s->pairing_hard12_from) || groups <= s->pairing_two_wave_upto) && w->pair_f.ensure(pairing_f12_bytes(groups)) == KZG355_OK)
+            f12 = w->pair_f.as<Fp>();
+        launch_pairing(w->pair_pts.as<PairPt>(), s->t, groups, d_ok, w->stream, s->pairing_two_wave_upto, f12, s->pairing_hard12_from, s->miller_segments);
     }
     tm.end();
     return KZG355_OK;
@@ -1084,6 +1087,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         s->rhash_lanes_from = opt.rhash_lanes_from > 0 ? opt.rhash_lanes_from : 4 * cus;     // transcript hash with a lane per batch from one wave per SIMD on (1024)
         s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
         s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;     // two waves per pairing up to 256 batches
+        if (const char *e = getenv("KZG355_MILLER_SEGMENTS")) { const int v = atoi(e); if (v >= 1 && v <= MILLER_SPLIT_MAX) s->miller_segments = v; }      // (tuning knob, not an option)
         s->pairing_hard12_from = opt.pairing_hard12_from < 0 ? 0 : opt.pairing_hard12_from > 0 ? opt.pairing_hard12_from : 16 * cus;   // hard part twelve lanes per check from 4096 batches on
         s->challenge_two_wave_upto = 2 * cus * 64;                                           // two-wave hash while every wave has a SIMD to itself (512 workgroups of 64 blobs)
     }

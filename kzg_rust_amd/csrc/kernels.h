@@ -117,7 +117,8 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
                                int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage = 0 /* 1: digits only; 2: sums only */);
 void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st,
                     int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */,
-                    Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */, int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */);
+                    Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */, int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */,
+                    int miller_segments = 0 /* few batches: segments per Miller loop, 2 waves each (1: the two-wave kernel; 0: the default, 2) */);
 size_t pairing_f12_bytes(int groups);
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
 

@@ -597,6 +597,44 @@ KZG_HD Fp12W &coop_slot(CoopMem &m, int s) {
 // SET_ONE, then per bit SQR and per line LINE_EVAL + two line products; the conjugation for x < 0 belongs to the tail
 constexpr int COOP_MILLER_INSNS = 1 + 63 + 3 * N_LINES;
 
+// The Miller loops of a lone check on SEVERAL waves per pair.  f = prod_i l_i^(2^(e_i)) is a product over the lines, so a wave may own a segment of the
+// iterations: it starts from f = 1 at its first iteration, multiplies its segment's lines in, and only squares from the end of the segment to the end
+// of the loop; the product of all the waves' values is the loop's.  With K segments per pair the dependent chain is the 63 squarings plus ONE segment's
+// line products instead of all 68.  The split (host side): segment boundaries that equalise  (lines of the segment) x c_line + (squarings from the
+// segment's start to the end) x c_sqr  over the segments, with the measured costs of the two operations (profiles/r04/pairing_op_breakdown.txt).
+constexpr int MILLER_SPLIT_MAX = 4;
+struct MillerSplit { int k; int pc_start[MILLER_SPLIT_MAX]; int pc_lines_end[MILLER_SPLIT_MAX]; };
+inline MillerSplit miller_split(const CoopInsn *prog, int k, double c_sqr = 2.3, double c_line = 2.1) {
+    int sq[64], steps[64], n_it = 0;
+    for (int pc = 0; pc < 1 + 63 + 3 * N_LINES; pc++) {
+        if (prog[pc].op == OP_SQR) { sq[n_it] = pc; steps[n_it] = 0; n_it++; }
+        else if (prog[pc].op == OP_MUL_LINE0 && n_it > 0) steps[n_it - 1]++;
+    }
+    MillerSplit sp; sp.k = k < 1 ? 1 : k > MILLER_SPLIT_MAX ? MILLER_SPLIT_MAX : k;
+    int bound[MILLER_SPLIT_MAX + 1];
+    auto fits = [&](double T) {                                  // segments from the END of the loop backwards, each as long as T allows
+        int b = n_it;
+        bound[sp.k] = n_it;
+        for (int j = sp.k - 1; j >= 0; j--) {
+            double lines = 0;
+            while (b > 0 && lines + steps[b - 1] * c_line + c_sqr * (n_it - (b - 1)) <= T) { b--; lines += steps[b] * c_line; }
+            bound[j] = b;
+        }
+        return b == 0;
+    };
+    double lo = 0, hi = n_it * (c_sqr + 2 * c_line) + 1;
+    for (int it = 0; it < 40; it++) { const double mid = 0.5 * (lo + hi); if (fits(mid)) hi = mid; else lo = mid; }
+    fits(hi);
+    bound[0] = 0;
+    for (int j = 0; j < MILLER_SPLIT_MAX; j++) { sp.pc_start[j] = 0; sp.pc_lines_end[j] = 0x7fffffff; }
+    for (int j = 0; j < sp.k; j++) {
+        const int end_pc = 1 + 63 + 3 * N_LINES;
+        sp.pc_start[j] = j == 0 ? 0 : bound[j] < n_it ? sq[bound[j]] : end_pc;       // (segment 0 starts at SET_ONE; an empty segment runs nothing)
+        sp.pc_lines_end[j] = j == sp.k - 1 || bound[j + 1] >= n_it ? 0x7fffffff : sq[bound[j + 1]];
+    }
+    return sp;
+}
+
 // Interpreter, in three pieces so that the two Miller loops of a check can also run on two waves (k_pairing.hip):
 //   coop_init     schedules and the two G1 points into the wave's CoopMem
 //   coop_run      instructions [pc0, pc1); use1 / use2 = false skips that pair's line products (a pair at infinity contributes 1)
@@ -619,8 +657,10 @@ KZG_HD void coop_init(CoopMem &m, const CoopScheds *scheds, const PairPt &p1, co
     COOP_SYNC();
 }
 // pre (or null): the line evaluations of both pairs made ahead of the loop, [pair][line][l0, l6, l2, l8, l3, l9 at the point] (coop_eval_lines)
+// line_pc_end: line products are made only by instructions below it (a wave that owns a SEGMENT of a Miller loop multiplies its segment's lines
+// in and only squares from there on: k_pairing_coop_split)
 KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const LineW *lines1, const LineW *lines2, bool use1, bool use2, const FrobTables &ft,
-                     const Fp *pre = nullptr) {
+                     const Fp *pre = nullptr, int line_pc_end = 0x7fffffff) {
     if (pc1 <= pc0) return;
     CoopInsn nxt = prog[pc0];
     int cur_line = 0;                                             // with pre: the line the next line products take (set by OP_LINE_EVAL)
@@ -630,7 +670,7 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
         Fp12W &dst = coop_slot(m, in.dst);
         const Fp12W &a = coop_slot(m, in.a);
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
-            const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2);
+            const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2) || (pc >= line_pc_end && (in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1));
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
             const Fp *bs = mask != LINE_MASK ? nullptr                                     // the line as its six evaluated coefficients:
                            : pre ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6      // all made ahead of the loop (two-wave kernel)

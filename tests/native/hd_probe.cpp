@@ -290,6 +290,53 @@ int hd_pairings_verify_coop_proj(int *ok, const uint8_t *p1, const uint8_t *q1, 
     delete m0; delete m1;
     return 0;
 }
+// The Miller loops in K segments per pair on 2 K "waves" (k_pairing_coop_split: miller_split's boundaries, every wave from f = 1 at its segment's first
+// iteration, lines only inside the segment, squarings to the end of the loop), the tree of products over the partial values, the rest of the program.
+int hd_pairings_verify_coop_segments(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2, int K) {
+    G1Affine a, b; G2Affine qa, qb;
+    if (K < 1 || K > MILLER_SPLIT_MAX) return 4;
+    if (g1_decompress(a, p1) || g1_decompress(b, p2) || g2_decompress(qa, q1) || g2_decompress(qb, q2)) return 1;
+    std::vector<LineCoeff> l1(N_LINES), l2(N_LINES);
+    std::vector<LineW> w1(N_LINES), w2(N_LINES);
+    if (!g2a_is_inf(qa)) precompute_lines(l1.data(), qa);
+    if (!g2a_is_inf(qb)) precompute_lines(l2.data(), qb);
+    for (int i = 0; i < N_LINES; i++) { line_to_w(w1[i], l1[i]); line_to_w(w2[i], l2[i]); }
+    G1Affine an = a; if (!g1a_is_inf(an)) fp_neg(an.y, an.y);
+    PairPt pa, pb; pairpt_from_affine(pa, an); pairpt_from_affine(pb, b);
+    const bool use1 = !fp_is_zero(pa.az) && !g2a_is_inf(qa), use2 = !fp_is_zero(pb.az) && !g2a_is_inf(qb);
+    static const uint32_t A1[12][NFP] = FROBW_A1_INIT, B1[12][NFP] = FROBW_B1_INIT, A2[12][NFP] = FROBW_A2_INIT;
+    FrobTables ft;
+    for (int k = 0; k < 12; k++) for (int i = 0; i < NFP; i++) { ft.a1[k].l[i] = A1[k][i]; ft.b1[k].l[i] = B1[k][i]; ft.a2[k].l[i] = A2[k][i]; }
+    static CoopInsn prog[COOP_PROGRAM_MAX];
+    const int n_insn = build_pairing_program(prog);
+    if (n_insn > COOP_PROGRAM_MAX) return 2;
+    static CoopScheds sc;
+    if (!build_coop_schedules(sc)) return 3;
+    const MillerSplit sp = miller_split(prog, K);
+    // every iteration must belong to exactly one segment
+    for (int j = 0; j + 1 < K; j++) if (sp.pc_lines_end[j] != sp.pc_start[j + 1]) return 5;
+    if (sp.pc_start[0] != 0 || sp.pc_lines_end[K - 1] < COOP_MILLER_INSNS) return 6;
+    std::vector<Fp> pre(2 * N_LINES * 6);
+    const PairPt pab[2] = {pa, pb};
+    for (int item = 0; item < 2 * N_LINES * 6; item++) coop_eval_lines_item(pre.data(), item, w1.data(), w2.data(), pab);
+    std::vector<CoopMem *> m(2 * K);
+    for (int w = 0; w < 2 * K; w++) {
+        m[w] = new CoopMem();
+        coop_init(*m[w], &sc, pa, pb);
+        const int pair = w & 1, seg = w >> 1;
+        if (seg > 0) coop_set_one(m[w]->f);
+        coop_run(*m[w], prog, sp.pc_start[seg], COOP_MILLER_INSNS, w1.data(), w2.data(), pair == 0 && use1, pair == 1 && use2, ft, pre.data(), sp.pc_lines_end[seg]);
+    }
+    for (int stride = 1; stride < 2 * K; stride <<= 1)
+        for (int w = 0; w + stride < 2 * K; w += 2 * stride) {
+            for (int k = 0; k < 12; k++) m[w]->t0.c[k] = m[w + stride]->f.c[k];
+            coop_product(*m[w], m[w]->sc.mul, m[w]->f, m[w]->f, m[w]->t0, FULL_MASK);
+        }
+    coop_run(*m[0], prog, COOP_MILLER_INSNS, n_insn, w1.data(), w2.data(), false, false, ft);
+    *ok = coop_is_one(*m[0], m[0]->t0) ? 1 : 0;
+    for (auto *x : m) delete x;
+    return 0;
+}
 // The pairing check with the hard part of the final exponentiation run twelve lanes per check (pairing_lanes.h) behind the cooperative Miller loops
 // and easy part.  Returns 0 and the verdict; 4 if any coefficient of the hard part's result differs (as a field element) from the cooperative run's.
 int hd_pairings_verify_lanes12(int *ok, const uint8_t *p1, const uint8_t *q1, const uint8_t *p2, const uint8_t *q2) {

@@ -359,6 +359,10 @@ def test_pairing_with_projective_arguments_and_split_miller_loops(hd, oracle, se
             got = C.c_int(-1)
             assert hd.hd_pairings_verify_coop_proj(C.byref(got), a, qa, b, qb, z) == 0
             assert got.value == want.value, (z, a.hex()[:8], b.hex()[:8])
+        for k in (1, 2, 3, 4):          # the Miller loops in k segments per pair (k_pairing_coop_split)
+            got = C.c_int(-1)
+            assert hd.hd_pairings_verify_coop_segments(C.byref(got), a, qa, b, qb, k) == 0
+            assert got.value == want.value, (k, a.hex()[:8], b.hex()[:8])
 
 
 def test_window_shifts_started_from_x_alone(hd, setup_bytes):
