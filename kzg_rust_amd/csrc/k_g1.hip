@@ -436,11 +436,26 @@ __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups,
     const int id = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;         // (batch, class, window)
     if (id >= 2 * LC_WINDOWS * groups) return;                    // (no barrier below: every lane keeps to its own LDS column)
     const LcSlot *s = S + (size_t)id * LC_BUCKETS;                // the bucket kernel's raw (lazy extended-Jacobian) sums; all-zero = infinity
-    G1X acc = s[LC_BUCKETS - 1].raw;
+    // Leading empty buckets are COMMON, not rare: the top window's digit has 3 value bits and a carry, so its buckets 9 .. 16 are empty in every
+    // batch, and every wave holds two or three top-window lanes.  g1x_add_lazy2 sends an operand at infinity through the canonical complete
+    // addition -- a divergent branch, so the whole wave ran it: 18 of a wave's 30 additions.  A lane now starts at its highest non-empty bucket
+    // and sits out the steps above it (the sums are the same: infinity + infinity); an empty bucket further down still takes the complete addition.
+    int start = -1;
+#pragma unroll 1
+    for (int b = LC_BUCKETS - 1; b >= 0 && start < 0; b--) {
+        const Fp zz = s[b].raw.zz;
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < NFP; i++) o |= zz.l[i];
+        if (o) start = b;
+    }
+    if (start < 0) { W[id] = g1_inf(); return; }                 // nothing in this window (no barrier below)
+    G1X acc = s[start].raw;
 #pragma unroll
     for (int i = 0; i < NFP; i++) { tot[i][tid] = acc.x.l[i]; tot[NFP + i][tid] = acc.y.l[i]; tot[2 * NFP + i][tid] = acc.zz.l[i]; tot[3 * NFP + i][tid] = acc.zzz.l[i]; }
 #pragma unroll 1
     for (int b = LC_BUCKETS - 2; b >= 0; b--) {
+        if (b >= start) continue;
         g1x_add_lazy2(acc, acc, s[b].raw);
         asm volatile("" ::: "memory");                            // the total is fetched only now ...
         G1X sum;
