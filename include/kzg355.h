@@ -100,7 +100,7 @@ typedef struct kzg355_options {
     int lincomb_form;          /* batch linear combination: 0 by size, 1 per-term windows, 2 buckets, 3 pre-shifted        KZG355_LINCOMB=window|bucket|preshift */
     int pairing_lane;          /* 1: one-lane pairing kernel (A/B and tests)                                               KZG355_PAIRING=lane */
     int pairing_two_wave_upto; /* batches per launch set up to which a pairing runs its two Miller loops on two waves; 0 = 1 per CU; -1 never  KZG355_PAIRING_2W_UPTO */
-    int lc_chain_from;         /* batches from which the bucket form ends in one Horner chain per class; 0 = 24 per CU      KZG355_LC_CHAIN_FROM */
+    int lc_chain_from;         /* batches from which the bucket form ends in one Horner chain per class; 0 = 4 per CU       KZG355_LC_CHAIN_FROM */
     int rhash_lanes_from;      /* batches from which the r-transcripts are hashed one lane per batch; 0 = 4 per CU          KZG355_RHASH_LANES_FROM */
     int beside_max_blobs;      /* blobs per launch set up to which the point kernels run on side streams; 0 = 64 per CU */
     int split_parts;           /* device-resident verify calls as this many overlapped launch sets (0 / 1: one set)         KZG355_SPLIT=parts[,streams] */

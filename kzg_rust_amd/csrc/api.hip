@@ -128,7 +128,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
-    int lc_chain_from = 6144;      // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM); measured: lincomb + tail at 2048 / 4096 / 8192 batches: 6.0 / 11.1 / 21.9 ms with 16 chains per class, 6.7 / 11.2 / 20.2 ms with one
+    int lc_chain_from = 1024;      // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM).  Round 4, with the chain walked by quads and sets kept in flight (blobs/s, three sets in flight, 16 chains per class against one): 512 batches 2.81 M either way, 1024 3.99 -> 4.03 M, 2048 4.14 -> 4.26 M, 4096 4.25 -> 4.36 M (profiles/r04/chain_from_sweep.txt); one set at a time it is within +-2 % from 512 to 4096
     int rhash_lanes_from = 1024;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM); measured: 1024 batches of 512 records 6.75 -> 3.47 ms, 8192 of 64: 2.44 -> 0.57 ms
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
     int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
@@ -1083,7 +1083,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         int cus = 256;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         s->cu_count = cus;
-        s->lc_chain_from = opt.lc_chain_from > 0 ? opt.lc_chain_from : 24 * cus;             // one Horner chain per class from 6144 batches on
+        s->lc_chain_from = opt.lc_chain_from > 0 ? opt.lc_chain_from : 4 * cus;              // one Horner chain per class from 1024 batches on
         s->rhash_lanes_from = opt.rhash_lanes_from > 0 ? opt.rhash_lanes_from : 4 * cus;     // transcript hash with a lane per batch from one wave per SIMD on (1024)
         s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
         s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;     // two waves per pairing up to 256 batches

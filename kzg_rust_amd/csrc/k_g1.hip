@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 //                 lane and walked back to back in one loop                          -> bucket sums B[class][window][b]
 //   k_lc_horner   one lane per (batch, class, b): Horner over the 26 windows (5 doublings + 1 addition each), then the
 //                 weights b over the 16 lanes of a class (suffix scan + butterfly), to affine
-//   k_lc_wsum + k_lc_hchain_quad   the tail for many batches (from 6144 on): window sums weighted first, one Horner chain per class
+//   k_lc_wsum + k_lc_hchain_quad   the tail for many batches (from 1024 on: half the instructions of the 16 chains per class): window sums weighted first, one Horner chain per class
 // Window width: the bucket kernel's work is (items x windows) additions -- 4-bit digits 11.6 k per 64-blob batch, 5-bit 9.7 k,
 // 6-bit 8.4 k -- while the Horner tail has one chain per bucket index: 16 lanes per class at 5 bits still leave it a
 // latency-bound kernel of ~one wave per SIMD at 2048 batches; at 6 bits it would be as much work as the buckets.
