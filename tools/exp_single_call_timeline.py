@@ -27,10 +27,19 @@ def run():
     cs = [kz.Kzg.blob_to_kzg_commitment(b, s) for b in blobs]
     ps = [kz.Kzg.compute_blob_kzg_proof(b, c, s) for b, c in zip(blobs, cs)]
     ts = []
+    op = os.environ.get("OP", "verify_batch")          # or: commit, proof (compute_kzg_proof), blob_proof, verify_proof, verify_blob
+    z = bytes(31) + b"\x05"
+    y = kz.Kzg.compute_kzg_proof(blobs[0], z, s)[1] if op == "verify_proof" else None
+    pz = kz.Kzg.compute_kzg_proof(blobs[0], z, s)[0] if op == "verify_proof" else None
     for _ in range(40):
         time.sleep(0.003)
         t0 = time.perf_counter()
-        assert kz.Kzg.verify_blob_kzg_proof_batch(blobs, cs, ps, s)
+        if op == "verify_batch": assert kz.Kzg.verify_blob_kzg_proof_batch(blobs, cs, ps, s)
+        elif op == "commit": kz.Kzg.blob_to_kzg_commitment(blobs[0], s)
+        elif op == "proof": kz.Kzg.compute_kzg_proof(blobs[0], z, s)
+        elif op == "blob_proof": kz.Kzg.compute_blob_kzg_proof(blobs[0], cs[0], s)
+        elif op == "verify_proof": assert kz.Kzg.verify_kzg_proof(cs[0], z, y, pz, s)
+        elif op == "verify_blob": assert kz.Kzg.verify_blob_kzg_proof(blobs[0], cs[0], ps[0], s)
         ts.append((time.perf_counter() - t0) * 1e3)
     print(f"wall per call (python wrapper included): median {sorted(ts)[20]:.3f} ms, min {min(ts):.3f} ms", file=sys.stderr)
     s.free()
@@ -54,8 +63,10 @@ def parse(directory):
         cur.append(r)
     if cur:
         calls.append(cur)
-    calls = [c for c in calls if any(x[2].startswith("k_pairing") for x in c) and any(x[2].startswith("k_challenge_from_digest") for x in c)]
-    assert calls, "no host-hashed verify call in the trace"
+    need = os.environ.get("NEED", "k_pairing,k_challenge_from_digest").split(",")      # kernels a call of the traced operation must contain
+    calls = [c for c in calls if all(any(x[2].startswith(k) for x in c) for k in need)]
+    assert calls, "no call with the kernels " + str(need) + " in the trace"
+    calls = calls[len(calls) // 4:]                    # (the first calls of a run include one-time work)
     calls.sort(key=lambda c: max(x[1] for x in c) - c[0][0])
     c = calls[len(calls) // 2]
     t0 = c[0][0]
