@@ -94,6 +94,56 @@ __global__ void __launch_bounds__(256) k_subgroup_points_quad(const G1Affine *pt
     if (!skip && role == 0 && !ok) atomicOr(&err[j / (2 * n_per_group)], ERR_BAD_POINT);      // infinity is accepted (utils.rs:298-301)
 }
 
+// The same ladder started from x ALONE, beside the square root of the decoding instead of behind it (the trick of k_ps_shift: with s = x^3 + 4 = y^2 the
+// curve E'': Y^2 = X^3 + 4 s^3 is isomorphic to E, (s x, s^2) is the image of P = (x, y), and neither the doubling nor the addition formulas of a = 0
+// curves involve the constant -- so [x^2] of that point is walked on E'' unchanged, and a Jacobian point (X, Y, Z) of E'' IS (X, Y, y Z) on E).  For
+// compute_blob_kzg_proof the commitment's validation is the critical path once the challenge is hashed on the host: 0.45 ms of square root, THEN 0.65 ms
+// of ladder.  k_subgroup_ladder_from_x_quad leaves [x^2]P'' per point; k_subgroup_finish, behind both, applies y and tests phi(P) == -[x^2]P.
+__global__ void __launch_bounds__(256) k_subgroup_ladder_from_x_quad(const uint8_t *cbytes, int stride, int n, G1Jac *T) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, role = tid & 3;
+    const bool live = (tid >> 2) < n;
+    const int i = live ? (tid >> 2) : n - 1;                      // idle quads redo the last point (every lane takes part in the DPP moves)
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = cbytes[(size_t)stride * i + k];
+    Fp x = fp_zero(), sv;
+    bool inf = false, large;
+    if (g1_parse_compressed(x, inf, large, b)) inf = true;       // (a bad encoding is an error of the decoding kernel; here it is the point at infinity)
+    g1_curve_rhs(sv, x);
+    G1Jac base;
+    fp_mul(base.x, sv, x); fp_sqr(base.y, sv); base.z = fp_one();
+    if (inf) base = g1_inf();
+    G1Jac t = base;
+    // one loop, one inlined instance of each quad routine: two passes of the 63-step ladder for |x| = 0xd201000000010000
+#pragma unroll 1
+    for (int step = 0; step < 126; step++) {
+        const int bit = 62 - (step % 63);
+        if (step == 63) { g1_canon_lazy(t, t); base = t; }       // second ladder: [|x|] of the first one's result
+        g1_dbl_quad(t, role);
+        if ((BLS_X_ABS >> bit) & 1) g1_add_quad(t, t, base, role);   // (a constant exponent: the branch is uniform)
+    }
+    g1_canon_lazy(t, t);
+    if (live && role == 0) T[i] = t;
+}
+// pts: the decoded points in the [group][commitments | proofs] layout with one commitment per group (slot 2 i); T: the ladder's results on E''
+__global__ void __launch_bounds__(64) k_subgroup_finish(const G1Affine *pts, const G1Jac *T, int n, int *err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = pts[2 * (size_t)i];
+    if (g1a_is_inf(p)) return;                                    // infinity is accepted (utils.rs:298-301); a point that failed to decode was flagged there
+    G1Jac t = T[i];
+    Fp tz; fp_mul(tz, t.z, p.y);                                  // (X, Y, Z) on E'' = (X, Y, y Z) on E
+    bool ok = !fp_is_zero(tz);
+    const uint32_t bc[NFP] = FP_BETA_INIT;
+    Fp beta; for (int q = 0; q < NFP; q++) beta.l[q] = bc[q];
+    Fp z2, z3, lhs, rhs;
+    fp_sqr(z2, tz); fp_mul(z3, z2, tz);
+    fp_mul(lhs, p.x, beta); fp_mul(lhs, lhs, z2);                 // beta x Z^2 == X
+    ok = ok && fp_eq(lhs, t.x);
+    fp_mul(lhs, p.y, z3); fp_neg(rhs, t.y);                       // y Z^3 == -Y
+    ok = ok && fp_eq(lhs, rhs);
+    if (!ok) atomicOr(&err[i], ERR_BAD_POINT);
+}
+
 // Decompress the C_i / proof_i fields of gathered records (already validated by their owner rank).
 __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *records, int n_total, int n_per_group, G1Affine *pts, int *err) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -727,6 +777,14 @@ void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group,
         return;
     }
     hipLaunchKernelGGL(k_subgroup_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_pts, 2 * n_total, n_per_group, d_err, commitments_only);
+}
+void launch_subgroup_ladder_from_x(const uint8_t *d_commitments, int stride, int n, G1Jac *d_T, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_subgroup_ladder_from_x_quad, dim3((4 * n + 255) / 256), dim3(256), 0, st, d_commitments, stride, n, d_T);
+}
+void launch_subgroup_finish(const G1Affine *d_pts, const G1Jac *d_T, int n, int *d_err, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_subgroup_finish, dim3((n + 63) / 64), dim3(64), 0, st, d_pts, d_T, n, d_err);
 }
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st) {
     if (n_total <= 0) return;

@@ -91,6 +91,9 @@ void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_c
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, const Fr *d_zpow, DeviceTables t, int n_total, int n_per_group, Fr *d_y /* may be null */,
                  uint8_t *d_records /* y written at +80; may be null */, int *d_err, hipStream_t st);
 // stage 2 (per group of n records): points from records, r-powers, lincomb, pairing
+// few commitments (compute_blob_kzg_proof): the subgroup ladder from x alone (beside the square root of the decoding), then the test once y is there
+void launch_subgroup_ladder_from_x(const uint8_t *d_commitments, int stride, int n, G1Jac *d_T, hipStream_t st);
+void launch_subgroup_finish(const G1Affine *d_pts, const G1Jac *d_T, int n, int *d_err, hipStream_t st);
 void launch_points_from_records(const uint8_t *d_records, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st);
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
                     uint32_t *d_scal_c, int *d_err, hipStream_t st, int n_fe = N_FE /* the u64be(FIELD_ELEMENTS_PER_BLOB) field of the transcript */,
