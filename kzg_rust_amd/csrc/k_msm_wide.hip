@@ -19,6 +19,7 @@
 #define KZG_MID_INLINE 1
 #define KZG_G1_ADD_MUL2 1       // the accumulation's Y3 as two products under one reduction (g1.h g1x_add_mixed_lazy)
 #include "kernels.h"
+#include "g1_quad.h"
 #include "fr_block.h"
 
 namespace kzg {
@@ -220,23 +221,38 @@ __global__ void __launch_bounds__(256) k_msm_wide_glv(const uint8_t *blobs, cons
     G1Jac acc;
     { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
     if (!FROM_FR && bad && part == 0) atomicOr(&err[blob], ERR_NONCANONICAL_FR);          // blob_to_polynomial (kzg.rs:282-291)
+    // The 256 sums of the workgroup -> one.  Two butterfly levels of complete additions leave every lane of a quad with the quad's sum -- the operand form
+    // of the quad addition (g1_quad.h: five products deep instead of sixteen, no canonicalisation) -- which takes the other four levels, the two waves of
+    // each half, and T_a + (-phi)(T_b).  (A lone blob's MSM is 8 additions per lane and was 9 complete additions of reduction: 345 us of which ~200.)
 #pragma unroll 1
-    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        G1Jac ta = red[0], tb = red[2];
-        { G1Jac o = red[1]; g1_add(ta, ta, o); }
-        { G1Jac o = red[3]; g1_add(tb, tb, o); }
-        if (!g1_is_inf(tb)) {                                     // (-phi)(X, Y, Z) = (beta X, -Y, Z)
-            const uint32_t bc[NFP] = FP_BETA_INIT;
-            Fp beta; for (int q = 0; q < NFP; q++) beta.l[q] = bc[q];
-            fp_mul(tb.x, tb.x, beta);
-            fp_neg(tb.y, tb.y);
+    for (int off = 1; off < 4; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
+    // (the four lanes hold the same POINT, but a + b and b + a come out as different Jacobian representatives -- (X, Y, Z) and (X, -Y, -Z) -- and the quad
+    // addition needs identical coordinates in its four lanes: lane 0's go to all)
+    acc.x = fp_quad_bcast<0>(acc.x); acc.y = fp_quad_bcast<0>(acc.y); acc.z = fp_quad_bcast<0>(acc.z);
+    const int role = tid & 3, quad = (tid >> 2) & 15;
+    // one loop, one inlined instance of the quad addition (k_g1.hip: several instances in a row have been miscompiled)
+#pragma unroll 1
+    for (int step = 0; step < 6; step++) {
+        G1Jac o;
+        if (step < 4) o = g1_shfl_xor_w(acc, 4 << step);
+        else if (step == 4) {
+            g1_canon_lazy(acc, acc);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();                                      // (uniform: every thread reaches this step)
+            acc = red[2 * (quad & 1)]; o = red[2 * (quad & 1) + 1];      // even quads: the waves of the a halves, odd quads: of the b halves
+        } else {
+            g1_canon_lazy(acc, acc);
+            if ((quad & 1) && !g1_is_inf(acc)) {                  // (-phi)(X, Y, Z) = (beta X, -Y, Z)
+                const uint32_t bc[NFP] = FP_BETA_INIT;
+                Fp beta; for (int q = 0; q < NFP; q++) beta.l[q] = bc[q];
+                fp_mul(acc.x, acc.x, beta);
+                fp_neg(acc.y, acc.y);
+            }
+            o = g1_shfl_xor_w(acc, 4);
         }
-        g1_add(ta, ta, tb);
-        partials[(size_t)blob * wgpb + wg] = ta;
+        g1_add_quad(acc, acc, o, role);
     }
+    if (tid == 0) { g1_canon_lazy(acc, acc); partials[(size_t)blob * wgpb + wg] = acc; }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
