@@ -149,15 +149,24 @@ __global__ void __launch_bounds__(256) k_msm_wide(const uint8_t *blobs, const Fr
     G1Jac acc;
     { G1X cx; g1x_from_lazy(cx, accx, started); g1x_to_jac(acc, cx); }
     if (!FROM_FR && bad && part == 0) atomicOr(&err[blob], ERR_NONCANONICAL_FR);          // blob_to_polynomial (kzg.rs:282-291)
+    // the workgroup's 256 sums -> one: two butterfly levels of complete additions, then quad additions (see k_msm_wide_glv)
 #pragma unroll 1
-    for (int off = 1; off < 64; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        G1Jac t = red[0];
-        for (int q = 1; q < 4; q++) { G1Jac o = red[q]; g1_add(t, t, o); }
-        partials[(size_t)blob * wgpb + wg] = t;
+    for (int off = 1; off < 4; off <<= 1) { G1Jac o = g1_shfl_xor_w(acc, off); g1_add(acc, acc, o); }
+    acc.x = fp_quad_bcast<0>(acc.x); acc.y = fp_quad_bcast<0>(acc.y); acc.z = fp_quad_bcast<0>(acc.z);      // one Jacobian representative per quad
+    const int role = tid & 3, quad = (tid >> 2) & 15;
+#pragma unroll 1
+    for (int step = 0; step < 6; step++) {
+        G1Jac o;
+        if (step < 4) o = g1_shfl_xor_w(acc, 4 << step);
+        else if (step == 4) {
+            g1_canon_lazy(acc, acc);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();                                      // (uniform: every thread reaches this step)
+            acc = red[2 * (quad & 1)]; o = red[2 * (quad & 1) + 1];
+        } else o = g1_shfl_xor_w(acc, 4);
+        g1_add_quad(acc, acc, o, role);
     }
+    if (tid == 0) { g1_canon_lazy(acc, acc); partials[(size_t)blob * wgpb + wg] = acc; }
 }
 
 // The GLV form (WideShape.glv): every scalar is split k = a + b x^2 and the table spans 128 bits.  Waves 0 and 1 of the workgroup walk the
