@@ -596,6 +596,45 @@ def test_batch_fixtures_stage_by_stage(n, kz, settings):
     torch.cuda.synchronize()
 
 
+@pytest.mark.gpu
+def test_differential_blob_proof_commitment_mutations(kz, settings, oracle, oracle_settings, random_set):
+    """compute_blob_kzg_proof validates its commitment (kzg.rs:321-323, utils.rs:282-310) before it hashes it.  The product walks the subgroup
+    ladder from x alone beside the square root of the decoding (k_subgroup_ladder_from_x_quad + k_subgroup_finish): honest commitments, the other
+    square root (-C: a valid point, another challenge), infinity, random x (off the curve, or on it and outside G1), corrupted flag bits and
+    bytes -- the 48 proof bytes or the Err must be the oracle's, case by case."""
+    import random
+    from oracle.oracle import OracleError
+    rnd = random.Random(4844)
+    blobs, cs, ps = random_set
+    n_ok = n_err = 0
+    for it in range(60):
+        i = rnd.randrange(len(blobs))
+        c = bytearray(cs[i])
+        k = it % 6
+        if k == 1:
+            c[0] ^= 0x20                                            # the other square root
+        elif k == 2:
+            c = bytearray(bytes([0xC0]) + bytes(47))                # infinity
+        elif k == 3:                                                # random x: half of them on the curve, practically none of those in G1
+            c = bytearray(rnd.randrange(1 << 381).to_bytes(48, "big")); c[0] = (c[0] & 0x1F) | 0x80 | (0x20 if rnd.random() < .5 else 0)
+        elif k == 4:
+            c[0] ^= rnd.choice([0x80, 0x40])                        # compression / infinity flag
+        elif k == 5:
+            c[rnd.randrange(1, 48)] ^= 1 << rnd.randrange(8)
+        c = bytes(c)
+        try:
+            want = oracle.compute_blob_kzg_proof(blobs[i], c, oracle_settings)
+        except OracleError:
+            want = None
+        try:
+            got = kz.Kzg.compute_blob_kzg_proof(kz.Blob(blobs[i]), kz.KzgCommitment(c), settings).to_bytes()
+        except kz.Error:
+            got = None
+        assert got == want, (it, k, c.hex())
+        n_ok += want is not None; n_err += want is None
+    assert n_ok >= 15 and n_err >= 15                               # both outcomes well represented
+
+
 def test_differential_batch_mutations(kz, settings, oracle, oracle_settings, random_set):
     """Differential test of verify_blob_kzg_proof_batch against the oracle on mutated batches of 1..6 blobs: honest, a field
     element of a blob pushed to r / r-1 / 2^256-1, a blob byte flipped, proofs swapped, a commitment replaced by another
