@@ -63,7 +63,7 @@ KERNEL_BYTES_PER_BLOB.update({
     "msm_wide": B_COMMIT,
     "msm_finalize": 32 * 168 + 48,
     "digits": 131072 + 131072,
-    "quotient": 131072 + 131072 + 147456,
+    "quotient": 131072 + 131072 + 131072,            # blob + roots sweep in, the quotient in the blob format out (rounds 1-4: 147,456 B of Montgomery limbs)
 })
 FAMILIES = list(KERNEL_BYTES_PER_BLOB)
 PER_BATCH_FAMILIES = ("rpowers", "lincomb", "lincomb_prep", "lincomb_horner", "pairing", "points_from_records")
@@ -74,7 +74,7 @@ OP_METRIC = {"verify": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, 
 KERNEL_NAMES = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets", "k_lc_carry"], "lincomb_prep": ["k_lc_prep"],
                 "lincomb_horner": ["k_lc_wsum", "k_lc_hchain_quad", "k_lc_horner"], "lincomb_shift": ["k_ps_shift"], "pairing": ["k_pairing_coop", "k_pairing_hard12"], "validate_points": ["k_validate_points"], "rpowers": ["k_rhash_lanes", "k_rpowers"],
                 "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"],
-                "msm_wide": ["k_msm_wide_glv<false>", "k_msm_wide_glv<true>", "k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient"], "msm_finalize": ["k_msm_finalize"]}
+                "msm_wide": ["k_msm_wide_glv<false>", "k_msm_wide_glv<true>", "k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient_tree<4>", "k_quotient_tree<2>", "k_quotient_tree<6>", "k_quotient_prep", "k_quotient_scan", "k_quotient"], "msm_finalize": ["k_msm_finalize"]}
 ALTERNATIVE_FORMS = ("challenge", "msm_bucket", "msm_wide")     # lists of alternative forms of one kernel, not sequences
 
 
@@ -178,6 +178,7 @@ def main():
                     help="time the host-buffer drop-in entry point (H2D over PCIe inside the timed region); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the config.host_inputs measurements of the default run")
+    ap.add_argument("--no-msm-legs", action="store_true", help="skip the commitment / proof legs of the default run (BASELINE configs[1], [2])")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-batch latency calls (profiling runs: every launch is then a full-size one)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels of the timed region (A/B of their cost; no roofline)")
     ap.add_argument("--sharded-path", action="store_true",
@@ -463,6 +464,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
 
+    msm_legs = None
+    if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_msm_legs and not args.sharded_path:
+        # BASELINE configs[1] and [2] in the same driver-timed run: the verify handle and its launch sets are released first (69 GB of blobs,
+        # the table the untimed setup built), then a handle with the widest MSM table that fits serves both legs
+        msm_form_verify_setup = s.msm_form
+        n_leg = min(n_blobs, 16384)
+        keep_b = t_blobs[:n_leg * BLOB].clone(); keep_c = t_c[:n_leg * 48].clone()
+        s.free(); engine = None
+        t_blobs = t_c = t_p = None
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        msm_legs = run_msm_legs(kz, L, torch, dev, g1, g2, keep_b, keep_c, commitments[:48 * n_leg], proofs[:48 * n_leg], n_leg)
+        msm_legs["verify_setup_msm_form"] = msm_form_verify_setup
+        s = None
+
     if rank == 0:
         line = {
             "metric": OP_METRIC[args.op],
@@ -476,7 +491,7 @@ def main():
                                          "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)")),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
-                       "msm_form": s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
+                       "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
                        "host_inputs": host_inputs, "mid_size_sets": mid_size, "power": power},
@@ -492,10 +507,129 @@ def main():
             line["value_mid_size_sets_in_flight"] = mid_size["blobs_per_s"]              # 1024-batch sets, three in flight (config.mid_size_sets)
         if exchange_stats:
             line["config"]["exchange"] = exchange_stats
+        flatten_scalars(line, host_inputs, mid_size, power, msm_legs)
         print(json.dumps(line), flush=True)
-    s.free()
+    if s is not None:
+        s.free()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_msm_legs(kz, L, torch, dev, g1, g2, t_blobs, t_c, commitments, proofs, n, steps=6, warmup=2):
+    """BASELINE configs[1] / [2] inside the default run: blob_to_kzg_commitment and compute_blob_kzg_proof over n independent device-resident blobs
+    per launch (benches/kzg_benches.rs:46-91 time one call each; here one launch set of n blobs is a step, as for `value`).  The handle is loaded
+    for the widest fixed-base table that fits the card now that the verify launch sets are gone (16-bit GLV windows = 143.5 GB when >= 160 GB are free,
+    else what the handle picks from half of the free HBM); every step's outputs are compared with the untimed setup's (made with ANOTHER table
+    width: the two forms must agree byte for byte).  `north_star`'s "fraction of the HBM-read roofline for the G1 trusted-setup sweep" is
+    g1_sweep_hbm_frac: SURVEY 8d's B_commit / B_proof bytes per blob x blobs/s over the 8 TB/s peak; traffic_over_algorithmic says what the wide table
+    really moves (committed PMC passes of `bench.py --op commit|proof`), gather_frac prices it against the measured random-128-B-row gather ceiling."""
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    want16 = free_b >= 160 * (1 << 30)
+    t0 = time.perf_counter()
+    s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)],
+                                             device=dev.index or 0, msm_bits=16 if want16 else 0)
+    s.build_msm_table()
+    build_s = time.perf_counter() - t0
+    bits, wins, glv, table_bytes = s.msm_shape()
+    out48 = C.create_string_buffer(48 * n)
+    st = (C.c_int * n)()
+    legs = {"blobs_per_launch": n, "steps": steps, "msm_bits": bits, "msm_glv": bool(glv), "table_gb": round(table_bytes / 1e9, 1), "table_build_s": round(build_s, 2),
+            "free_hbm_gb_before_table": round(free_b / 1e9, 1)}
+    rows_per_blob = 4096 * ((2 * wins) if glv else (wins if bits != 15 else 17.45)) if bits >= 10 else None
+    for op in ("commit", "proof"):
+        def step():
+            if op == "commit":
+                rc = L.kzg355_blob_to_kzg_commitment_many_device(out48, st, t_blobs.data_ptr(), n, s.handle)
+                assert rc == 0 and out48.raw[:48 * n] == commitments, "commitments differ between the two table forms"
+            else:
+                rc = L.kzg355_compute_blob_kzg_proof_many_device(out48, st, t_blobs.data_ptr(), t_c.data_ptr(), n, s.handle)
+                assert rc == 0 and out48.raw[:48 * n] == proofs, "proofs differ between the two table forms"
+        for _ in range(warmup):
+            step()
+        L.kzg355_reset_kernel_stats(s.handle)
+        s.set_kernel_timing(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s.set_kernel_timing(False)
+        rate = steps * n / dt
+        kms = {}
+        for fam in FAMILIES:
+            tot, cnt = C.c_double(), C.c_long()
+            L.kzg355_kernel_ms_stats(s.handle, fam.encode(), C.byref(tot), C.byref(cnt))
+            if cnt.value:
+                kms[fam] = round(tot.value / cnt.value, 4)
+        b_alg = OP_BYTES_PER_BLOB[op]
+        traffic = 0.0
+        src = None
+        for fam in kms:
+            tr, f = pmc_traffic(fam, 1, op)
+            if tr:
+                traffic += tr; src = f
+        d = {"blobs_per_s": round(rate, 1), "ms_per_launch": round(dt * 1e3 / steps, 3), "kernel_ms": kms,
+             "algorithmic_bytes_per_blob": b_alg, "g1_sweep_hbm_frac": round(rate * b_alg / (HBM_PEAK_GBPS * 1e9), 5),
+             "traffic_bytes_per_blob": round(traffic) if traffic else None, "traffic_over_algorithmic": round(traffic / b_alg, 2) if traffic else None, "traffic_source": src}
+        if rows_per_blob:
+            d["rows_per_blob"] = round(rows_per_blob)
+            d["rows_per_s"] = round(rows_per_blob * rate)
+            d["gather_frac"] = round(rows_per_blob * rate * 128 / 1427.0e9, 4)        # profiles/r03/gather_rate_random_128B.txt: 11.1 G rows/s = 1427 GB/s
+        legs[op] = d
+    s.free()
+    return legs
+
+
+def flatten_scalars(line, host_inputs, mid_size, power, msm_legs):
+    """The driver's record of this line keeps SCALARS under config / roofline / cpu_baseline and drops nested objects and extra top-level keys
+    (VERDICT r4): every number BASELINE.md quotes is therefore also a flat scalar.  The nested objects stay for readers of the raw line."""
+    cfg, roof, cpu = line["config"], line.get("roofline"), line.get("cpu_baseline")
+    if host_inputs:
+        cfg["single_call_ms"] = host_inputs["single_call_ms"]                      # ONE verify_blob_kzg_proof_batch(n = 64) on host slices (benches/kzg_benches.rs:113-120)
+        cfg["single_call_ms_min"] = host_inputs["single_call_ms_min"]
+        cfg["single_call_blobs_per_s"] = host_inputs["single_call_blobs_per_s"]
+        cfg["single_call_ms_device_hash"] = host_inputs["single_call_ms_device_hash"]
+        cfg["host_stream_blobs_per_s"] = host_inputs["stream_blobs_per_s"]         # pageable host memory -> HBM inside the call
+        cfg["host_stream_h2d_gbps"] = host_inputs["stream_h2d_gbps"]
+    if mid_size:
+        cfg["mid_size_blobs_per_s"] = mid_size["blobs_per_s"]                      # 1024-batch sets (8.6 GB), three in flight
+        cfg["mid_size_one_set_blobs_per_s"] = mid_size["blobs_per_s_one_set_at_a_time"]
+    if power:
+        cfg["sclk_mhz_median"] = power["sclk_mhz"]["median"]
+        cfg["socket_power_w_median"] = power["socket_power_w"]["median"]
+    if msm_legs:
+        for op in ("commit", "proof"):
+            d = msm_legs[op]
+            cfg[f"{op}_blobs_per_s"] = d["blobs_per_s"]
+            cfg[f"{op}_ms_per_launch"] = d["ms_per_launch"]
+            cfg[f"{op}_g1_sweep_hbm_frac"] = d["g1_sweep_hbm_frac"]
+            cfg[f"{op}_traffic_over_algorithmic"] = d["traffic_over_algorithmic"]
+            cfg[f"{op}_gather_frac"] = d.get("gather_frac")
+        cfg["commit_msm_bits"] = msm_legs["msm_bits"]
+        cfg["commit_table_gb"] = msm_legs["table_gb"]
+        cfg["commit_blobs_per_launch"] = msm_legs["blobs_per_launch"]
+        cfg["proof_quotient_ms"] = msm_legs["proof"]["kernel_ms"].get("quotient")
+        cfg["msm_legs"] = msm_legs
+    if roof:
+        per = roof.get("per_kernel") or {}
+        for fam, key in (("eval", "eval"), ("challenge", "challenge"), ("validate_points", "validate"), ("lincomb", "lincomb"), ("pairing", "pairing")):
+            if fam in per:
+                roof[f"{key}_ms"] = per[fam]["avg_launch_ms"]
+                roof[f"{key}_frac"] = per[fam]["frac"]
+        alu = roof.get("alu") or {}
+        if "path_frac_of_nominal" in alu:
+            roof["alu_path_frac_of_nominal"] = alu["path_frac_of_nominal"]
+            roof["alu_path_wave_insts_per_blob"] = alu["path_valu_wave_insts_per_blob"]
+        if "path_frac_of_mix_floor" in alu:
+            roof["alu_path_frac_of_mix_floor"] = alu["path_frac_of_mix_floor"]
+        for fam, d in (alu.get("per_kernel") or {}).items():
+            if "frac_of_mix_floor" in d:
+                roof[f"alu_{fam}_frac_of_mix_floor"] = d["frac_of_mix_floor"]
+            roof[f"alu_{fam}_frac_of_nominal"] = d["frac_of_nominal"]
+    if cpu and cpu.get("all_cores"):
+        cpu["all_cores_value"] = cpu["all_cores"]["value"]
+        cpu["all_cores_threads"] = cpu["all_cores"]["threads"]
 
 
 def stream_copy_peak(torch, dev):
@@ -642,6 +776,11 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
     ceil_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "valu_ceiling.json")))
     ceiling = json.load(open(ceil_files[-1])) if ceil_files else None
     total_insts = 0.0
+    # the floor of each kernel's OWN instruction mix at the measured class rates (tools/inst_mix.py: static full-rate / half-rate counts from the
+    # gfx950 disassembly of the shipped objects x 1.12 / 1.78 ns per wave-instruction per SIMD, profiles/r02/valu_issue_rates.txt)
+    mix_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "inst_mix.json")))
+    mix = json.load(open(mix_files[-1]))["per_kernel"] if mix_files else {}
+    floor_ns_weighted = 0.0
     for fam, (tot_ms, cnt) in stats.items():
         names = KERNEL_NAMES.get(fam)
         if not names:
@@ -658,12 +797,27 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
         total_insts += insts
         out["per_kernel"][fam] = {"valu_wave_insts_per_blob": round(insts, 1), "achieved_wave_insts_per_s": rate,
                                   "frac_of_nominal": round(rate / NOMINAL_WAVE_INSTS_PER_S, 4), "wait_inst_any_frac": wait}
+        # instruction-weighted floor over the kernels of the family that ran (SQ counts as weights)
+        fl = [(d["valu_wave_insts_per_blob"], mix[k]["mix_floor_ns"]) for k, d in ((k, per[k]) for k in names if k in per) if k in mix]
+        if fam in ALTERNATIVE_FORMS:
+            fl = fl[:1]
+        if fl and rate:
+            floor_ns = sum(w * f for w, f in fl) / sum(w for w, _ in fl)
+            achieved_ns = N_SIMD / rate * 1e9
+            out["per_kernel"][fam].update({"mix_floor_ns_per_wave_inst_per_simd": round(floor_ns, 4), "achieved_ns_per_wave_inst_per_simd": round(achieved_ns, 4),
+                                           "frac_of_mix_floor": round(floor_ns / achieved_ns, 4)})
+            floor_ns_weighted += floor_ns * insts
         out["source"] = os.path.relpath(f, ROOT)
     if total_insts:
         out["path_valu_wave_insts_per_blob"] = round(total_insts, 1)
         out["path_achieved_wave_insts_per_s"] = total_insts * blobs_per_s_per_gpu
         out["path_frac_of_nominal"] = round(total_insts * blobs_per_s_per_gpu / NOMINAL_WAVE_INSTS_PER_S, 4)
         out["nominal_ceiling_blobs_per_s"] = round(NOMINAL_WAVE_INSTS_PER_S / total_insts, 1)
+        if floor_ns_weighted:
+            # the step if every kernel issued at the floor of its own mix: sum(insts x floor_ns) / 1024 SIMDs per blob
+            out["mix_floor_source"] = os.path.relpath(mix_files[-1], ROOT)
+            out["mix_floor_ceiling_blobs_per_s"] = round(N_SIMD * 1e9 / floor_ns_weighted, 1)
+            out["path_frac_of_mix_floor"] = round(blobs_per_s_per_gpu / (N_SIMD * 1e9 / floor_ns_weighted), 4)
     if ceiling:
         # context only, not a bound: measured issue rates of the instruction classes this path is made of (tools/ubench/valu_rates.hip).  Round 2
         # quoted kernel rates against "ceilings" derived from these and got fractions above 1: the ubench bodies are two loop bodies of this

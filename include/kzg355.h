@@ -119,6 +119,9 @@ typedef struct kzg355_options {
     int submit_sets;           /* submit / collect: 0 by size (sets of <= 128 blobs per CU as 1, larger ones as 2); 1 = every submitted set on a stream of its
                                   own; 2 = two-stage pipeline: stage 1 of the submitted sets in order on one stream, stage 2 of a set on a second
                                   one, queued behind the NEXT set's Fiat-Shamir kernel                                   KZG355_SUBMIT=sets|pipeline */
+    int host_hash_device_max_blobs; /* DEVICE-RESIDENT verify / blob-proof calls (the *_device entry points) of up to this many blobs copy their blobs back
+                                  to the host (8 MiB = 0.16 ms per 64) and hash the challenges on the host threads instead of the 3.7 ms device
+                                  chain: 0 = 512, -1 never; host_hash = -1 turns it off as well                          KZG355_HOST_HASH_DEVICE_MAX */
 } kzg355_options;
 void kzg355_options_default(kzg355_options *options);
 void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */

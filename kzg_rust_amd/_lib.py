@@ -17,7 +17,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_size_t)] + [(name, C.c_int) for name in (
         "device", "msm_bits", "msm_require_wide", "self_test", "host_threads", "host_hash", "host_hash_max_blobs", "host_sha", "host_rhash", "host_rhash_max_records", "challenge_form",
         "lincomb_form", "pairing_lane", "pairing_two_wave_upto", "lc_chain_from", "rhash_lanes_from", "beside_max_blobs", "split_parts",
-        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "msm_glv", "msm_eager", "pairing_hard12_from", "submit_sets")]
+        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "msm_glv", "msm_eager", "pairing_hard12_from", "submit_sets", "host_hash_device_max_blobs")]
 
 
 def load():

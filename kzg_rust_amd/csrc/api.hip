@@ -40,9 +40,9 @@ using namespace kzg;
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue run one
 // after the other.  A small call of this library is a chain on three streams, so the default lets one such call run at full speed and
 // serialises the streams of concurrent ones (threads of n = 64 calls on one handle, median ms per call at 1 / 2 / 4 / 8 threads: 2.2 / 3.0 / 5.0 / 6.9
-// with 4 queues, 2.2 / 2.3 / 2.9 / 3.3 with 24; profiles/r04/concurrent_small_calls.txt).  Unless the process has set the variable itself, ask
-// for 24 -- effective when this library is loaded before the process's first HIP call.
-__attribute__((constructor)) static void kzg355_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// with 4 queues, 2.2 / 2.3 / 2.9 / 3.3 with 24; profiles/r04/concurrent_small_calls.txt).  The variable belongs to the PROCESS: a host that serves
+// concurrent small calls exports GPU_MAX_HW_QUEUES=24 before its first HIP call (kzg_rust_amd/_lib.py and bench.py do).  The library
+// does not touch the environment (round 4 set it from a constructor: ADVICE r4); it reads the variable once per handle and otherwise assumes 4.
 
 namespace {
 
@@ -85,12 +85,13 @@ struct Workspace {
     // work on the side streams that the main stream has not waited for yet: everything (ev_join: the validation verdicts are in the error
     // words), the decoded points alone (ev_pts; recorded only when they are ready before the verdicts), the window shifts (ev_shift)
     bool side_pending = false, pts_pending = false, shift_pending = false;
-    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, pair_f, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests, zpow;
+    DevBuf blobs, commitments, proofs, records, z, y, pts, scal_a, scal_b, scal_c, pair_pts, pair_f, ok, err, digits, partials, q, out48, small, lc_partials, shifts, digests, zpow, qprep;
     bool shift_ready = false;        // stage 1 has queued the window shifts of this launch set's points (pre-shifted lincomb)
     PinBuf h_ok, h_err, h_out, h_digests, h_records, h_rdig;
     PinBuf h_stage, h_stage_cp;      // pinned staging of caller memory (blobs; commitments | proofs): slot of the host pipeline
     hipEvent_t ev[32];
     bool ev_ok = false;
+    hipEvent_t ev_d2h[8] = {};       // device-resident small calls hashed on the host: one event per chunk of the blobs' way back (host_hash_from_device)
     bool in_flight = false;          // a launch set has been enqueued on `stream` and not collected yet
     bool owns_side = false, owns_side2 = false;
     hipStream_t borrowed[2] = {nullptr, nullptr};   // the handle's pipeline streams while a submitted set of this workspace is on them
@@ -107,10 +108,11 @@ struct Workspace {
         in_flight = false; side_pending = false; pts_pending = false; shift_pending = false; shift_ready = false;
     }
     ~Workspace() {
-        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &pair_f, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow}) b->release();
+        for (DevBuf *b : {&blobs, &commitments, &proofs, &records, &z, &y, &pts, &scal_a, &scal_b, &scal_c, &pair_pts, &pair_f, &ok, &err, &digits, &partials, &q, &out48, &small, &lc_partials, &shifts, &digests, &zpow, &qprep}) b->release();
         h_ok.release(); h_err.release(); h_out.release(); h_stage.release(); h_stage_cp.release(); h_digests.release(); h_records.release(); h_rdig.release();
         if (ev_ok) for (auto &e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_join, ev_pts, ev_shift, ev_stage, ev_done, ev_fork2}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_d2h) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(own_stream);       // (side is the handle's shared stream unless owns_side)
         if (owns_side && side) (void)hipStreamDestroy(side);
         if (owns_side2 && side2) (void)hipStreamDestroy(side2);
@@ -128,6 +130,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
+    int quotient_form = 0;    // k_quotient_tree: 0 by size, 2 / 4 / 6 = 2^form leaves per lane (KZG355_QUOTIENT_FORM: tuning knob and test hook, not an option)
     int lc_chain_from = 1024;      // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM).  Round 4, with the chain walked by quads and sets kept in flight (blobs/s, three sets in flight, 16 chains per class against one): 512 batches 2.81 M either way, 1024 3.99 -> 4.03 M, 2048 4.14 -> 4.26 M, 4096 4.25 -> 4.36 M (profiles/r04/chain_from_sweep.txt); one set at a time it is within +-2 % from 512 to 4096
     int rhash_lanes_from = 1024;   // batches per launch set from which the r-transcripts are hashed one lane per batch (KZG355_RHASH_LANES_FROM); measured: 1024 batches of 512 records 6.75 -> 3.47 ms, 8192 of 64: 2.44 -> 0.57 ms
     int lincomb_mode = 0;     // 0 auto, 1 windowed per-term, 2 bucket method, 3 pre-shifted (KZG355_LINCOMB=window|bucket|preshift)
@@ -142,15 +145,18 @@ struct kzg355_settings {
     hipStream_t pipe_main = nullptr, pipe_tail = nullptr;         // submit / collect: stage 1 of every submitted set in order on pipe_main, stage 2 on pipe_tail
     std::mutex pipe_mu;                                           // orders the submits / collects that queue work on the two
     struct kzg355_ticket *pending_tail = nullptr;                 // the submitted set whose stage 2 is not queued yet (it goes out behind the next set's hash)
-    std::atomic<int> tickets_out{0};                              // submitted and not yet collected (freeing the handle then is the caller's bug: the device is drained first)
+    std::atomic<int> tickets_out{0};                              // submitted and not yet collected
+    bool free_deferred = false;                                   // kzg355_free_trusted_setup came while tickets were out (the caller's bug): the handle stays alive until the last of them is collected (under pipe_mu)
     bool own_side_streams = true;    // side streams per workspace (round 4; KZG355_SIDE=shared: one pair per handle, round 3's form) -- measured with
                                      // 4 threads of n = 64 calls: median call 5.0-7.9 ms shared, 3.6-5.2 ms own (4 hardware queues), 2.5-3.9 ms own with 8 queues
     std::atomic<int> calls_in_flight{0};   // host-buffer calls inside host_pipeline right now
-    int hw_queues = 4;                     // GPU_MAX_HW_QUEUES as the process has it (the runtime's default is 4; kzg355_runtime_defaults asks for 24)
+    int hw_queues = 4;                     // GPU_MAX_HW_QUEUES as the process has it when the handle is loaded (the runtime's default is 4)
     int submit_mode = 0;             // 0 by size; 1: every submitted set on its workspace's own stream; 2: two-stage software pipeline over pipe_main / pipe_tail (KZG355_SUBMIT=sets|pipeline)
     int host_hash = 0;               // Fiat-Shamir hashing of host-buffer calls on host threads: 0 by size (<= host_hash_max blobs), 1 always, -1 never (KZG355_HOST_HASH=auto|on|off)
     int host_hash_max = 4096;        // blobs per call up to which the host hashes (KZG355_HOST_HASH_MAX): measured, profiles/r03/host_hash_crossover_v4.txt: host route ahead up to 4096 blobs (17.1 against 18.4 ms), level at 8192
+    int host_hash_device_max = 512;  // device-resident verify / blob-proof calls of up to this many blobs copy them BACK and hash on the host threads (0.16 ms of D2H per 64 blobs + ~35 us x blobs / threads against the 3.7 ms device chain); KZG355_HOST_HASH_DEVICE_MAX, 0 in the options = 512, -1 never
     int host_rhash = 0;              // batch challenge r of lone small calls hashed on the host (records copied back): 0 by size, -1 never (KZG355_HOST_RHASH=off)
+    int host_rhash_loaded = 0;       // ... as the handle was loaded: kzg355_settings_set_host_hash(-1) forces -1, any other mode puts this back
     int host_rhash_max_records = 256;    // records per call up to which that is done
     int sha_impl = 0;                // host SHA-256 form: 0 auto (SHA extensions when the CPU has them), 1 portable, 2 SHA extensions (KZG355_HOST_SHA=portable|shani)
     std::atomic<long> n_host_hashed{0};   // introspection: host-buffer calls whose challenges were hashed on the host
@@ -167,6 +173,11 @@ struct kzg355_settings {
     int msm_bits_wanted = 0, msm_glv = 1;
     bool msm_required = false;
     std::once_flag wide_once;
+    // The table is PUBLISHED, not written into `t`: launches copy `t` by value while another thread may be building, so `t` stays as the load
+    // left it and msm_to_host takes shape + rows from here (release-stored once the new table has passed its check against the bucket form).
+    struct WidePub { WideShape shape; WideRow *rows; };
+    WidePub wide_store{};
+    std::atomic<const WidePub *> wide_pub{nullptr};
     int wide_rc = KZG355_OK;                  // what building it returned (msm_require_wide: a failure fails the calls that need it)
     bool timing = false;
     struct KStat { double last = -1, total = 0; long count = 0; };
@@ -308,9 +319,51 @@ struct HostFront {
     const uint8_t *h_blobs = nullptr;   // the call's blobs in caller memory: copied to the device AFTER the point kernels are queued
     size_t bytes = 0;
     bool running = false;
+    // device-resident form (host_hash_from_device): the blobs are in HBM already; they come BACK in chunks behind the point kernels' fork and the
+    // hashing job is started there (run_stage1 / msm_op_enqueue), not by the caller
+    const uint8_t *d_commitments = nullptr;
+    size_t n_blobs = 0;
+    bool from_device = false;
     void finish() { if (running) { running = false; pool->finish(job); job.reset(); } }
     ~HostFront() { finish(); }
 };
+
+// A small DEVICE-RESIDENT call (one 64-blob batch already in HBM took 5.3 ms against 1.97 ms for the same batch arriving in host
+// memory, because only host-buffer calls had the host hash).  The blobs go back over PCIe in up to eight chunks (8 MiB = 0.16 ms for 64 blobs), each
+// followed by an event; the hashing job's index k (blobs 2k, 2k + 1, interleaved) waits for the event of its chunk and hashes out of the pinned
+// slot -- the first pairs are being hashed while the later chunks are still on the wire.  Queued on w->stream AFTER the point kernels have forked
+// off it (their side streams do not wait for the copies).  Leaves hf->running set; the caller joins the job and uploads the digests.
+int host_hash_from_device(kzg355_settings *s, Workspace *w, HostFront *hf, const uint8_t *d_blobs) {
+    int rc;
+    const size_t nb = hf->n_blobs, BB = blob_bytes_of(s);
+    if ((rc = w->h_stage.ensure(BB * nb)) || (rc = w->h_stage_cp.ensure(48 * nb)) || (rc = w->h_digests.ensure(32 * nb)) || (rc = w->digests.ensure(32 * nb))) return rc;
+    size_t nch = (nb + 1) / 2 < 8 ? (nb + 1) / 2 : 8;
+    size_t per = (nb + nch - 1) / nch;
+    per += per & 1;                                               // whole pairs per chunk
+    nch = (nb + per - 1) / per;
+    for (size_t c = 0; c < nch; c++)
+        if (!w->ev_d2h[c] && hipEventCreateWithFlags(&w->ev_d2h[c], hipEventDisableTiming) != hipSuccess) { w->ev_d2h[c] = nullptr; (void)hipGetLastError(); return KZG355_DEVICE_ERROR; }
+    HIPCHK(hipMemcpyAsync(w->h_stage_cp.p, hf->d_commitments, 48 * nb, hipMemcpyDeviceToHost, w->stream));
+    for (size_t c = 0; c < nch; c++) {
+        const size_t lo = c * per, cnt = nb - lo < per ? nb - lo : per;
+        HIPCHK(hipMemcpyAsync(w->h_stage.as<uint8_t>() + BB * lo, d_blobs + BB * lo, BB * cnt, hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(hipEventRecord(w->ev_d2h[c], w->stream));
+    }
+    uint8_t *dig = w->h_digests.as<uint8_t>();
+    const uint8_t *hb = w->h_stage.as<uint8_t>(), *hcm = w->h_stage_cp.as<uint8_t>();
+    const uint64_t n_fe = (uint64_t)s->t.n_fe; const int impl = s->sha_impl;
+    hipEvent_t evs[8];
+    for (size_t c = 0; c < 8; c++) evs[c] = w->ev_d2h[c];
+    struct Ev8 { hipEvent_t e[8]; } ev8; memcpy(ev8.e, evs, sizeof evs);
+    auto job = [=](size_t k) {
+        (void)hipEventSynchronize(ev8.e[(2 * k) / per]);          // (chunks hold whole pairs: both blobs of the pair are behind this event)
+        kzg_host::challenge_digests(dig + 64 * k, hb + BB * 2 * k, BB, hcm + 96 * k, nb - 2 * k < 2 ? nb - 2 * k : 2, n_fe, impl);
+    };
+    hf->job = s->host_pool->begin((nb + 1) / 2, job);
+    hf->pool = s->host_pool; hf->running = true;
+    s->n_host_hashed++;
+    return KZG355_OK;
+}
 
 // The point work of stage 1 depends on nothing but the inputs, so for small calls it runs BESIDE the main chain:
 //   side    point validation (utils.rs:282-310); in the pre-shifted form of the linear combination as two kernels, so that the decoded
@@ -394,7 +447,8 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
     if (hf) {
         // the blobs follow the point kernels into their queues (the copy from pageable memory holds the host thread for its duration);
         // then the digests the host threads have been computing meanwhile: 32 bytes per blob instead of a 2050-compression chain
-        HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
+        if (hf->from_device) { if ((rc = host_hash_from_device(s, w, hf, d_blobs))) return rc; }
+        else HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
         hf->finish();
         HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * (size_t)n_total, hipMemcpyHostToDevice, w->stream));
         tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(), d_records, w->stream); tm.end();
@@ -532,6 +586,17 @@ int verify_collect(Workspace *w, Timed &tm, bool *ok, int *status, int G, size_t
     return first;
 }
 
+thread_local bool tl_msm_inner = false;      // this thread is inside the build (or the load-time self-test): its MSM calls take the handle as it is
+thread_local const kzg355_settings::WidePub *tl_wide_candidate = nullptr;   // ... and, while the builder checks it, the table that is not published yet
+thread_local bool tl_force_bucket = false;   // the load-time self-test's second opinion: the bucket form although a table is published
+// a device-resident call small enough that bringing its blobs back and hashing them on the host threads beats the device's 3.7 ms hash chain; not while
+// submitted sets are in flight (their caller is feeding a pipeline from one thread: the join of the hashing job would stall it)
+bool device_call_hashes_on_host(const kzg355_settings *s, size_t n_blobs) {
+    if (tl_msm_inner) return false;                               // the load-time self-test checks the DEVICE kernels: its calls keep the device hash
+    return !is_small(s) && s->host_pool && s->host_hash >= 0 && s->host_hash_device_max > 0 && n_blobs <= (size_t)s->host_hash_device_max &&
+           s->tickets_out.load() == 0;
+}
+
 int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, size_t npg, size_t groups,
                             const kzg355_settings *cs) {
     if (!cs || !ok) return KZG355_BADARGS;
@@ -540,7 +605,7 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         for (size_t g = 0; g < groups; g++) { ok[g] = true; if (status) status[g] = KZG355_OK; }
         return KZG355_OK;
     }
-    if (npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    if (npg > (size_t)1 << 24 || groups > (size_t)1 << 24 || npg * groups > (size_t)1 << 24) return KZG355_BADARGS;
     if (!d_blobs || !d_c || !d_p || ((uintptr_t)d_blobs & 15) || ((uintptr_t)d_c & 3) || ((uintptr_t)d_p & 3)) return KZG355_BADARGS;   // 16-byte loads of the blobs
     // Optional (KZG355_SPLIT=parts[,streams]): cut the call into `parts` launch sets dealt round-robin to `streams` workspaces, so
     // that the narrow kernels of one set (r powers, Horner tail) run under the wide kernels of another.  Measured
@@ -556,7 +621,11 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
         WsGuard g(cs);
         if (!g.w) return KZG355_NO_DEVICE;
         Timed tm(g.s, g.w);
-        int rc = verify_enqueue(g.s, g.w, tm, d_blobs, d_c, d_p, (int)npg, (int)groups, 0, 0, nullptr, true);
+        HostFront hf;
+        const bool via_host = device_call_hashes_on_host(g.s, npg * groups);
+        struct InFlight { std::atomic<int> *n; ~InFlight() { if (n) (*n)--; } } in_flight{nullptr};
+        if (via_host) { hf.from_device = true; hf.d_commitments = d_c; hf.n_blobs = npg * groups; g.s->calls_in_flight++; in_flight.n = &g.s->calls_in_flight; }
+        int rc = verify_enqueue(g.s, g.w, tm, d_blobs, d_c, d_p, (int)npg, (int)groups, 0, 0, via_host ? &hf : nullptr, true);
         if (rc) return rc;
         return verify_collect(g.w, tm, ok, status, (int)groups);
     }
@@ -611,7 +680,6 @@ int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, c
 // the widest GLV form whose table (plus the ~7.5 GB the build parks its Jacobian runs in) fits HALF of the HBM that is free at that
 // moment: 16-bit windows 143.5 GB (16 rows per scalar), 15: 68.9 GB (18), 13: 20.1 GB (20), 12: 10.9 GB (22).  Then a check of the new
 // table against the bucket form on two known blobs; a table that fails it is dropped (bucket form from then on, said on stderr).
-thread_local bool tl_msm_inner = false;      // this thread is inside the build (or the load-time self-test): its MSM calls take the handle as it is
 int ensure_wide_table(kzg355_settings *s) {
     if (s->msm_bits_wanted == 8 || tl_msm_inner || is_small(s)) return KZG355_OK;
     std::call_once(s->wide_once, [s] {
@@ -630,35 +698,52 @@ int ensure_wide_table(kzg355_settings *s) {
             if (bits == 0) { s->wide_table_failed = true; s->wide_rc = KZG355_NO_MEMORY; }
         }
         if (bits) {
-            s->t.wide = wide_shape(bits, s->msm_glv != 0);
-            if (s->wide.ensure(wide_table_bytes(s->t.wide)) != KZG355_OK) { s->wide_table_failed = true; s->wide_rc = KZG355_NO_MEMORY; }
+            const WideShape shape = wide_shape(bits, s->msm_glv != 0);
+            if (s->wide.ensure(wide_table_bytes(shape)) != KZG355_OK) { s->wide_table_failed = true; s->wide_rc = KZG355_NO_MEMORY; }
             else {
                 DeviceTables t = s->t;
+                t.wide = shape;
                 t.wide_table = s->wide.as<WideRow>();
+                s->wide_store = kzg355_settings::WidePub{shape, t.wide_table};
                 if (build_wide_table(t, nullptr)) { s->wide.release(); s->wide_table_failed = true; s->wide_rc = KZG355_DEVICE_ERROR; }
                 else {
-                    // the new table against the bucket form: the all-ones blob and the blob (w_0, .., w_{N-1}), bit for bit
+                    // the new table against the bucket form, bit for bit, on three blobs: all ones; (w_0, .., w_{N-1}) -- 255-bit elements, both GLV
+                    // halves of every scalar busy; and a blob of extreme digits: r - 1 - i at even positions (the largest canonical elements), at odd
+                    // positions 0x0080 0x8000 ... (every 16-bit digit of both halves at the sign boundary of the recoding) with i folded in
                     const size_t BB = blob_bytes_of(s);
                     DevBuf blobs;
-                    uint8_t c_wide[96], c_bucket[96]; int st[2] = {0, 0};
-                    int rc = blobs.ensure(2 * BB);
+                    uint8_t c_wide[144], c_bucket[144]; int st[3] = {0, 0, 0};
+                    int rc = blobs.ensure(3 * BB);
                     if (rc == KZG355_OK) {
-                        std::vector<uint8_t> ones(BB, 0);
-                        for (size_t i = 0; i < (size_t)s->t.n_fe; i++) ones[32 * i + 31] = 1;
+                        std::vector<uint8_t> ones(BB, 0), ext(BB, 0);
+                        static const uint8_t R_BE[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+                                                         0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+                        for (size_t i = 0; i < (size_t)s->t.n_fe; i++) {
+                            ones[32 * i + 31] = 1;
+                            uint8_t *e = ext.data() + 32 * i;
+                            if (i & 1) { for (int k = 0; k < 32; k++) e[k] = (k & 1) ? 0x00 : 0x80; e[0] = 0x00; e[30] ^= (uint8_t)(i >> 8); e[31] ^= (uint8_t)i; }
+                            else {      // r - 1 - i: big-endian subtraction of 1 + i with borrow
+                                memcpy(e, R_BE, 32);
+                                uint32_t sub = 1 + (uint32_t)i;
+                                for (int k = 31; k >= 0 && sub; k--) { const uint32_t d = sub & 0xff; sub >>= 8; if (e[k] >= d) e[k] = (uint8_t)(e[k] - d); else { e[k] = (uint8_t)(e[k] + 256 - d); sub += 1; } }
+                            }
+                        }
                         if (hipMemcpy(blobs.p, ones.data(), BB, hipMemcpyHostToDevice) != hipSuccess) rc = KZG355_DEVICE_ERROR;
+                        if (hipMemcpy(blobs.as<uint8_t>() + 2 * BB, ext.data(), BB, hipMemcpyHostToDevice) != hipSuccess) rc = KZG355_DEVICE_ERROR;
                         launch_fr_to_bytes(s->t.roots, s->t.n_fe, blobs.as<uint8_t>() + BB, nullptr);
                         if (hipDeviceSynchronize() != hipSuccess) rc = KZG355_DEVICE_ERROR;
                     }
-                    tl_msm_inner = true;                      // (the two commitments below must not come back here)
-                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_bucket, st, blobs.as<uint8_t>(), nullptr, 2, s);
-                    s->t.wide_table = t.wide_table;
-                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_wide, st, blobs.as<uint8_t>(), nullptr, 2, s);
+                    tl_msm_inner = true;                      // (the commitments below must not come back here)
+                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_bucket, st, blobs.as<uint8_t>(), nullptr, 3, s);        // nothing published yet: bucket form
+                    tl_wide_candidate = &s->wide_store;
+                    if (rc == KZG355_OK) rc = msm_op_many_device_impl(c_wide, st, blobs.as<uint8_t>(), nullptr, 3, s);
+                    tl_wide_candidate = nullptr;
                     tl_msm_inner = false;
                     blobs.release();
-                    if (rc != KZG355_OK || memcmp(c_wide, c_bucket, 96) != 0) {
+                    if (rc != KZG355_OK || memcmp(c_wide, c_bucket, 144) != 0) {
                         fprintf(stderr, "kzg355: the wide-window MSM table failed its check against the bucket form (status %d): dropped\n", rc);
-                        s->t.wide_table = nullptr; s->wide.release(); s->wide_table_failed = true; s->wide_rc = rc != KZG355_OK ? rc : KZG355_INTERNAL;
-                    }
+                        s->wide.release(); s->wide_table_failed = true; s->wide_rc = rc != KZG355_OK ? rc : KZG355_INTERNAL;
+                    } else s->wide_pub.store(&s->wide_store, std::memory_order_release);
                 }
             }
         }
@@ -679,8 +764,11 @@ int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_
     if ((rc = w->partials.ensure(sizeof(G1Jac) * (size_t)n * MSM_WINDOWS))) return rc;
     if ((rc = w->out48.ensure(48 * (size_t)n))) return rc;
     if ((rc = w->h_out.ensure(48 * (size_t)n))) return rc;
-    if (s->t.wide_table) {
-        tm.begin("msm_wide"); launch_msm_wide(d_blobs, d_scalars, s->t, n, w->partials.as<G1Jac>(), w->err.as<int>(), w->stream); tm.end();
+    const kzg355_settings::WidePub *wp = tl_force_bucket ? nullptr : tl_wide_candidate ? tl_wide_candidate : s->wide_pub.load(std::memory_order_acquire);
+    if (wp) {
+        DeviceTables t = s->t;
+        t.wide = wp->shape; t.wide_table = wp->rows;
+        tm.begin("msm_wide"); launch_msm_wide(d_blobs, d_scalars, t, n, w->partials.as<G1Jac>(), w->err.as<int>(), w->stream); tm.end();
         tm.begin("msm_finalize"); launch_msm_finalize(w->partials.as<G1Jac>(), n, w->out48.as<uint8_t>(), w->stream, msm_wide_partials_per_blob(n)); tm.end();
     } else {
         if ((rc = w->digits.ensure((size_t)BLOB_BYTES * n))) return rc;
@@ -699,9 +787,12 @@ int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_
 int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, int n) {
     int rc;
     if ((rc = w->y.ensure(sizeof(Fr) * (size_t)n))) return rc;
-    if ((rc = w->q.ensure(sizeof(Fr) * (size_t)n * N_FE))) return rc;
-    tm.begin("quotient"); launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<Fr>(), w->err.as<int>(), w->stream); tm.end();
-    return msm_to_host(s, w, tm, n, nullptr, w->q.as<Fr>());
+    if ((rc = w->q.ensure((size_t)BLOB_BYTES * n))) return rc;                  // the quotient in the blob format: the MSM reads it like a blob
+    if ((rc = w->qprep.ensure(quotient_scratch_bytes(n)))) return rc;
+    tm.begin("quotient");
+    if (launch_quotient(d_blobs, w->z.as<Fr>(), s->t, n, w->y.as<Fr>(), w->q.as<uint8_t>(), w->qprep.p, w->err.as<int>(), w->stream, s->quotient_form)) return KZG355_DEVICE_ERROR;
+    tm.end();
+    return msm_to_host(s, w, tm, n, w->q.as<uint8_t>(), nullptr);
 }
 
 // n commitments (d_c == null) or n blob proofs against the commitments d_c: enqueue on w->stream ...
@@ -750,7 +841,8 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
             HIPCHK(hipEventRecord(w->ev_join, w->side));
         } else { tm.begin("validate_points"); launch_validate_points(d_c, nullptr, (int)n, 1, nullptr, w->err.as<int>(), w->stream); tm.end(); }
         if (hf) {                                                 // challenges hashed on the host (see run_stage1)
-            HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
+            if (hf->from_device) { if ((rc = host_hash_from_device(s, w, hf, d_blobs))) return rc; }
+            else HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
             hf->finish();
             HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * n, hipMemcpyHostToDevice, w->stream));
             tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, nullptr, w->stream); tm.end();
@@ -784,7 +876,11 @@ int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, c
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     Timed tm(g.s, g.w);
-    int rc = msm_op_enqueue(g.s, g.w, tm, d_blobs, d_c, n);
+    HostFront hf;
+    const bool via_host = d_c && device_call_hashes_on_host(g.s, n);      // blob proofs: the challenge hashes the blob (kzg.rs:298-339)
+    struct InFlight { std::atomic<int> *n; ~InFlight() { if (n) (*n)--; } } in_flight{nullptr};
+    if (via_host) { hf.from_device = true; hf.d_commitments = d_c; hf.n_blobs = n; g.s->calls_in_flight++; in_flight.n = &g.s->calls_in_flight; }
+    int rc = msm_op_enqueue(g.s, g.w, tm, d_blobs, d_c, n, via_host ? &hf : nullptr);
     if (rc) return rc;
     return msm_op_collect(g.w, tm, out, status, n);
 }
@@ -975,6 +1071,8 @@ void kzg355_options_from_env(kzg355_options *o) {
     num("KZG355_HOST_THREADS", 1, 64, &o->host_threads);
     if (const char *e = getenv("KZG355_HOST_HASH")) o->host_hash = strcmp(e, "on") == 0 ? 1 : strcmp(e, "off") == 0 ? -1 : 0;
     num("KZG355_HOST_HASH_MAX", 1, 1 << 24, &o->host_hash_max_blobs);
+    num("KZG355_HOST_HASH_DEVICE_MAX", 0, 1 << 24, &o->host_hash_device_max_blobs);
+    if (getenv("KZG355_HOST_HASH_DEVICE_MAX") && o->host_hash_device_max_blobs == 0) o->host_hash_device_max_blobs = -1;      // "0": never
     if (const char *e = getenv("KZG355_HOST_SHA")) o->host_sha = strcmp(e, "portable") == 0 ? 1 : strcmp(e, "shani") == 0 ? 2 : 0;
     if (const char *e = getenv("KZG355_HOST_RHASH")) o->host_rhash = strcmp(e, "off") == 0 ? -1 : 0;
     num("KZG355_HOST_RHASH_MAX", 1, 1 << 20, &o->host_rhash_max_records);
@@ -1083,8 +1181,9 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         s->host_pool = new HostPool(workers - 1);                            // the calling thread is one of the workers
         s->host_hash = opt.host_hash;
         if (opt.host_hash_max_blobs > 0) s->host_hash_max = opt.host_hash_max_blobs;
+        if (opt.host_hash_device_max_blobs != 0) s->host_hash_device_max = opt.host_hash_device_max_blobs > 0 ? opt.host_hash_device_max_blobs : 0;
         s->sha_impl = opt.host_sha;
-        s->host_rhash = opt.host_rhash;
+        s->host_rhash = s->host_rhash_loaded = opt.host_rhash;
         if (opt.host_rhash_max_records > 0) s->host_rhash_max_records = opt.host_rhash_max_records;
         if (opt.chunk_mb > 0) s->chunk_bytes = (size_t)opt.chunk_mb << 20;
         s->pinned_ring = opt.staging_ring != 0;
@@ -1099,6 +1198,7 @@ static int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_
         s->rhash_lanes_from = opt.rhash_lanes_from > 0 ? opt.rhash_lanes_from : 4 * cus;     // transcript hash with a lane per batch from one wave per SIMD on (1024)
         s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
         s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;     // two waves per pairing up to 256 batches
+        if (const char *e = getenv("KZG355_QUOTIENT_FORM")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 6) s->quotient_form = v; }
         if (const char *e = getenv("KZG355_MILLER_SEGMENTS")) { const int v = atoi(e); if (v >= 1 && v <= MILLER_SPLIT_MAX) s->miller_segments = v; }      // (tuning knob, not an option)
         s->pairing_hard12_from = opt.pairing_hard12_from < 0 ? 0 : opt.pairing_hard12_from > 0 ? opt.pairing_hard12_from : 16 * cus;   // hard part twelve lanes per check from 4096 batches on
         s->challenge_two_wave_upto = 2 * cus * 64;                                           // two-wave hash while every wave has a SIMD to itself (512 workgroups of 64 blobs)
@@ -1174,12 +1274,11 @@ static int device_self_test(kzg355_settings *s) {
         // Either the arithmetic is wrong or the caller's points are not a Lagrange basis of this domain (the reference loads any
         // on-curve points that pass its pairing check, kzg.rs:833-899).  Tell the two apart with the other, independent MSM form:
         // if both forms agree the setup is merely unusual and the identities above do not apply -- nothing more can be checked.
-        if (!s->t.wide_table) { blobs.release(); return KZG355_OK; }
-        WideRow *keep = s->t.wide_table;
+        if (!s->wide_pub.load(std::memory_order_acquire)) { blobs.release(); return KZG355_OK; }
         uint8_t c2[96];
-        s->t.wide_table = nullptr;
+        tl_force_bucket = true;
         rc = msm_op_many_device_impl(c2, st, blobs.as<uint8_t>(), nullptr, 2, s);
-        s->t.wide_table = keep;
+        tl_force_bucket = false;
         if (rc != KZG355_OK || memcmp(c, c2, 96) != 0) return fail("the wide-table and the bucket form of the MSM disagree");
         blobs.release();
         return KZG355_OK;
@@ -1399,9 +1498,15 @@ static void free_single(kzg355_settings *s) {
     if (!s) return;
     DeviceScope scope;
     (void)scope.enter(s->device);
-    if (s->tickets_out.load() > 0) {          // a caller's bug (kzg355.h: collect every ticket first); at least nothing may still be running on what is freed below
-        fprintf(stderr, "kzg355: handle freed with %d submitted launch set(s) not collected: their tickets are now invalid\n", s->tickets_out.load());
-        (void)hipDeviceSynchronize();
+    {
+        // a caller's bug (kzg355.h: collect every ticket first).  The tickets hold this handle, its workspaces and streams: the free is DEFERRED to the
+        // collect of the last of them (kzg355_verify_collect) -- nothing is leaked and no ticket dangles
+        std::lock_guard<std::mutex> lk(s->pipe_mu);
+        if (s->tickets_out.load() > 0) {
+            fprintf(stderr, "kzg355: handle freed with %d submitted launch set(s) not collected: it is released when the last of them is collected\n", s->tickets_out.load());
+            s->free_deferred = true;
+            return;
+        }
     }
     for (Workspace *w : s->pool) delete w;
     s->pool.clear();
@@ -1429,31 +1534,32 @@ int kzg355_settings_device(const kzg355_settings *s) { return s ? s->device : -1
 int kzg355_settings_field_elements_per_blob(const kzg355_settings *s) { return s ? s->t.n_fe : 0; }
 int kzg355_settings_msm_form(const kzg355_settings *s) {
     if (!s) return 0;
-    if (s->t.wide_table) return s->t.wide.bits;
+    if (const kzg355_settings::WidePub *wp = s->wide_pub.load(std::memory_order_acquire)) return wp->shape.bits;
     if (s->wide_table_failed) return -8;
     return s->msm_bits_wanted == 8 ? 8 : s->msm_bits_wanted;     // not built yet: the width asked for, 0 = to be sized from the free HBM
 }
 int kzg355_settings_msm_shape(const kzg355_settings *s, int *bits, int *windows, int *glv, size_t *table_bytes) {
     if (!s) return KZG355_BADARGS;
-    const bool built = s->t.wide_table != nullptr;
-    if (bits) *bits = built ? s->t.wide.bits : 0;
-    if (windows) *windows = built ? s->t.wide.windows : 0;
-    if (glv) *glv = built ? s->t.wide.glv : 0;
-    if (table_bytes) *table_bytes = built ? wide_table_bytes(s->t.wide) : 0;
+    const kzg355_settings::WidePub *wp = s->wide_pub.load(std::memory_order_acquire);
+    const bool built = wp != nullptr;
+    if (bits) *bits = built ? wp->shape.bits : 0;
+    if (windows) *windows = built ? wp->shape.windows : 0;
+    if (glv) *glv = built ? wp->shape.glv : 0;
+    if (table_bytes) *table_bytes = built ? wide_table_bytes(wp->shape) : 0;
     return KZG355_OK;
 }
 int kzg355_settings_build_msm_table(const kzg355_settings *cs) {
     if (!cs) return KZG355_BADARGS;
     kzg355_settings *s = const_cast<kzg355_settings *>(cs);
     for (kzg355_settings *r : replicas_of(s)) { const int rc = ensure_wide_table(r); if (rc) return rc; }
-    return s->t.wide_table ? KZG355_OK : (s->msm_bits_wanted == 8 ? KZG355_OK : s->wide_rc == KZG355_OK ? KZG355_NO_MEMORY : s->wide_rc);
+    return s->wide_pub.load(std::memory_order_acquire) ? KZG355_OK : (s->msm_bits_wanted == 8 ? KZG355_OK : s->wide_rc == KZG355_OK ? KZG355_NO_MEMORY : s->wide_rc);
 }
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s) { return s ? s->n_host_hashed.load() : 0L; }
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs) {
     if (!s || mode < -1 || mode > 1 || max_blobs < 0) return KZG355_BADARGS;
     // both Fiat-Shamir hashes follow the mode: -1 keeps the per-blob challenges AND the batch challenge r on the device
-    for (kzg355_settings *r : s->multi ? replicas_of(s) : std::vector<kzg355_settings *>{s}) { r->host_hash = mode; r->host_rhash = mode < 0 ? -1 : 0; if (max_blobs) r->host_hash_max = max_blobs; }
+    for (kzg355_settings *r : s->multi ? replicas_of(s) : std::vector<kzg355_settings *>{s}) { r->host_hash = mode; r->host_rhash = mode < 0 ? -1 : r->host_rhash_loaded; if (max_blobs) r->host_hash_max = max_blobs; }
     return KZG355_OK;
 }
 int kzg355_host_sha256(uint8_t out[32], const uint8_t *msg, size_t len, int impl) {
@@ -1525,7 +1631,7 @@ int kzg355_verify_blob_kzg_proof_batch_many_device_submit(kzg355_ticket **ticket
                                                           const uint8_t *d_proofs, size_t n_per_group, size_t groups, const kzg355_settings *cs) {
     if (!ticket || !cs) return KZG355_BADARGS;
     *ticket = nullptr;
-    if (n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;
+    if (n_per_group > (size_t)1 << 24 || groups > (size_t)1 << 24 || n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;      // (each factor first: the product must not wrap)
     std::unique_ptr<kzg355_ticket> t(new kzg355_ticket());
     kzg355_settings *s = t->s = const_cast<kzg355_settings *>(cs);
     t->npg = n_per_group; t->groups = groups;
@@ -1590,7 +1696,6 @@ int kzg355_verify_collect(kzg355_ticket *ticket, bool *ok, int *status) {
         return KZG355_OK;
     }
     kzg355_settings *s = t->s; Workspace *w = t->w;
-    s->tickets_out--;
     DeviceScope scope;
     const bool entered = scope.enter(s->device);
     int rc = !entered ? KZG355_NO_DEVICE : KZG355_OK;
@@ -1612,6 +1717,10 @@ int kzg355_verify_collect(kzg355_ticket *ticket, bool *ok, int *status) {
     if (rc == KZG355_OK) rc = verify_collect(w, *t->tm, ok, status, (int)t->groups);
     w->quiesce();
     ws_release(s, w);
+    t.reset();
+    bool free_now;
+    { std::lock_guard<std::mutex> lk(s->pipe_mu); free_now = --s->tickets_out == 0 && s->free_deferred; }
+    if (free_now) free_single(s);                                 // the handle was freed while this ticket was out
     return rc;
 }
 
@@ -1640,7 +1749,7 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     // a refusal of the call as a whole writes nothing to d_records / d_points: every batch carries the status, so that a caller that
     // reads per-batch statuses cannot mistake it for success
     auto refuse = [&](int code) { for (size_t i = 0; i < groups; i++) status[i] = code; return code; };
-    if (n_local * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
+    if (n_local > (size_t)1 << 24 || groups > (size_t)1 << 24 || n_local * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
     if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || !d_blobs || ((uintptr_t)d_blobs & 15) || !d_commitments || !d_proofs) return refuse(KZG355_BADARGS);
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
@@ -1653,7 +1762,13 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     Timed tm(s, w);
     // any error poisons its batch, as the `?`s at kzg.rs:673-682 do for the call
     // (no window shifts here: stage 2 runs on the gathered batch, on whichever rank gets it)
-    if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, reinterpret_cast<G1Affine *>(d_points), w->err.as<int>(), false))) return rc;
+    // (a small shard -- BASELINE config 5 gives every rank 64 blobs of the one batch -- takes the host-hash route of the device-resident calls:
+    // the 3.7 ms device hash chain would be the whole of such a rank's stage 1)
+    HostFront hf;
+    const bool via_host = device_call_hashes_on_host(s, n_local * groups);
+    if (via_host) { hf.from_device = true; hf.d_commitments = d_commitments; hf.n_blobs = n_local * groups; }
+    if ((rc = run_stage1(s, w, tm, d_blobs, d_commitments, d_proofs, (int)(n_local * groups), (int)n_local, d_records, reinterpret_cast<G1Affine *>(d_points), w->err.as<int>(), false,
+                         via_host ? &hf : nullptr))) return rc;
     if ((rc = join_side(w))) return rc;
     if (d_words) {                                                // statuses stay on the device: no copy back, the caller reads them after its merge
         if ((uintptr_t)d_words & 3) return KZG355_BADARGS;
@@ -1699,7 +1814,7 @@ static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8
     if (groups == 0) return KZG355_OK;
     auto refuse = [&](int code) { if (status) for (size_t i = 0; i < groups; i++) status[i] = code; return code; };      // whole-call refusals mark every batch
     if (n == 0) return refuse(KZG355_BADARGS);                   // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
-    if (n * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
+    if (n > (size_t)1 << 24 || groups > (size_t)1 << 24 || n * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
     if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3)) return refuse(KZG355_BADARGS);      // the kernels read the records 16 bytes at a time
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
@@ -1986,7 +2101,7 @@ int kzg355_verify_blob_kzg_proof_batch_many(bool *ok, int *status, const uint8_t
 int kzg355_debug_verify_host_records(uint8_t *records_out, bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
                                      size_t n_per_group, size_t groups, const kzg355_settings *cs) {
     if (!cs || !ok || !records_out || !blobs || !commitments || !proofs || n_per_group == 0 || groups == 0 || cs->multi) return KZG355_BADARGS;
-    if (n_per_group * groups > (size_t)1 << 24 || blob_bytes_of(cs) * n_per_group * groups > ((size_t)64 << 20)) return KZG355_BADARGS;      // one chunk
+    if (n_per_group > (size_t)1 << 24 || groups > (size_t)1 << 24 || n_per_group * groups > (size_t)1 << 24 || blob_bytes_of(cs) * n_per_group * groups > ((size_t)64 << 20)) return KZG355_BADARGS;      // one chunk
     HostCall hc{0, blobs, commitments, proofs, n_per_group, ok, nullptr, status};
     hc.records_out = records_out;
     return host_pipeline(hc, groups, cs);
@@ -1995,7 +2110,7 @@ int kzg355_debug_verify_host_records(uint8_t *records_out, bool *ok, int *status
 int kzg355_debug_verify_sharded_intermediates(uint8_t *out, bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
                                               size_t n_per_group, size_t groups, const kzg355_settings *cs) {
     if (!cs || !ok || !out || !blobs || !commitments || !proofs || !cs->multi || groups == 0) return KZG355_BADARGS;
-    if (n_per_group < cs->multi->rep.size() || n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;      // every device gets a block of every batch
+    if (n_per_group < cs->multi->rep.size() || n_per_group > (size_t)1 << 24 || groups > (size_t)1 << 24 || n_per_group * groups > (size_t)1 << 24) return KZG355_BADARGS;      // every device gets a block of every batch
     return multi_verify_sharded(ok, status, blobs, commitments, proofs, n_per_group, groups, cs, out);
 }
 

@@ -6,6 +6,7 @@
 namespace kzg {
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+constexpr uint32_t FR_MOD_TOP_WORD = 0x73eda753u;    // r = 0x73eda753 299d7d48 ...: a blob element whose top word is below it is canonical
 
 KZG_HD void load_blob_element_words(uint32_t w[8], const uint8_t *blob, int e) {
 #if defined(__HIP_DEVICE_COMPILE__)

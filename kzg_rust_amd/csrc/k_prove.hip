@@ -2,6 +2,9 @@
 //   y   = p(z)                                         (kzg.rs:467, evaluate_polynomial_in_evaluation_form)
 //   q_i = (p_i - y) / (w_i - z)            i != m      (kzg.rs:470-490)
 //   q_m = sum_{i != m} (p_i - y) w_i / (z (z - w_i))   when z == w_m is inside the domain (kzg.rs:494-523)
+// Round 5: three kernels.  k_quotient_prep (a lane per blob: powers of z, the ONE inversion 1 / (z^N - 1), the list of blobs whose z is inside the
+// domain), k_quotient_tree (quot_core.h: the inverses come down a binary tree over the domain, 4.4 field products per element, q leaves as canonical
+// big-endian bytes that the fixed-base MSM reads like a blob) and, for the listed in-domain blobs only, k_quotient_scan -- the kernel of rounds 1-4:
 // One 1024-thread workgroup per blob, 4 elements per thread.  Instead of the reference's three 4096-long batch
 // inversions, T_i = prod_{j != i} (z - w_j) comes from the same "product of all the others" scan as k_eval, and
 //     1/(z - w_i) = T_i * W,   W = 1/(z^N - 1)                       (one Fr inversion per blob)
@@ -11,6 +14,7 @@
 // The 4096-point MSM over q is k_msm.hip.
 #include "kernels.h"
 #include "fr_block.h"
+#include "quot_core.h"
 
 namespace kzg {
 
@@ -39,13 +43,27 @@ __device__ __forceinline__ Fr load_p(const uint8_t *blob, int e) {
     return p;
 }
 
-__global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const Fr *z_in, const Fr *roots, Fr *y_out, Fr *q_out, int *err) {
+// q_i as the canonical 32-byte big-endian integer (the blob format: the MSM reads the quotient like a blob)
+__device__ __forceinline__ void store_q_bytes(uint8_t *q, int e, const uint32_t w[8]) {
+    uint4 *dst = reinterpret_cast<uint4 *>(q + 32 * (size_t)e);
+    dst[0] = make_uint4(bswap32(w[7]), bswap32(w[6]), bswap32(w[5]), bswap32(w[4]));
+    dst[1] = make_uint4(bswap32(w[3]), bswap32(w[2]), bswap32(w[1]), bswap32(w[0]));
+}
+
+// The scan form (rounds 1-4), now for the blobs k_quotient_prep listed only: z inside the domain.  A fixed grid walks the list.
+__global__ void __launch_bounds__(1024) k_quotient_scan(const uint8_t *blobs, const Fr *z_in, const Fr *roots, Fr *y_out, uint8_t *q_out, int *err,
+                                                        const int *list, const int *count) {
     __shared__ Fr wave_tot[16], wave_ex[16], wave_sum[16], bcast;
     __shared__ uint32_t ts[4 * NFR * 1024];           // T_k per element, [k][limb][thread] (registers are capped at 128)
     __shared__ int hit;
-    const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_listed = *count;
+#pragma unroll 1
+    for (int idx = blockIdx.x; idx < n_listed; idx += gridDim.x) {
+    const int blob_i = list[idx];
     const uint8_t *blob = blobs + (size_t)BLOB_BYTES * blob_i;
-    Fr *q = q_out + (size_t)N_FE * blob_i;
+    uint8_t *q = q_out + (size_t)BLOB_BYTES * blob_i;
+    __syncthreads();                                   // (the previous blob of this workgroup is done with the shared buffers)
     if (tid == 0) hit = -1;
     __syncthreads();
     const Fr z = z_in[blob_i];
@@ -131,7 +149,7 @@ __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const F
         const Fr p = load_p(blob, e);
         fr_sub(ymp, y, p);
         fr_mul(qe, ymp, inv);                                     // (p_i - y) / (w_i - z)
-        q[e] = qe;
+        { uint32_t qw[8]; fr_to_words(qw, qe); store_q_bytes(q, e, qw); }
         if (m >= 0) { Fr t; fr_mul(t, qe, roots[e]); fr_sub(S2, S2, t); }   // + (p_i - y) w_i / (z - w_i)
     }
     if (m >= 0) {
@@ -140,7 +158,120 @@ __global__ void __launch_bounds__(1024) k_quotient(const uint8_t *blobs, const F
             Fr zi = one, zz = z;                                  // z^-1 = z^(N-1) = z^4095 for z in the domain
             for (int i = 0; i < 12; i++) { fr_mul(zi, zi, zz); fr_sqr(zz, zz); }
             Fr qm; fr_mul(qm, S2, zi);
-            q[m] = qm;
+            uint32_t qw[8]; fr_to_words(qw, qm); store_q_bytes(q, m, qw);
+        }
+    }
+    }
+}
+
+// a lane per blob: quot_prep; blobs whose z is inside the domain go to the list of k_quotient_scan
+__global__ void __launch_bounds__(64) k_quotient_prep(const Fr *z_in, int n, QuotPrep *prep, int *list, int *count) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    QuotPrep pp;
+    if (quot_prep(pp, z_in[i])) list[atomicAdd(count, 1)] = i;
+    prep[i] = pp;
+}
+
+// The tree form: 4096 >> LG threads per blob, 2^LG leaves (consecutive positions of the bit-reversed domain: 32 x 2^LG bytes of the blob) per lane,
+// walked in groups of four leaves = one 128-byte line.  Pass 1: inverses down the tree, u_i = p_i / (z - w_i), the inverse parked in q's slot;
+// the blob's two sums; pass 2: q_i = (y - p_i) / (z - w_i).  (quot_core.h)
+template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(const uint8_t *blobs, const QuotPrep *prep, const Fr *roots, Fr *y_out, uint8_t *q_out, int *err) {
+    constexpr int TPB = 4096 >> LG, NW = TPB / 64, L = LG - 2, D0 = 12 - LG, GROUPS = 1 << L;
+    static_assert(LG >= 2 && LG <= 6 && (TPB % 64) == 0, "2^LG leaves per lane, whole waves per blob");
+    __shared__ __attribute__((aligned(16))) uint32_t red[NW][2][NFR + 1];
+    const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const QuotPrep &pp = prep[blob_i];
+    if (fr_is_zero(pp.W)) return;                                  // z inside the domain (block-uniform): k_quotient_scan's
+    const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob_i);
+    uint4 *q = reinterpret_cast<uint4 *>(q_out + (size_t)BLOB_BYTES * blob_i);
+    Fr inv0;
+    quot_path(inv0, pp, roots, D0, tid);
+    Fr c[L > 0 ? L : 1][2];
+    Fr Su = fr_zero(), Sp = fr_zero();
+    bool bad = false;
+#pragma unroll 1
+    for (int g = 0; g < GROUPS; g++) {
+#pragma unroll
+        for (int l = 0; l < L; l++) {                              // level l: the children of this lane's node at depth D0 + l that g enters now
+            if ((g & ((1 << (L - l)) - 1)) == 0) {
+                Fr src;
+                if (l == 0) src = inv0;
+                else fr_select(src, ((g >> (L - l)) & 1) != 0, c[l > 0 ? l - 1 : 0][0], c[l > 0 ? l - 1 : 0][1]);
+                const int a = (tid << l) + (g >> (L - l));
+                quot_children(c[l][0], c[l][1], src, pp.zsq[11 - (D0 + l)], roots[2 * a]);
+            }
+        }
+        Fr inv10;
+        if (L == 0) inv10 = inv0;
+        else fr_select(inv10, (g & 1) != 0, c[L > 0 ? L - 1 : 0][0], c[L > 0 ? L - 1 : 0][1]);
+        const int a10 = (tid << L) + g;
+        uint32_t pw[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 a = blob[8 * a10 + 2 * j], b = blob[8 * a10 + 2 * j + 1];
+            pw[j][7] = bswap32(a.x); pw[j][6] = bswap32(a.y); pw[j][5] = bswap32(a.z); pw[j][4] = bswap32(a.w);
+            pw[j][3] = bswap32(b.x); pw[j][2] = bswap32(b.y); pw[j][1] = bswap32(b.z); pw[j][0] = bswap32(b.w);
+        }
+        // bytes_to_bls_field (utils.rs:267-271): value < r.  The top word settles it unless it EQUALS r's top word.
+        const uint32_t top = max(max(pw[0][7], pw[1][7]), max(pw[2][7], pw[3][7]));
+        if (top >= FR_MOD_TOP_WORD) {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) bad = bad || !fr_words_canonical(pw[j]);
+        }
+        Fr inv12[4];
+        quot_group_pass1(inv12, Su, Sp, pw, inv10, a10, pp, roots);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                             // parked in q's own slot until pass 2 (this lane writes it, this lane reads it back)
+            uint32_t w[8]; limbs_to_words<NFR, 8>(w, inv12[j].l);
+            q[8 * a10 + 2 * j] = make_uint4(w[0], w[1], w[2], w[3]);
+            q[8 * a10 + 2 * j + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+    if (bad) atomicOr(&err[blob_i], ERR_NONCANONICAL_FR);
+    // the blob's sums: fold, add over the wave, fold, add over the waves
+    quot_fold(Su); quot_fold(Sp);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const Fr a = fr_shfl_down(Su, off), b = fr_shfl_down(Sp, off);
+        fr_add_lazy(Su, Su, a); fr_add_lazy(Sp, Sp, b);
+    }
+    quot_fold(Su); quot_fold(Sp);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NFR; k++) { red[wid][0][k] = Su.l[k]; red[wid][1][k] = Sp.l[k]; }
+    }
+    __syncthreads();
+    Su = fr_zero(); Sp = fr_zero();
+#pragma unroll 1
+    for (int w = 0; w < NW; w++) {
+        Fr a, b;
+#pragma unroll
+        for (int k = 0; k < NFR; k++) { a.l[k] = red[w][0][k]; b.l[k] = red[w][1][k]; }
+        fr_add_lazy(Su, Su, a); fr_add_lazy(Sp, Sp, b);
+    }
+    Fr y;
+    quot_y(y, Su, Sp, pp);
+    if (tid == 0) {                                               // Montgomery form for the callers that hand y out (compute_kzg_proof, kzg.rs:455)
+        const uint32_t r2[NFR] = FR_R2_INIT;
+        Fr R2; for (int i = 0; i < NFR; i++) R2.l[i] = r2[i];
+        Fr ym; fr_mul(ym, y, R2);
+        y_out[blob_i] = ym;
+    }
+#pragma unroll 1
+    for (int g = 0; g < GROUPS; g++) {
+        const int a10 = (tid << L) + g;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 a = blob[8 * a10 + 2 * j], b = blob[8 * a10 + 2 * j + 1];
+            const uint4 ia = q[8 * a10 + 2 * j], ib = q[8 * a10 + 2 * j + 1];
+            uint32_t pw[8], iw[8], qw[8];
+            pw[7] = bswap32(a.x); pw[6] = bswap32(a.y); pw[5] = bswap32(a.z); pw[4] = bswap32(a.w);
+            pw[3] = bswap32(b.x); pw[2] = bswap32(b.y); pw[1] = bswap32(b.z); pw[0] = bswap32(b.w);
+            iw[0] = ia.x; iw[1] = ia.y; iw[2] = ia.z; iw[3] = ia.w; iw[4] = ib.x; iw[5] = ib.y; iw[6] = ib.z; iw[7] = ib.w;
+            quot_leaf_pass2(qw, pw, iw, y);
+            q[8 * a10 + 2 * j] = make_uint4(bswap32(qw[7]), bswap32(qw[6]), bswap32(qw[5]), bswap32(qw[4]));
+            q[8 * a10 + 2 * j + 1] = make_uint4(bswap32(qw[3]), bswap32(qw[2]), bswap32(qw[1]), bswap32(qw[0]));
         }
     }
 }
@@ -174,9 +305,22 @@ void launch_status_words(const int *d_err, const int *d_ok, int32_t *d_words, in
     hipLaunchKernelGGL(k_status_words, dim3((groups + 255) / 256), dim3(256), 0, st, d_err, d_ok, d_words, groups);
 }
 
-void launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, Fr *d_q, int *d_err, hipStream_t st) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_quotient, dim3(n), dim3(1024), 0, st, d_blobs, d_z, t.roots, d_y, d_q, d_err);
+size_t quotient_scratch_bytes(int n) { return sizeof(QuotPrep) * (size_t)n + sizeof(int) * ((size_t)n + 4); }
+// d_q: n x 131,072 bytes -- the quotient of every blob in the BLOB format (4096 canonical 32-byte big-endian integers), 16-byte aligned;
+// d_scratch: quotient_scratch_bytes(n).  form: 0 by size, 2 / 4 / 6 = 2^form leaves per lane
+int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q, void *d_scratch, int *d_err, hipStream_t st, int form) {
+    if (n <= 0) return 0;
+    QuotPrep *prep = reinterpret_cast<QuotPrep *>(d_scratch);
+    int *count = reinterpret_cast<int *>(prep + n), *list = count + 4;
+    if (hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_quotient_prep, dim3((n + 63) / 64), dim3(64), 0, st, d_z, n, prep, list, count);
+    // few blobs: 1024 lanes per blob (a lone proof is a chain: 10 + 6 + 8 products deep instead of 8 + 30 + 32); many: 256 (fewer repeated path levels)
+    if (form == 0) form = n < 512 ? 2 : 4;
+    if (form == 2) hipLaunchKernelGGL(k_quotient_tree<2>, dim3(n), dim3(1024), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
+    else if (form == 6) hipLaunchKernelGGL(k_quotient_tree<6>, dim3(n), dim3(64), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
+    else hipLaunchKernelGGL(k_quotient_tree<4>, dim3(n), dim3(256), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
+    hipLaunchKernelGGL(k_quotient_scan, dim3(n < 32 ? n : 32), dim3(1024), 0, st, d_blobs, d_z, t.roots, d_y, d_q, d_err, list, count);
+    return 0;
 }
 void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err, hipStream_t st) {
     if (n <= 0) return;

@@ -244,7 +244,6 @@ __global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *dig
 // the tile (still the same 1 KiB per instruction), and lane g reads its part j back from slot 8 g + (j ^ (g & 7)).
 // The exchange buffer holds 256 values of 9 limbs, entry e at words 9 e .. 9 e + 8: a lane's writes are 9 words apart (odd:
 // conflict-free), its four children are 36 consecutive words read as nine b128 (lanes 36 words apart: 16 lanes cover all banks).
-constexpr uint32_t FR_MOD_TOP_WORD = 0x73eda753u;    // r = 0x73eda753 299d7d48 ...
 __device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, uint4 *tile, int lane) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {

@@ -153,7 +153,11 @@ void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_
 
 // ---- k_prove.hip
 // quotient polynomial q(X) = (p(X) - y)/(X - z) in evaluation form (kzg.rs:461-523) for n blobs; also y.
-void launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, Fr *d_q /* [n][4096] */, int *d_err, hipStream_t st);
+// d_q: the quotient of every blob in the BLOB format (n x 131,072 bytes: 4096 canonical 32-byte big-endian integers; 16-byte aligned) -- the fixed-base MSM
+// reads it like a blob; d_scratch: quotient_scratch_bytes(n) of device memory; form: 0 by size, 2 / 4 / 6 = 2^form leaves per lane.  Non-zero: a HIP call failed.
+size_t quotient_scratch_bytes(int n);
+int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q /* [n][131072] */, void *d_scratch, int *d_err, hipStream_t st,
+                    int form = 0);
 void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err /* per element, ERR_NONCANONICAL_FR */, hipStream_t st);
 void launch_fr_to_bytes(const Fr *d_in, int n, uint8_t *d_out32, hipStream_t st);
 void launch_status_words(const int *d_err, const int *d_ok /* or null */, int32_t *d_words, int groups, hipStream_t st);

@@ -254,7 +254,9 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
     """The N > 1 path over an engine that leaves its per-batch results on the device (HipEngine): statuses and verdicts travel as int32 words in
     device memory -- through the all-gather's buffer or the all-reduce -- and are read back ONCE, at the end; a failure of a whole engine call is
     a status on every batch of that rank, seen by all ranks after the merge (nobody raises in the middle of a collective sequence).
-    Raises RuntimeError on every rank together when a merged status is a device-level failure (KZG355_NO_DEVICE and above)."""
+    Raises RuntimeError on every rank together when a merged status is a device-level failure (KZG355_NO_DEVICE and above): the all-to-all form
+    merges all words in its all-reduce; the all-gather form carries the stage-1 words in the gathered buffer and all-reduces ONE word for stage 2
+    (replicated there: only a failure needs telling)."""
     import time
     import numpy as np
     import torch
@@ -290,7 +292,21 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
         t0 = _tick(timings, "exchange_ms", t0)
         engine.verify_records_words(recs, points, n_local * world, groups, code[groups:])      # every rank: all the batches
         t0 = _tick(timings, "stage2_ms", t0)
-        merged = torch.cat([st1, code[groups:]]).cpu().numpy().astype(np.int64)                # the one read-back
+        # Stage 2 is replicated, so its verdicts need no merge -- but a whole-call failure of ONE rank's stage 2 (out of memory: every rank runs
+        # world x the stage-2 work) would be that rank's alone, and it would raise while the others walk into the next collective.
+        # One 4-byte word travels: the largest device-level status (>= 6) any rank's stage 2 left; every rank then raises, or none does.
+        w2 = code[groups:] >> 8
+        fail = torch.where(w2 >= 6, w2, torch.zeros_like(w2)).max().reshape(1)
+        if on_host:
+            fail_h = fail.cpu()
+            dist.all_reduce(fail_h, op=dist.ReduceOp.MAX, group=group)
+            fail = fail_h.to(dev)
+        else:
+            dist.all_reduce(fail, op=dist.ReduceOp.MAX, group=group)
+        merged = torch.cat([st1, code[groups:], fail]).cpu().numpy().astype(np.int64)          # the one read-back
+        if merged[-1] >= 6:
+            raise RuntimeError(f"sharded verification: engine failure in stage 2 on a rank (status {int(merged[-1])}); every rank raises")
+        merged = merged[:-1]
     else:
         shares = [((groups * r) // world, (groups * (r + 1)) // world) for r in range(world)]
         g_lo, g_hi = shares[rank]

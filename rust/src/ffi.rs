@@ -51,6 +51,7 @@ pub struct kzg355_options {
     pub msm_eager: c_int,
     pub pairing_hard12_from: c_int,
     pub submit_sets: c_int,
+    pub host_hash_device_max_blobs: c_int,
 }
 
 extern "C" {

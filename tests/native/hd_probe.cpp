@@ -10,6 +10,7 @@
 #include "../../kzg_rust_amd/csrc/pairing_coop.h"
 #include "../../kzg_rust_amd/csrc/pairing_lanes.h"
 #include "../../kzg_rust_amd/csrc/eval_core.h"
+#include "../../kzg_rust_amd/csrc/quot_core.h"
 #include <vector>
 #include <cstring>
 using namespace kzg;
@@ -91,6 +92,70 @@ int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
     Fr y; eval_level6(y, h5, zp[5], imag);
     limbs_to_words<NFR, 8>(w, y.l);
     for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8; out32[4 * i + 3] = v; }
+    return 0;
+}
+// y and the quotient q_i = (p_i - y) / (w_i - z) through quot_core.h, the way k_quotient_tree<lg> deals the tree to its lanes: 4096 >> lg "lanes", each
+// with the path from the root to its node, the subtree below it in groups of four leaves, pass 1 / the sums (folded per lane, per wave of 64 lanes,
+// per blob) / pass 2 with the inverses parked as 8 words in between.  out_q: 4096 x 32 big-endian bytes; out_y: 32.  2: z inside the domain
+// (the device hands those blobs to k_quotient_scan).
+int hd_quotient(uint8_t *out_q, uint8_t *out_y, const uint8_t *blob, const uint8_t *z_be, int lg) {
+    constexpr int N_FE = 4096;
+    if (lg != 2 && lg != 4 && lg != 6) return 3;
+    static Fr roots[N_FE]; static bool ready = false;
+    if (!ready) {
+        const uint32_t rootc[NFR] = FR_ROOT4096_INIT;
+        Fr base; for (int k = 0; k < NFR; k++) base.l[k] = rootc[k];
+        Fr acc = fr_one();
+        for (int i = 0; i < N_FE; i++) {
+            uint32_t rev = 0; for (int b = 0; b < 12; b++) rev |= ((i >> b) & 1u) << (11 - b);
+            roots[rev] = acc; fr_mul(acc, acc, base);
+        }
+        ready = true;
+    }
+    uint32_t w[8]; be32_to_words(w, z_be);
+    Fr z; fr_from_words(z, w);
+    QuotPrep pp;
+    if (quot_prep(pp, z)) return 2;
+    const int lanes = N_FE >> lg, L = lg - 2, D0 = 12 - lg, groups = 1 << L;
+    std::vector<uint32_t> stash(8 * N_FE);
+    std::vector<Fr> su(lanes), sp(lanes);
+    for (int t = 0; t < lanes; t++) {
+        Fr inv0; quot_path(inv0, pp, roots, D0, t);
+        Fr Su = fr_zero(), Sp = fr_zero();
+        Fr c[5][2];
+        for (int g = 0; g < groups; g++) {
+            for (int l = 0; l < L; l++)
+                if ((g & ((1 << (L - l)) - 1)) == 0) {
+                    const Fr src = l == 0 ? inv0 : c[l - 1][(g >> (L - l)) & 1];
+                    const int a = (t << l) + (g >> (L - l));
+                    quot_children(c[l][0], c[l][1], src, pp.zsq[11 - (D0 + l)], roots[2 * a]);
+                }
+            const Fr inv10 = L == 0 ? inv0 : c[L - 1][g & 1];
+            const int a10 = (t << L) + g;
+            uint32_t pw[4][8];
+            for (int j = 0; j < 4; j++) { be32_to_words(pw[j], blob + 32 * (4 * a10 + j)); if (!fr_words_canonical(pw[j])) return 1; }
+            Fr inv12[4];
+            quot_group_pass1(inv12, Su, Sp, pw, inv10, a10, pp, roots);
+            for (int j = 0; j < 4; j++) limbs_to_words<NFR, 8>(&stash[8 * (4 * a10 + j)], inv12[j].l);
+        }
+        quot_fold(Su); quot_fold(Sp);
+        su[t] = Su; sp[t] = Sp;
+    }
+    Fr Su = fr_zero(), Sp = fr_zero();
+    for (int w0 = 0; w0 < lanes; w0 += 64) {                       // a wave's 64 lanes, then the fold, then the waves
+        Fr a = fr_zero(), b = fr_zero();
+        for (int t = w0; t < w0 + 64 && t < lanes; t++) { fr_add_lazy(a, a, su[t]); fr_add_lazy(b, b, sp[t]); }
+        quot_fold(a); quot_fold(b);
+        fr_add_lazy(Su, Su, a); fr_add_lazy(Sp, Sp, b);
+    }
+    Fr y; quot_y(y, Su, Sp, pp);
+    limbs_to_words<NFR, 8>(w, y.l); words_to_be32(out_y, w);
+    for (int e = 0; e < N_FE; e++) {
+        uint32_t pw[8], qw[8];
+        be32_to_words(pw, blob + 32 * e);
+        quot_leaf_pass2(qw, pw, &stash[8 * e], y);
+        words_to_be32(out_q + 32 * e, qw);
+    }
     return 0;
 }
 // 0 ok / 1 bad encoding / 2 not on curve / 3 not in subgroup ; out = recompressed point

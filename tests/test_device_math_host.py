@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h", "quot_core.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
@@ -241,6 +241,39 @@ def test_eval_group_of_four_matches_oracle(hd, oracle, oracle_settings, golden_b
             assert out.raw == y, z.hex()
     bad = bytearray(blobs[0]); bad[32 * 77:32 * 78] = (R_).to_bytes(32, "big")
     assert hd.hd_eval_poly(out, bytes(bad), zs[0]) == 1
+
+
+def test_quotient_tree_matches_the_definition_and_the_oracle(hd, oracle, oracle_settings, golden_blobs):
+    """quot_core.h (what k_quotient_tree runs per lane; reference src/kzg.rs:461-490): y against the oracle's compute_kzg_proof, and every q_i against
+    its definition q_i (w_i - z) = p_i - y in Python integers, for the three lane shapes of the kernel, on random / extreme blobs and z = random, 0, 1,
+    r - 2, 2, 5 (r - 1 = w^(N/2) is IN the domain); z inside the domain is reported (the device gives those blobs to the scan kernel)."""
+    from synth import random_blob, random_field_element
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    w = pow(7, (R_ - 1) // 4096, R_)
+    brp = lambda i: int(format(i, "012b")[::-1], 2)
+    dom = [pow(w, brp(i), R_) for i in range(4096)]
+    top = (R_ - 1).to_bytes(32, "big")
+    ones = (((R_ >> 232) << 232) - 1).to_bytes(32, "big")          # every 29-bit limb below the top one at its maximum
+    blobs = [random_blob(4343), bytes(131072), top * 4096, (top + bytes(32)) * 2048, ones * 4096, (bytes(64) + ones + top) * 1024]
+    zs = [random_field_element(300), random_field_element(301)] + [v.to_bytes(32, "big") for v in (0, 1 + 1, R_ - 2, 5)]
+    out_q, out_y = C.create_string_buffer(131072), C.create_string_buffer(32)
+    for bi, blob in enumerate(blobs):
+        p = [int.from_bytes(blob[32 * i:32 * i + 32], "big") for i in range(4096)]
+        for zi, zb in enumerate(zs):
+            lgs = (2, 4, 6) if (bi < 2 and zi < 2) else (4,)
+            for lg in lgs:
+                assert hd.hd_quotient(out_q, out_y, blob, zb, lg) == 0, (bi, zi, lg)
+                _, y = oracle.compute_kzg_proof(blob, zb, oracle_settings)
+                assert out_y.raw == y, (bi, zi, lg)
+                yv, zv = int.from_bytes(y, "big"), int.from_bytes(zb, "big")
+                q = out_q.raw
+                for i in range(4096):
+                    qi = int.from_bytes(q[32 * i:32 * i + 32], "big")
+                    assert qi < R_ and (qi * (dom[i] - zv) - (p[i] - yv)) % R_ == 0, (bi, zi, lg, i)
+    for pos in (0, 1, 2049, 4095):
+        assert hd.hd_quotient(out_q, out_y, blobs[0], dom[pos].to_bytes(32, "big"), 4) == 2
+    bad = bytearray(blobs[0]); bad[32 * 77:32 * 78] = (R_).to_bytes(32, "big")
+    assert hd.hd_quotient(out_q, out_y, bytes(bad), zs[0], 4) == 1
 
 
 def test_g1_xyzz_accumulator(hd, oracle, setup_bytes):

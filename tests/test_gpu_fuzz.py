@@ -1,0 +1,83 @@
+"""-m gpu: the differential fuzzers of tools/ (fuzz_verify.py, fuzz_msm.py) with a fixed seed and a reduced count, so that the driver's own
+`pytest -m gpu` run repeats them (the 30,000-batch / 12,000-blob runs of round 4 exist only as builder-written text under
+profiles/r04/).  Pass rule as the reference's vector loops (src/lib.rs:189-201): Ok(true) / Ok(false) / Err of every batch equals the
+oracle's, commitments and proofs are byte-exact.
+
+  * 400 mutated batches of 1..12 blobs x 3 routes (one host-buffer call per batch, *_many on host buffers, device-resident submit / collect),
+    once per dispatch form: the defaults (few batches: pre-shifted / windowed lincomb, two-wave segmented pairing), then the forms only LARGE
+    launch sets take by themselves, forced through the KZG355_* test overrides -- the bucket lincomb ending in one Horner chain per class,
+    the final exponentiation's hard part twelve lanes per check, three Miller segments per pair;
+  * 300 blobs of five kinds (uniform, bench recipe, sparse, GLV halves with extreme digits, all-equal) x the five MSM table forms."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+N_BATCHES = 400
+N_BLOBS = 300
+
+FORMS = {
+    "defaults": {},
+    "bucket lincomb with one chain per class + hard part twelve lanes per check": {"KZG355_LINCOMB": "bucket", "KZG355_LC_CHAIN_FROM": "1", "KZG355_PAIRING_HARD12_FROM": "1",
+                                                                                    "KZG355_RHASH_LANES_FROM": "1"},
+    "three Miller segments per pair + windowed lincomb + device hashes": {"KZG355_MILLER_SEGMENTS": "3", "KZG355_LINCOMB": "window", "KZG355_HOST_HASH": "off", "KZG355_HOST_RHASH": "off"},
+}
+
+
+@pytest.fixture(scope="module")
+def verify_cases():
+    import kzg_rust_amd as kz
+    import fuzz_verify as fv
+    s = fv.load_product(kz)
+    blobs, cs, ps = fv.honest_pool(kz, s)
+    s.free()
+    cases = fv.make_cases(N_BATCHES, blobs, cs, ps, seed=0x4844_0005)
+    want = fv.oracle_verdicts(cases)
+    # the mutations must exercise all three outcomes, or the run proves nothing
+    assert want.count(True) > 40 and want.count(False) > 100 and want.count(None) > 60, (want.count(True), want.count(False), want.count(None))
+    return cases, want
+
+
+@pytest.mark.parametrize("form", list(FORMS))
+def test_verify_fuzz_three_routes(verify_cases, form):
+    import kzg_rust_amd as kz
+    import fuzz_verify as fv
+    cases, want = verify_cases
+    env = FORMS[form]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = fv.load_product(kz)             # (kzg355_load_trusted_setup reads the KZG355_* test overrides)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        bad = fv.run_routes(kz, s, cases, want)
+    finally:
+        s.free()
+    assert bad == (0, 0, 0), f"{form}: mismatches per route (single calls, *_many, submit / collect) {bad} of {len(cases)} batches"
+
+
+@pytest.fixture(scope="module")
+def msm_cases():
+    import fuzz_msm as fm
+    blobs = fm.make_blobs(N_BLOBS, seed=0x4845)
+    want_c, want_p = fm.oracle_outputs(blobs)
+    return blobs, want_c, want_p
+
+
+@pytest.mark.parametrize("form", [12, 13, 15, 16, "glv-off-12"])
+def test_msm_fuzz_every_table_form(msm_cases, form):
+    import kzg_rust_amd as kz
+    import fuzz_msm as fm
+    blobs, want_c, want_p = msm_cases
+    bad_c, bad_p, shape = fm.run_form(kz, form, blobs, want_c, want_p)
+    assert shape[0] == int(str(form).split("-")[-1]) and shape[2] == (0 if str(form).startswith("glv-off") else 1), shape
+    assert (bad_c, bad_p) == (0, 0), f"table form {form} {shape}: {bad_c} commitments and {bad_p} proofs of {len(blobs)} differ from the oracle"

@@ -268,3 +268,123 @@ def test_explicit_options_ignore_the_environment(kz, setup_bytes, batch, monkeyp
         assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, [Pr[1]] + Pr[1:], s) is False
     finally:
         s.free()
+
+
+def _device_records(kz, s, blobs, cs, ps, npg, groups):
+    """stage 1 of a DEVICE-RESIDENT call (kzg355_verify_shard_records_device on torch tensors): the 160-byte records, read back"""
+    import torch
+    L = kz.kzg.lib()
+    dev = torch.device("cuda", s.device)
+    n = npg * groups
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(ps[:n])), dtype=torch.uint8).to(dev)
+    rec = torch.empty(160 * n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = (C.c_int * groups)()
+    rc = L.kzg355_verify_shard_records_device(rec.data_ptr(), st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), npg, groups, s.handle)
+    return rc, list(st), bytes(rec.cpu().numpy()), (tb, tc, tp)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_device_resident_small_calls_take_the_host_route(mode, kz, settings, batch, oracle, oracle_settings):
+    """a small call whose blobs are ALREADY in HBM copies them back in chunks and hashes on the host threads (5.3 -> ~2 ms for one
+    64-blob batch) instead of the 3.7 ms device chain.  z_i and y_i of the records byte for byte against the oracle on that route and with it off
+    (set_host_hash(-1)); verdicts / Errs of kzg355_verify_blob_kzg_proof_batch_many_device and blob proofs of the *_device call the same both ways."""
+    import torch
+    blobs, cs, ps = batch
+    L = kz.kzg.lib()
+    inter = oracle.verify_batch_intermediates(blobs, cs, ps, oracle_settings)
+    settings.set_host_hash(0 if mode == "host" else -1)
+    try:
+        for npg, groups in ((64, 1), (67, 1), (1, 1), (16, 4), (3, 5), (2, 1)):
+            before = settings.host_hashed_calls
+            rc, st, rec, _ = _device_records(kz, settings, blobs, cs, ps, npg, groups)
+            assert rc == 0 and st == [0] * groups, (npg, groups, rc, st)
+            assert (settings.host_hashed_calls - before == 1) == (mode == "host"), (mode, npg, groups)
+            for i in range(npg * groups):
+                r = rec[160 * i:160 * i + 160]
+                assert r[:48] == cs[i] and r[112:] == ps[i]
+                assert r[48:80] == inter["z"][i], f"z[{i}] ({mode}, device-resident, {npg} x {groups})"
+                assert r[80:112] == inter["y"][i], f"y[{i}] ({mode}, device-resident, {npg} x {groups})"
+        # whole calls on device-resident inputs: honest, swapped proofs, an invalid point, a non-canonical element
+        dev = torch.device("cuda", settings.device)
+        n, G = 16, 4
+        P = list(ps[:n * G]); P[16], P[17] = P[17], P[16]                      # batch 1: false
+        Cm = list(cs[:n * G]); Cm[2 * 16 + 5] = bytes([0x9a]) + b"\xff" * 47    # batch 2: Err
+        Bl = list(blobs[:n * G]); nc = bytearray(Bl[3 * 16 + 1]); nc[32 * 9:32 * 10] = b"\xff" * 32; Bl[3 * 16 + 1] = bytes(nc)   # batch 3: Err
+        tb = torch.frombuffer(bytearray(b"".join(Bl)), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(b"".join(Cm)), dtype=torch.uint8).to(dev)
+        tp = torch.frombuffer(bytearray(b"".join(P)), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        ok = (C.c_bool * G)(); st = (C.c_int * G)()
+        before = settings.host_hashed_calls
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, settings.handle)
+        assert rc == 1 and list(st) == [0, 0, 1, 1] and bool(ok[0]) is True and bool(ok[1]) is False, (rc, list(st), list(ok))
+        assert (settings.host_hashed_calls - before == 1) == (mode == "host")
+        # blob proofs of device-resident blobs (the challenge hashes the blob: same route)
+        out = C.create_string_buffer(48 * 5); st5 = (C.c_int * 5)()
+        tb5 = torch.frombuffer(bytearray(b"".join(blobs[:5])), dtype=torch.uint8).to(dev)
+        tc5 = torch.frombuffer(bytearray(b"".join(cs[:5])), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        before = settings.host_hashed_calls
+        rc = L.kzg355_compute_blob_kzg_proof_many_device(out, st5, tb5.data_ptr(), tc5.data_ptr(), 5, settings.handle)
+        assert rc == 0 and out.raw == b"".join(ps[:5])
+        assert (settings.host_hashed_calls - before == 1) == (mode == "host")
+    finally:
+        settings.set_host_hash(0)
+
+
+def test_device_resident_host_route_crossover(kz, setup_bytes, batch):
+    """the route is taken up to host_hash_device_max_blobs only (default 512; here 8), and never while submitted sets are in flight"""
+    import torch
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], host_hash_device_max_blobs=8)
+    try:
+        rc, st, rec8, _ = _device_records(kz, s, blobs, cs, ps, 8, 1)
+        assert rc == 0 and s.host_hashed_calls == 1
+        rc, st, rec9, _ = _device_records(kz, s, blobs, cs, ps, 9, 1)
+        assert rc == 0 and s.host_hashed_calls == 1                            # above the crossover: device hash
+        assert rec8 == rec9[:160 * 8]
+        # with a submitted set out, a synchronous small device-resident call keeps the device hash
+        L = kz.kzg.lib()
+        dev = torch.device("cuda", s.device)
+        tb = torch.frombuffer(bytearray(b"".join(blobs[:8])), dtype=torch.uint8).to(dev)
+        tc = torch.frombuffer(bytearray(b"".join(cs[:8])), dtype=torch.uint8).to(dev)
+        tp = torch.frombuffer(bytearray(b"".join(ps[:8])), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        tk = C.c_void_p()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), 8, 1, s.handle) == 0
+        ok = (C.c_bool * 1)(); st1 = (C.c_int * 1)()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st1, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), 8, 1, s.handle) == 0 and ok[0]
+        assert s.host_hashed_calls == 1
+        ok2 = (C.c_bool * 1)(); st2 = (C.c_int * 1)()
+        assert L.kzg355_verify_collect(tk, ok2, st2) == 0 and ok2[0]
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st1, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), 8, 1, s.handle) == 0 and ok[0]
+        assert s.host_hashed_calls == 2
+    finally:
+        s.free()
+
+
+def test_handle_freed_with_a_ticket_out_is_released_by_the_last_collect(kz, setup_bytes, batch):
+    """kzg355_free_trusted_setup with a submitted set not collected used to free what the ticket points into.  The free is deferred
+    to the collect of the last ticket; the collect still returns the set's verdicts."""
+    import torch
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    s = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
+    L = kz.kzg.lib()
+    dev = torch.device("cuda", s.device)
+    n, G = 8, 3
+    P = list(ps[:n * G]); P[8], P[9] = P[9], P[8]
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n * G])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n * G])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(P)), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    tk = C.c_void_p()
+    assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, G, s.handle) == 0
+    s.free()                                                               # the caller's bug: a ticket is still out
+    ok = (C.c_bool * G)(); st = (C.c_int * G)()
+    assert L.kzg355_verify_collect(tk, ok, st) == 0
+    assert [bool(x) for x in ok] == [True, False, True] and list(st) == [0, 0, 0]

@@ -48,7 +48,25 @@ def _worker(rank, world, port, blobs, cs, ps, q):
         ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange)
         ok1, st1 = verify_blob_kzg_proof_batch_sharded(tb[:n_local * 131072], tc[:n_local * 48], tp[:n_local * 48], n_local, 1, eng, exchange=exchange)    # one batch: rank 0's share is empty
         res.append((exchange, ok, st, ok1, st1))
-    q.put((rank, res))
+
+    # a whole-call failure of stage 2 on ONE rank (here: rank 1 reports NO_MEMORY for every batch it was given) must raise on EVERY rank in both
+    # exchanges -- in the all-gather form stage 2 is replicated and nothing else would tell rank 0
+    class FailingStage2(HipEngine):
+        def verify_records_words(self, records, points, n, groups, words):
+            if rank == 1:
+                words.fill_(1 + 256 * 7)
+            else:
+                super().verify_records_words(records, points, n, groups, words)
+    raised = []
+    for exchange in ("alltoall", "allgather"):
+        try:
+            verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, FailingStage2(s), exchange=exchange)
+            raised.append(False)
+        except RuntimeError:
+            raised.append(True)
+    # ... and the ranks are still in step afterwards: an honest call goes through
+    ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange="allgather")
+    q.put((rank, res, raised, ok, st))
     s.free()
     dist.destroy_process_group()
 
@@ -84,7 +102,9 @@ def test_sharded_driver_two_ranks_on_the_hip_engine():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, per_exchange in res:
+    for rank, per_exchange, raised, ok_after, st_after in res:
+        assert raised == [True, True], (rank, raised)
+        assert ok_after == [True, False, False] and st_after[:2] == [0, 0], (rank, ok_after, st_after)
         for exchange, ok, st, ok1, st1 in per_exchange:
             assert ok == [True, False, False], (rank, exchange, ok)
             assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, exchange, st)
