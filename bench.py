@@ -186,8 +186,11 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="launch sets in flight (device-resident verify, 1 GPU): >1 submits every step with kzg355_verify_blob_kzg_proof_batch_many_device_submit and "
                          "collects the oldest once this many are queued -- mid-size sets (--batches-per-step 1024) kept in flight from one thread")
-    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "alltoall"),
-                    help="N > 1: alltoall = stage 2 split by batch (default); allgather = BASELINE north_star's single all-gather with stage 2 replicated")
+    ap.add_argument("--exchange", choices=["both", "alltoall", "allgather"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "both"),
+                    help="N > 1: both (default) = K timed steps of each form back to back, `value` = the better one (config.value_exchange names it); "
+                         "alltoall = stage 2 split by batch; allgather = BASELINE north_star's single all-gather with stage 2 replicated")
+    ap.add_argument("--no-parity-gate", action="store_true", help="N > 1: skip the byte-exact check of the sharded path on the real ranks before the timed steps")
+    ap.add_argument("--no-in-library-leg", action="store_true", help="N > 1: skip the timing of the library's own multi-device handle (kzg355_load_trusted_setup_devices) on rank 0")
     ap.add_argument("--sweep", action="store_true",
                     help="criterion sweep: verify_blob_kzg_proof_batch for n in {1,..,64} and the five single-op benches, single calls on host inputs")
     args = ap.parse_args()
@@ -209,6 +212,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     import torch
     import torch.distributed as dist
+    if world > 1 and not os.environ.get("KZG355_BENCH_ONE_GPU") and torch.cuda.device_count() < world:
+        # fail fast, with one clear line, before any rank enters a rendezvous it cannot finish (device_count does not initialise the GPU)
+        sys.stderr.write(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible to rank {rank}\n")
+        raise SystemExit(3)
     # Rehearsal hooks for a one-GPU box (never set by the driver): KZG355_BENCH_BACKEND=gloo and KZG355_BENCH_ONE_GPU=1 run the N-rank
     # code path (sharding, the all-to-all, the status merge, max-over-ranks timing) with every rank on device 0; the line says so.
     backend = os.environ.get("KZG355_BENCH_BACKEND", "nccl")
@@ -220,10 +227,20 @@ def main():
     os.environ.setdefault("KZG355_DEVICE", str(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)                              # the communicator is created here: an RCCL that cannot initialise fails NOW, not in the timed steps
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            else:
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench.py: rank {rank}: torch.distributed / RCCL initialisation failed over {world} ranks: {e!r}\n")
+            raise SystemExit(4)
+        parking = dist.new_group(backend="gloo") if backend == "nccl" else None      # host-side barriers (the in-library leg parks the other ranks off their GPUs)
     if args.op != "verify":
         # commit / proof are bound by the fixed-base MSM: 16-bit windows over the GLV halves of the scalars (8 windows per half = 16 table rows per
         # scalar, 143.5 GB table) -- a handle left to itself sizes the table from half of the free HBM (15-bit: 18 rows, 68.9 GB, on an empty
@@ -297,6 +314,7 @@ def main():
     out48 = C.create_string_buffer(48 * n_blobs)
 
     exchange_acc = {}                              # stage / exchange wall times of the sharded path, accumulated over the timed steps (this rank)
+    mode_now = ["alltoall" if args.exchange == "both" else args.exchange]      # the exchange the sharded steps take right now
 
     def run_steps(g):
         """one launch set over g independent 64-blob batches; returns when the results are on the host."""
@@ -317,7 +335,7 @@ def main():
             assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         else:
             # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
-            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, exchange=args.exchange, timings=exchange_acc)
+            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, exchange=mode_now[0], timings=exchange_acc)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
     def barrier():
@@ -361,59 +379,75 @@ def main():
         else:
             run_steps(Cc)                              # synchronous: returns when this step's verdicts are on the host
 
-    for _ in range(W):
-        one_step()
-    while pending:
-        collect_oldest()
-    L.kzg355_reset_kernel_stats(s.handle)
-    exchange_acc.clear()
-    s.set_kernel_timing(not args.no_kernel_timing)     # HIP events around every kernel, on its launch stream; the schedule is unchanged
-    step_ms = []
-    sampler = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
-    barrier()
-    if sampler: sampler.start()
-    t0 = time.perf_counter()
-    tp = t0
-    for _ in range(K):
-        one_step()
-        tn = time.perf_counter(); step_ms.append((tn - tp) * 1e3); tp = tn
-    while pending:                                     # (pipelined: the sets still in flight belong to the K timed steps)
-        collect_oldest()
-    barrier()
-    dt = time.perf_counter() - t0
-    power = sampler.stop() if sampler else None
-    s.set_kernel_timing(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    parity = None
+    if world > 1 and args.op == "verify" and not args.no_parity_gate:
+        # the only place real-xGMI parity can ever be checked: the sharded path on the real ranks against the committed fixture / the single-device run
+        parity = parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, backend)
 
-    # N > 1 (or --sharded-path): where a step's time goes on every rank -- stage 1, the exchange (collective + permute), stage 2, the
-    # verdict merge -- so that a sub-linear scaling curve can be attributed
-    exchange_stats = None
-    if exchange_acc:
-        mine = {k: round(v / K, 3) for k, v in exchange_acc.items()}
-        per_rank = [mine]
+    def timed_region(mode):
+        """W untimed + exactly K timed steps of one exchange form between barriers; max over ranks.  Returns everything the line needs of it."""
+        mode_now[0] = mode
+        for _ in range(W):
+            one_step()
+        while pending:
+            collect_oldest()
+        L.kzg355_reset_kernel_stats(s.handle)
+        exchange_acc.clear()
+        s.set_kernel_timing(not args.no_kernel_timing)     # HIP events around every kernel, on its launch stream; the schedule is unchanged
+        step_ms = []
+        sampler = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
+        barrier()
+        if sampler: sampler.start()
+        t0 = time.perf_counter()
+        tp = t0
+        for _ in range(K):
+            one_step()
+            tn = time.perf_counter(); step_ms.append((tn - tp) * 1e3); tp = tn
+        while pending:                                     # (pipelined: the sets still in flight belong to the K timed steps)
+            collect_oldest()
+        barrier()
+        dt = time.perf_counter() - t0
+        power = sampler.stop() if sampler else None
+        s.set_kernel_timing(False)
         if world > 1:
-            per_rank = [None] * world
-            dist.all_gather_object(per_rank, mine)
-        exchange_stats = {"mode": args.exchange, "per_rank_ms_per_step": per_rank,
-                          "exchange_ms": max(r.get("exchange_ms", 0.0) for r in per_rank), "stage1_ms": max(r.get("stage1_ms", 0.0) for r in per_rank),
-                          "stage2_ms": max(r.get("stage2_ms", 0.0) for r in per_rank), "merge_ms": max(r.get("merge_ms", 0.0) for r in per_rank),
-                          "note": "wall ms per step, max over ranks; alltoall: records + decoded points of each rank's share of the batches, then an all-reduce of "
-                                  "the verdict words (merge_ms); allgather (BASELINE north_star): one all-gather, stage 2 replicated on every rank"}
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        # N > 1 (or --sharded-path): where a step's time goes on every rank -- stage 1, the exchange (collective + permute), stage 2, the
+        # verdict merge -- so that a sub-linear scaling curve can be attributed
+        exchange_stats = None
+        if exchange_acc:
+            mine = {k: round(v / K, 3) for k, v in exchange_acc.items()}
+            per_rank = [mine]
+            if world > 1:
+                per_rank = [None] * world
+                dist.all_gather_object(per_rank, mine)
+            exchange_stats = {"mode": mode, "per_rank_ms_per_step": per_rank,
+                              "exchange_ms": max(r.get("exchange_ms", 0.0) for r in per_rank), "stage1_ms": max(r.get("stage1_ms", 0.0) for r in per_rank),
+                              "stage2_ms": max(r.get("stage2_ms", 0.0) for r in per_rank), "merge_ms": max(r.get("merge_ms", 0.0) for r in per_rank),
+                              "note": "wall ms per step, max over ranks; alltoall: records + decoded points of each rank's share of the batches, then an all-reduce of "
+                                      "the verdict words (merge_ms); allgather (BASELINE north_star): one all-gather, stage 2 replicated on every rank"}
+        stats = {}
+        for fam in FAMILIES:
+            tot, cnt = C.c_double(), C.c_long()
+            L.kzg355_kernel_ms_stats(s.handle, fam.encode(), C.byref(tot), C.byref(cnt))
+            if cnt.value:
+                stats[fam] = (tot.value, cnt.value)
+        return {"mode": mode, "dt": dt, "step_ms": step_ms, "power": power, "exchange_stats": exchange_stats, "stats": stats,
+                "blobs_per_s": K * Cc * n_local * world / dt}
+
+    sharded = world > 1 or args.sharded_path
+    modes = ["allgather", "alltoall"] if (sharded and args.exchange == "both" and args.op == "verify") else [mode_now[0]]
+    runs = {m: timed_region(m) for m in modes}              # (the same K and W for each form, back to back)
+    best = max(runs.values(), key=lambda r: r["blobs_per_s"])
+    dt, step_ms, power, exchange_stats, stats = best["dt"], best["step_ms"], best["power"], best["exchange_stats"], best["stats"]
+    value_exchange = best["mode"] if sharded else None
 
     blobs_total = K * Cc * n_local * world
     value = blobs_total / dt
     blobs_events = blobs_total
 
     # ---- roofline of the dominant kernel (HIP events recorded on the launch stream during the timed region)
-    stats = {}
-    for fam in FAMILIES:
-        tot, cnt = C.c_double(), C.c_long()
-        L.kzg355_kernel_ms_stats(s.handle, fam.encode(), C.byref(tot), C.byref(cnt))
-        if cnt.value:
-            stats[fam] = (tot.value, cnt.value)
     roofline = None
     if stats:
         dom = max(stats, key=lambda f: stats[f][0])
@@ -464,6 +498,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
 
+    msm_form_at_end = s.msm_form
     msm_legs = None
     if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_msm_legs and not args.sharded_path:
         # BASELINE configs[1] and [2] in the same driver-timed run: the verify handle and its launch sets are released first (69 GB of blobs,
@@ -478,6 +513,23 @@ def main():
         msm_legs["verify_setup_msm_form"] = msm_form_verify_setup
         s = None
 
+    in_library = None
+    if world > 1 and args.op == "verify" and not args.no_in_library_leg:
+        # The multi-GPU path a Rust / C caller actually gets: ONE handle over all N devices inside rank 0's process.  The other ranks
+        # give their GPUs back first and wait on a HOST-side barrier (gloo) -- an RCCL barrier would keep a kernel spinning on every card.
+        t_blobs = t_c = t_p = None
+        engine = None
+        s.free(); s = None
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        park = (lambda: dist.barrier(group=parking)) if parking is not None else dist.barrier
+        park()
+        if rank == 0:
+            try:
+                in_library = in_library_leg(kz, L, g1, g2, world, random_blob, one_gpu=bool(os.environ.get("KZG355_BENCH_ONE_GPU")))
+            except Exception as e:  # noqa: BLE001  (the leg must never cost the run its line)
+                in_library = {"in_library_error": repr(e)[:300]}
+        park()
+
     if rank == 0:
         line = {
             "metric": OP_METRIC[args.op],
@@ -487,11 +539,11 @@ def main():
             "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
-                                      + ("all-to-all of the 160-B records + decoded points (stage 2 split by batch)" if args.exchange == "alltoall" else
+                                      + ("all-to-all of the 160-B records + decoded points (stage 2 split by batch)" if value_exchange == "alltoall" else
                                          "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)")),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
-                       "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else s.msm_form, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
+                       "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else msm_form_at_end, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
                        "host_inputs": host_inputs, "mid_size_sets": mid_size, "power": power},
@@ -507,12 +559,163 @@ def main():
             line["value_mid_size_sets_in_flight"] = mid_size["blobs_per_s"]              # 1024-batch sets, three in flight (config.mid_size_sets)
         if exchange_stats:
             line["config"]["exchange"] = exchange_stats
+        if sharded:
+            # both exchange forms of the same run as scalars; `value` is the better one and says which (BASELINE config 5 / north_star name the all-gather)
+            cfg = line["config"]
+            cfg["value_exchange"] = value_exchange
+            for m, r in runs.items():
+                cfg[f"{m}_blobs_per_s"] = round(r["blobs_per_s"], 1)
+                cfg[f"{m}_ms_per_step"] = round(r["dt"] * 1e3 / K, 3)
+                for k in ("stage1_ms", "exchange_ms", "stage2_ms", "merge_ms"):
+                    if r["exchange_stats"]:
+                        cfg[f"{k}_{m}"] = r["exchange_stats"][k]
+            if len(runs) == 2:
+                cfg["exchange_by_mode"] = {m: r["exchange_stats"] for m, r in runs.items()}
+        if parity:
+            line["config"].update(parity)
+        if in_library:
+            line["config"].update(in_library)
         flatten_scalars(line, host_inputs, mid_size, power, msm_legs)
         print(json.dumps(line), flush=True)
     if s is not None:
         s.free()
     if world > 1:
         dist.destroy_process_group()
+
+
+def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, backend):
+    """N > 1, before anything is timed: ONE batch of 64 x N blobs -- the first 64 N blobs of the committed 512-blob fixture (tests/golden/batch512.json:
+    tests/synth.random_blob(512000 + i), commitments and proofs from the CPU oracle) -- through the sharded path on the REAL ranks, both exchange forms:
+      * verdict true; with two proofs swapped on rank 0: false;
+      * the gathered records (C | z | y | proof of every blob, the body of the r-transcript in the order of utils.rs:454-463) byte for byte equal
+        to what rank 0 computes for all 64 N blobs on its own device, and r / proof_lincomb / rhs of the gathered batch (kzg.rs:601-622) equal to the
+        single-device run's -- and, at N = 8, to the fixture's own values (oracle-derived, committed).
+    Any mismatch raises on rank 0 after a verdict word has been shared, so that every rank leaves together."""
+    from kzg_rust_amd.sharded import verify_blob_kzg_proof_batch_sharded
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "batch512.json")))
+    n_local, n = N_PER_BATCH, N_PER_BATCH * world
+    if n > fx["n"]:
+        return {"parity_gate": f"skipped: {n} blobs exceed the committed {fx['n']}-blob fixture"}
+    first = fx["first_index"]
+    lo = rank * n_local
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    tb = to_dev(b"".join(random_blob(first + lo + i) for i in range(n_local)))
+    cs = [bytes.fromhex(c) for c in fx["commitments"][:n]]
+    ps = [bytes.fromhex(p) for p in fx["proofs"][:n]]
+    tc, tp = to_dev(b"".join(cs[lo:lo + n_local])), to_dev(b"".join(ps[lo:lo + n_local]))
+    sw = list(ps[lo:lo + n_local])
+    if rank == 0:
+        sw[1], sw[2] = sw[2], sw[1]
+    tsw = to_dev(b"".join(sw))
+    torch.cuda.synchronize()
+    problems = []
+    gathered = None
+    for mode in ("allgather", "alltoall"):
+        cap = {}
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, 1, engine, exchange=mode, capture=cap)
+        if ok != [True] or st != [0]:
+            problems.append(f"{mode}: honest batch gave {ok} / {st}")
+        if mode == "allgather":
+            gathered = cap.get("records")
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tsw, n_local, 1, engine, exchange=mode)
+        if ok != [False] or st != [0]:
+            problems.append(f"{mode}: swapped twin gave {ok} / {st}")
+    out = {}
+    if rank == 0:
+        if gathered is None or gathered.numel() != 160 * n:
+            problems.append("no gathered records captured")
+        else:
+            r_sh, pl_sh, rhs_sh, ok_sh, st_sh = engine.batch_intermediates(gathered, n, 1)[0]
+            # the same batch, whole, on this rank's device alone
+            all_b = to_dev(b"".join(random_blob(first + i) for i in range(n)))
+            all_c, all_p = to_dev(b"".join(cs)), to_dev(b"".join(ps))
+            rec = torch.empty(160 * n, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            st1 = (C.c_int * 1)()
+            rc = L.kzg355_verify_shard_records_device(rec.data_ptr(), st1, all_b.data_ptr(), all_c.data_ptr(), all_p.data_ptr(), n, 1, s.handle)
+            if rc != 0 or st1[0] != 0:
+                problems.append(f"single-device stage 1 failed: {rc} / {st1[0]}")
+            if bytes(rec.cpu().numpy()) != bytes(gathered.cpu().numpy()):
+                problems.append("gathered records differ from the single-device records (transcript order / exchange)")
+            r_1, pl_1, rhs_1, ok_1, st_1 = engine.batch_intermediates(rec, n, 1)[0]
+            if (r_sh, pl_sh, rhs_sh, ok_sh, st_sh) != (r_1, pl_1, rhs_1, True, 0):
+                problems.append("r / proof_lincomb / rhs of the sharded batch differ from the single-device run")
+            if n == fx["n"] and (r_sh.hex(), pl_sh.hex(), rhs_sh.hex()) != (fx["r"], fx["proof_lincomb"], fx["rhs"]):
+                problems.append("r / proof_lincomb / rhs differ from tests/golden/batch512.json")
+            out = {"parity_gate": "passed" if not problems else "FAILED: " + "; ".join(problems), "parity_gate_blobs": n,
+                   "parity_gate_r": r_sh.hex(), "parity_gate_against": ("tests/golden/batch512.json (oracle-derived r, proof_lincomb, rhs) and " if n == fx["n"] else "")
+                   + "the single-device run of the same batch on rank 0: records, r, proof_lincomb, rhs byte-exact; verdicts true / false in both exchange forms"}
+    flag = torch.tensor([1 if problems else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        if problems:
+            sys.stderr.write(f"bench.py: rank {rank}: parity gate FAILED: {'; '.join(problems)}\n")
+        raise SystemExit(5)
+    return out
+
+
+def in_library_leg(kz, L, g1, g2, world, random_blob, one_gpu=False, many_batches_per_device=128):
+    """kzg355_load_trusted_setup_devices over all N devices in ONE process (rank 0), timed through the drop-in C ABI on host slices:
+      (a) ONE verify_blob_kzg_proof_batch of 64 N blobs (BASELINE config 5 literally: per-device blocks of 64 blobs, stage 1 per block, the library's own
+          ncclAllGather of the 160-byte records over xGMI -- or its peer-copy fallback, the line says which -- stage 2 on one device);
+      (b) a *_many call of 128 N independent 64-blob batches fanned out over the devices (contiguous ranges, no exchange).
+    Inputs: the committed fixture's first 64 N blobs (a) and seeded blobs with commitments / proofs made by the same handle (b).  Host memory in, PCIe inside
+    the calls: these are drop-in figures, never `value`."""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "batch512.json")))
+    devices = [0] * world if one_gpu else list(range(world))
+    t0 = time.perf_counter()
+    s = kz.KzgSettings.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], devices=devices)
+    load_s = time.perf_counter() - t0
+    out = {"in_library_devices": s.device_count, "in_library_load_s": round(load_s, 2)}
+    try:
+        n = N_PER_BATCH * world
+        first = fx["first_index"]
+        blobs = b"".join(random_blob(first + i) for i in range(n))
+        cs = b"".join(bytes.fromhex(c) for c in fx["commitments"][:n]); ps = b"".join(bytes.fromhex(p) for p in fx["proofs"][:n])
+        ok = C.c_bool()
+        ts = []
+        kind0, ag0, peer0 = s.exchange_stats()
+        for i in range(12):
+            t0 = time.perf_counter()
+            rc = L.kzg355_verify_blob_kzg_proof_batch(C.byref(ok), blobs, n, cs, n, ps, n, s.handle)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert rc == 0 and ok.value, (rc, ok.value)
+        kind, ag, peer = s.exchange_stats()
+        ts = ts[2:]
+        out.update({"in_library_single_call_ms": round(statistics.median(ts), 3), "in_library_single_call_ms_min": round(min(ts), 3),
+                    "in_library_single_call_blobs": n, "in_library_single_call_blobs_per_s": round(n / (statistics.median(ts) / 1e3), 1),
+                    "in_library_exchange": "ncclAllGather (RCCL)" if ag > ag0 else "peer copies" if peer > peer0 else "none (not sharded)"})
+        # (b) fan-out: G batches of 64; commitments and proofs from the handle itself
+        G = many_batches_per_device * world
+        nb = G * N_PER_BATCH
+        import numpy as np
+        hb = np.empty(nb * BLOB, dtype=np.uint8)
+        base = np.frombuffer(b"".join(random_blob(900000 + i) for i in range(256)), dtype=np.uint8).reshape(256, BLOB)
+        for k in range(0, nb, 256):                               # 256 distinct blobs tiled (every batch is honest; the verdicts do not depend on distinctness)
+            m = min(256, nb - k)
+            hb[k * BLOB:(k + m) * BLOB] = base[:m].reshape(-1)
+        out48 = C.create_string_buffer(48 * 256); st = (C.c_int * 256)()
+        assert L.kzg355_blob_to_kzg_commitment_many(out48, st, base.ctypes.data_as(C.c_char_p), 256, s.handle) == 0
+        c256 = out48.raw
+        assert L.kzg355_compute_blob_kzg_proof_many(out48, st, base.ctypes.data_as(C.c_char_p), c256, 256, s.handle) == 0
+        p256 = out48.raw
+        reps = (nb + 255) // 256
+        hc, hp = (c256 * reps)[:48 * nb], (p256 * reps)[:48 * nb]
+        okg = (C.c_bool * G)(); stg = (C.c_int * G)()
+        rates = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            rc = L.kzg355_verify_blob_kzg_proof_batch_many(okg, stg, hb.ctypes.data_as(C.c_char_p), hc, hp, N_PER_BATCH, G, s.handle)
+            dtm = time.perf_counter() - t0
+            assert rc == 0 and bytes(okg) == b"\x01" * G, rc
+            if i:
+                rates.append(nb / dtm)
+        out.update({"in_library_blobs_per_s": round(statistics.median(rates), 1), "in_library_many_batches": G,
+                    "in_library_note": "ONE handle over all N devices in one process, host buffers through the drop-in C ABI (PCIe inside the calls): single_call = one "
+                                       "verify_blob_kzg_proof_batch of 64 N blobs (config 5's shape); blobs_per_s = one *_many call of 128 N batches of 64 fanned out over the devices"})
+    finally:
+        s.free()
+    return out
 
 
 def run_msm_legs(kz, L, torch, dev, g1, g2, t_blobs, t_c, commitments, proofs, n, steps=6, warmup=2):

@@ -95,7 +95,7 @@ typedef struct kzg355_options {
     int host_sha;              /* host SHA-256 form: 0 SHA extensions when the CPU has them, 1 portable C, 2 SHA extensions      KZG355_HOST_SHA=portable|shani */
     int host_rhash;            /* batch challenge r of lone small calls hashed on the host (records copied back, ~60 us instead of a 0.33 ms
                                   device chain): 0 by size, -1 never                                                       KZG355_HOST_RHASH=off */
-    int host_rhash_max_records;/* ... up to this many records per call (0 = 256)                                           KZG355_HOST_RHASH_MAX */
+    int host_rhash_max_records;/* ... up to this many records per call (0 = 1024: one 512-blob batch is a 2.6 ms chain on the device)  KZG355_HOST_RHASH_MAX */
     int challenge_form;        /* device Fiat-Shamir kernel: 0 by size (two-wave form up to 2 workgroups per CU), 1 one wave, 2 two waves   KZG355_CHALLENGE=1w|2w */
     int lincomb_form;          /* batch linear combination: 0 by size, 1 per-term windows, 2 buckets, 3 pre-shifted        KZG355_LINCOMB=window|bucket|preshift */
     int pairing_lane;          /* 1: one-lane pairing kernel (A/B and tests)                                               KZG355_PAIRING=lane */

@@ -29,8 +29,8 @@ def load():
     # /opt/rocm).  If torch is going to be used in this process (device tensors handed to the *_device entry points,
     # torch.distributed for the sharded path) it must be imported BEFORE libkzg355.so so that both bind to the same
     # runtime; loading ours first leaves torch unable to see the GPU.  Pure C / Rust consumers simply get /opt/rocm.
-    # (the library's constructor asks the HIP runtime for 24 hardware queues instead of 4 -- concurrent small calls are chains on several streams
-    # each, csrc/api.hip kzg355_runtime_defaults; said here as well, in case torch touches the runtime first)
+    # (24 hardware queues instead of the HIP runtime's 4: concurrent small calls are chains on several streams each, csrc/engine.h.  The variable
+    # belongs to the process, so it is set HERE, before the first HIP call -- the library itself no longer touches the environment)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     if os.environ.get("KZG355_NO_TORCH_PRELOAD") != "1":
         try:

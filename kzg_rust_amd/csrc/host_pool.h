@@ -1,4 +1,4 @@
-// host_pool.h -- the host worker threads of a settings handle (api.hip).  Header-only and free of HIP so that tests/native/host_pool_test.cpp can
+// host_pool.h -- the host worker threads of a settings handle (engine.h).  Header-only and free of HIP so that tests/native/host_pool_test.cpp can
 // run it under ThreadSanitizer on the build box.
 #pragma once
 #include <atomic>

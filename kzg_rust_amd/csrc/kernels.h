@@ -1,4 +1,4 @@
-// kernels.h -- internal interface between the C-ABI host code (api.hip) and the HIP kernel translation
+// kernels.h -- internal interface between the C-ABI host code (engine.h and the host translation units it lists) and the HIP kernel translation
 // units (k_setup.hip, k_verify.hip, k_msm.hip, k_prove.hip).  Not installed; the public boundary is
 // include/kzg355.h.
 #pragma once

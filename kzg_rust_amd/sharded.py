@@ -78,6 +78,17 @@ class HipEngine:
         if rc != 0:
             words.fill_(1 + 256 * rc)
 
+    def batch_intermediates(self, records, n, groups):
+        """audit readback of stage 2 on gathered records (kzg355_debug_batch_intermediates): per batch (r, proof_lincomb, rhs, ok, status) -- what
+        bench.py's N > 1 parity gate compares with the committed fixture / the single-device run (transcript order of utils.rs:454-463)"""
+        out = C.create_string_buffer(128 * max(groups, 1))
+        ok = (C.c_bool * max(groups, 1))()
+        st = (C.c_int * max(groups, 1))()
+        rc = self.L.kzg355_debug_batch_intermediates(out, ok, st, records.data_ptr(), n, groups, self.s.handle)
+        if rc not in (0, 1):
+            raise RuntimeError(f"kzg355_debug_batch_intermediates: status {rc}")
+        return [(out.raw[128 * g:128 * g + 32], out.raw[128 * g + 32:128 * g + 80], out.raw[128 * g + 80:128 * g + 128], bool(ok[g]), int(st[g])) for g in range(groups)]
+
     def verify_records(self, records, points, n, groups):
         ok = (C.c_bool * max(groups, 1))()
         st = (C.c_int * max(groups, 1))()
@@ -131,7 +142,7 @@ def _tick(timings, key, t0, device=None):
 
 
 def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group=None, force_exchange=False,
-                                        exchange=None, timings=None):
+                                        exchange=None, timings=None, capture=None):
     """`groups` independent batches; this rank holds n_local blobs of each (group-major uint8 tensors).
     Returns (ok[groups], status[groups]) -- identical on every rank.  status != 0 <=> the reference returns Err.
 
@@ -141,7 +152,9 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
       "allgather"  BASELINE.json's north_star form: ONE all-gather of every rank's records (+ points + stage-1 statuses), then EVERY rank
                    runs stage 2 on all batches (replicated: no second collective, world x the stage-2 work).
     timings (dict or None): accumulates stage1_ms / exchange_ms / stage2_ms / merge_ms of this rank, so that a scaling curve can be
-    attributed (bench.py reports them per rank in config.exchange)."""
+    attributed (bench.py reports them per rank in config.exchange).
+    capture (dict or None; device-words path only): receives "records" -- the gathered records this rank's stage 2 ran on, in transcript order
+    (all batches for "allgather", this rank's share for "alltoall": "share" = (first batch, end batch)) -- for bench.py's parity gate."""
     import time
     import numpy as np
     import torch
@@ -155,7 +168,7 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     dev = local_blobs.device
     t0 = time.perf_counter()
     if hasattr(engine, "shard_records_words") and local_blobs.is_cuda and (world > 1 or (force_exchange and dist.is_initialized())):
-        return _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world)
+        return _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world, capture)
     rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
     t0 = _tick(timings, "stage1_ms", t0)
     if world == 1 and not (force_exchange and dist.is_initialized()):      # (force_exchange: run the collectives of a one-rank group too -- test hook)
@@ -250,7 +263,7 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()
 
 
-def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world):
+def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world, capture=None):
     """The N > 1 path over an engine that leaves its per-batch results on the device (HipEngine): statuses and verdicts travel as int32 words in
     device memory -- through the all-gather's buffer or the all-reduce -- and are read back ONCE, at the end; a failure of a whole engine call is
     a status on every batch of that rank, seen by all ranks after the merge (nobody raises in the middle of a collective sequence).
@@ -290,6 +303,8 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
         st1 = per_src[:, groups * (rec_b + pts_b):].contiguous().view(torch.int32).view(world, groups).max(dim=0).values
         torch.cuda.synchronize(dev)                                # the permutes ran on torch's stream, the engine has its own
         t0 = _tick(timings, "exchange_ms", t0)
+        if capture is not None:
+            capture["records"], capture["share"] = recs, (0, groups)
         engine.verify_records_words(recs, points, n_local * world, groups, code[groups:])      # every rank: all the batches
         t0 = _tick(timings, "stage2_ms", t0)
         # Stage 2 is replicated, so its verdicts need no merge -- but a whole-call failure of ONE rank's stage 2 (out of memory: every rank runs
@@ -322,6 +337,8 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
             points = per_src[:, mine * rec_b:].reshape(world, mine, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
             torch.cuda.synchronize(dev)
             t0 = _tick(timings, "exchange_ms", t0)
+            if capture is not None:
+                capture["records"], capture["share"] = recs, (g_lo, g_hi)
             engine.verify_records_words(recs, points, n_local * world, mine, code[groups + g_lo:groups + g_hi])
             t0 = _tick(timings, "stage2_ms", t0)
         else:

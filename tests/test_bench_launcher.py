@@ -35,6 +35,27 @@ def test_gpus_2_launches_two_ranks_and_forwards_arguments():
     assert line["master_addr"] == "127.0.0.1"
 
 
+def test_default_exchange_is_both_and_the_new_flags_reach_the_ranks():
+    """round 5: one invocation times both exchange forms behind the parity gate; the flags that turn parts off are forwarded like the rest"""
+    r = run(["--gpus", "2", "--steps", "2", "--no-parity-gate", "--no-in-library-leg"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip())
+    assert line["exchange"] == "both" and line["world"] == 2
+    assert line["argv"] == ["--gpus", "2", "--steps", "2", "--no-parity-gate", "--no-in-library-leg"]
+    import bench
+    src = open(bench.__file__).read()
+    assert "def parity_gate(" in src and "def in_library_leg(" in src and "value_exchange" in src
+
+
+def test_too_few_devices_is_one_clear_line_and_a_non_zero_exit():
+    """`--gpus N` with fewer than N visible devices: every rank says so and exits 3 before any rendezvous (this container has no GPU at all)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KZG355_BENCH_ECHO")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_a_failing_rank_fails_the_launcher():
     r = run(["--gpus", "2"], KZG355_BENCH_ECHO_RC="7")
     assert r.returncode != 0

@@ -835,7 +835,7 @@ def lincomb_handles(kz, setup_bytes):
         hs["rhash-lanes"] = kz.Kzg.load_trusted_setup([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)])
     finally:
         del os.environ["KZG355_RHASH_LANES_FROM"]; del os.environ["KZG355_LC_CHAIN_FROM"]; del os.environ["KZG355_LINCOMB"]
-    # the batch challenge r of a lone small call is hashed on the HOST by default (records copied back, api.hip run_stage2): this
+    # the batch challenge r of a lone small call is hashed on the HOST by default (records copied back, verify_stages.hip run_stage2): this
     # handle keeps the device transcript hash (k_rpowers) for every size, so that both routes meet the same fixtures
     os.environ["KZG355_HOST_RHASH"] = "off"
     try:
