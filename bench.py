@@ -210,6 +210,9 @@ def main():
         raise SystemExit(int(os.environ.get("KZG355_BENCH_ECHO_RC", "0")) if rank == world - 1 else 0)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
+    # 24 hardware queues instead of the HIP runtime's 4 (concurrent small calls are chains on several streams each): the variable
+    # belongs to the process and must be set before its first HIP call -- here, in front of torch -- since the library no longer sets it itself
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     import torch
     import torch.distributed as dist
     if world > 1 and not os.environ.get("KZG355_BENCH_ONE_GPU") and torch.cuda.device_count() < world:

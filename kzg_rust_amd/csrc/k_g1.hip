@@ -9,13 +9,14 @@
 #endif
 #include "kernels.h"
 #include "g1_quad.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace kzg {
 
 // ------------------------------------------------------------------------------------------------ points
 // thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
-__global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
-                                                         G1Affine *pts, int *err, int stride) {
+__device__ __forceinline__ void validate_points_body(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group, G1Affine *pts, int *err, int stride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
     const bool is_proof = j >= n_total;
@@ -30,6 +31,16 @@ __global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commi
     const int g = i / n_per_group, k = i % n_per_group;
     if (rc != 0) { atomicOr(&err[g], ERR_BAD_POINT); p = g1a_inf(); }
     if (pts) pts[(size_t)g * 2 * n_per_group + (is_proof ? n_per_group + k : k)] = p;
+}
+__global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+                                                         G1Affine *pts, int *err, int stride) {
+    validate_points_body(commitments, proofs, n_total, n_per_group, pts, err, stride);
+}
+// VERDICT r4 item 9, one time-boxed attempt: the same body at ONE wave per SIMD, so that the 86 registers the two-wave form spills to scratch fit the
+// 512-register budget (the allocator parks them in AGPRs).  KZG355_VALIDATE_FORM=1w selects it; the measurement is in DESIGN.md section 8.
+__global__ void __launch_bounds__(256, 1) k_validate_points_w1(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
+                                                            G1Affine *pts, int *err, int stride) {
+    validate_points_body(commitments, proofs, n_total, n_per_group, pts, err, stride);
 }
 
 // The two halves of k_validate_points as kernels of their own, for the single-proof entry point: the linear combination only needs
@@ -744,7 +755,9 @@ __global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, 
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
                             hipStream_t st, int stride) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+    static const bool one_wave = [] { const char *e = getenv("KZG355_VALIDATE_FORM"); return e && strcmp(e, "1w") == 0; }();      // experiment knob
+    if (one_wave) hipLaunchKernelGGL(k_validate_points_w1, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+    else hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
 }
 // Test / audit readback of stage 2 (tests/test_gpu_parity.py): per batch  r (32 bytes big-endian, utils.rs:472) | proof_lincomb (48) |
 // rhs (48), the latter two ZCash-compressed like bytes_from_g1 (utils.rs:221-227).  pair_pts holds -proof_lincomb (utils.rs:198-201).

@@ -2,14 +2,14 @@
 # Collects the rocprofv3 evidence of a round on the GPU box: kernel-trace stats and the three counter passes (separately, as
 # MI355X_MICROARCH.md prescribes) over the same bench.py command, plus the secondary bench lines.  usage: collect_profiles.sh rNN vK
 set -u
-R=${1:-r04}; V=${2:-v1}
+R=${1:-r05}; V=${2:-v1}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the load-time self-test launches the verify kernels once on 16 blobs: kept out of the per-kernel averages of the profiled runs
 export KZG355_SELFTEST=0
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-leg --no-latency"   # every verify launch is a full-size one
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-leg --no-latency --no-msm-legs"   # every verify launch is a full-size one
 echo "== kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err; echo rc=$?
 echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/fetch.err; echo rc=$?
 echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/write.err; echo rc=$?

@@ -13,6 +13,7 @@ def blobs_of_launch(kernel, grid, npg=64):
         "k_eval": 64, "k_challenge_1w": 1, "k_challenge": 2, "k_challenge_from_digest": 1,
         "k_validate_points": 2, "k_decompress_points": 2, "k_subgroup_points": 2, "k_points_from_records": 2,
         "k_msm_wide<false>": 256, "k_msm_wide<true>": 256, "k_msm_wide_glv<false>": 256, "k_msm_wide_glv<true>": 256, "k_msm_finalize": 64, "k_quotient": 1024,
+        "k_quotient_tree<2>": 1024, "k_quotient_tree<4>": 256, "k_quotient_tree<6>": 64, "k_quotient_prep": 1, "k_validate_points_w1": 2,
         "k_digits_from_blobs": 4096, "k_digits_from_fr": 4096, "k_msm_bucket<4>": 512, "k_msm_bucket<1>": 4096,
         "k_small_records": 1, "k_small_commit": 1, "k_small_proof": 1,
     }
