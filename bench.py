@@ -526,11 +526,24 @@ def main():
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         park = (lambda: dist.barrier(group=parking)) if parking is not None else dist.barrier
         park()
+        hung = False
         if rank == 0:
-            try:
-                in_library = in_library_leg(kz, L, g1, g2, world, random_blob, one_gpu=bool(os.environ.get("KZG355_BENCH_ONE_GPU")))
-            except Exception as e:  # noqa: BLE001  (the leg must never cost the run its line)
-                in_library = {"in_library_error": repr(e)[:300]}
+            # The leg must never cost the run its line: an exception is reported in the line, and so is a HANG (an RCCL that deadlocks inside the library
+            # cannot be cancelled) -- the leg runs on a daemon thread under a watchdog, and a run whose leg did not come back prints its line, lets the
+            # other ranks go and leaves through os._exit.
+            import threading
+            box = {}
+
+            def leg():
+                try:
+                    box["out"] = in_library_leg(kz, L, g1, g2, world, random_blob, one_gpu=bool(os.environ.get("KZG355_BENCH_ONE_GPU")))
+                except Exception as e:  # noqa: BLE001
+                    box["out"] = {"in_library_error": repr(e)[:300]}
+            th = threading.Thread(target=leg, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("KZG355_BENCH_IN_LIBRARY_TIMEOUT", "240")))
+            hung = th.is_alive()
+            in_library = {"in_library_error": "timed out (the leg is still running; its thread was abandoned)"} if hung else box.get("out")
         park()
 
     if rank == 0:
@@ -584,6 +597,9 @@ def main():
         s.free()
     if world > 1:
         dist.destroy_process_group()
+        if rank == 0 and in_library and "timed out" in str(in_library.get("in_library_error", "")):
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)                                  # the abandoned in-library thread is stuck in a device call: no orderly interpreter shutdown
 
 
 def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, backend):
