@@ -180,6 +180,7 @@ template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(
     constexpr int TPB = 4096 >> LG, NW = TPB / 64, L = LG - 2, D0 = 12 - LG, GROUPS = 1 << L;
     static_assert(LG >= 2 && LG <= 6 && (TPB % 64) == 0, "2^LG leaves per lane, whole waves per blob");
     __shared__ __attribute__((aligned(16))) uint32_t red[NW][2][NFR + 1];
+    __shared__ uint32_t ybuf[NFR + 1];
     const int blob_i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const QuotPrep &pp = prep[blob_i];
     if (fr_is_zero(pp.W)) return;                                  // z inside the domain (block-uniform): k_quotient_scan's
@@ -242,22 +243,32 @@ template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(
         for (int k = 0; k < NFR; k++) { red[wid][0][k] = Su.l[k]; red[wid][1][k] = Sp.l[k]; }
     }
     __syncthreads();
-    Su = fr_zero(); Sp = fr_zero();
+    // y is the same for every lane of the blob: the compiler moves its three products and the folds to the SCALAR unit (~2700 scalar instructions).  ONE
+    // wave does that and leaves y in LDS for the others -- with every wave at it the kernel spent 11 % of its instructions there (below 10 %).
+    if (wid == 0) {
+        Su = fr_zero(); Sp = fr_zero();
 #pragma unroll 1
-    for (int w = 0; w < NW; w++) {
-        Fr a, b;
+        for (int w = 0; w < NW; w++) {
+            Fr a, b;
 #pragma unroll
-        for (int k = 0; k < NFR; k++) { a.l[k] = red[w][0][k]; b.l[k] = red[w][1][k]; }
-        fr_add_lazy(Su, Su, a); fr_add_lazy(Sp, Sp, b);
+            for (int k = 0; k < NFR; k++) { a.l[k] = red[w][0][k]; b.l[k] = red[w][1][k]; }
+            fr_add_lazy(Su, Su, a); fr_add_lazy(Sp, Sp, b);
+        }
+        Fr y0;
+        quot_y(y0, Su, Sp, pp);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NFR; k++) ybuf[k] = y0.l[k];
+            const uint32_t r2[NFR] = FR_R2_INIT;                  // Montgomery form for the callers that hand y out (compute_kzg_proof, kzg.rs:455)
+            Fr R2; for (int i = 0; i < NFR; i++) R2.l[i] = r2[i];
+            Fr ym; fr_mul(ym, y0, R2);
+            y_out[blob_i] = ym;
+        }
     }
+    __syncthreads();
     Fr y;
-    quot_y(y, Su, Sp, pp);
-    if (tid == 0) {                                               // Montgomery form for the callers that hand y out (compute_kzg_proof, kzg.rs:455)
-        const uint32_t r2[NFR] = FR_R2_INIT;
-        Fr R2; for (int i = 0; i < NFR; i++) R2.l[i] = r2[i];
-        Fr ym; fr_mul(ym, y, R2);
-        y_out[blob_i] = ym;
-    }
+#pragma unroll
+    for (int k = 0; k < NFR; k++) y.l[k] = ybuf[k];
 #pragma unroll 1
     for (int g = 0; g < GROUPS; g++) {
         const int a10 = (tid << L) + g;

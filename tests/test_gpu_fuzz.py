@@ -81,3 +81,33 @@ def test_msm_fuzz_every_table_form(msm_cases, form):
     bad_c, bad_p, shape = fm.run_form(kz, form, blobs, want_c, want_p)
     assert shape[0] == int(str(form).split("-")[-1]) and shape[2] == (0 if str(form).startswith("glv-off") else 1), shape
     assert (bad_c, bad_p) == (0, 0), f"table form {form} {shape}: {bad_c} commitments and {bad_p} proofs of {len(blobs)} differ from the oracle"
+
+
+@pytest.mark.parametrize("form", [2, 4, 6])
+def test_quotient_tree_every_lane_shape(msm_cases, form, oracle, oracle_settings, setup_bytes):
+    """k_quotient_tree<LG> (quot_core.h): 4 / 16 / 64 leaves per lane.  The library picks 2^2 below 512 blobs and 2^4 above; KZG355_QUOTIENT_FORM pins one.
+    Proofs of 60 blobs of the five kinds byte-exact against the oracle under each, and compute_kzg_proof at z outside and INSIDE the domain (the
+    latter goes to the scan kernel through k_quotient_prep's list whatever the form; reference src/kzg.rs:461-528)."""
+    import kzg_rust_amd as kz
+    blobs, want_c, want_p = msm_cases
+    g1, g2 = setup_bytes
+    os.environ["KZG355_QUOTIENT_FORM"] = str(form)
+    try:
+        s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], msm_bits=12)
+    finally:
+        del os.environ["KZG355_QUOTIENT_FORM"]
+    try:
+        n = 60
+        B = [kz.Blob(b) for b in blobs[:n]]
+        got = kz.Kzg.compute_blob_kzg_proof_many(B, [kz.KzgCommitment(c) for c in want_c[:n]], s)
+        assert [p.to_bytes() for p in got] == want_p[:n]
+        R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+        w = pow(7, (R_ - 1) // 4096, R_)
+        for zi in (5, R_ - 2, pow(w, 1, R_), pow(w, 2049, R_), 1, R_ - 1):       # the last four are roots of unity: z inside the domain
+            z = zi.to_bytes(32, "big")
+            for b in (blobs[1], blobs[3]):
+                pr, y = kz.Kzg.compute_kzg_proof(kz.Blob(b), kz.Bytes32(z), s)
+                wp, wy = oracle.compute_kzg_proof(b, z, oracle_settings)
+                assert (pr.to_bytes(), y.to_bytes()) == (wp, wy), (form, hex(zi))
+    finally:
+        s.free()
