@@ -388,3 +388,76 @@ def test_handle_freed_with_a_ticket_out_is_released_by_the_last_collect(kz, setu
     ok = (C.c_bool * G)(); st = (C.c_int * G)()
     assert L.kzg355_verify_collect(tk, ok, st) == 0
     assert [bool(x) for x in ok] == [True, False, True] and list(st) == [0, 0, 0]
+
+
+def test_concurrent_device_resident_small_calls(kz, settings, batch):
+    """Four threads making device-resident n = 64 calls on ONE handle at once: every call takes the host route on its own workspace (pinned slot, chunk
+    events, hashing job on the shared host threads), honest batches are true and a batch with two proofs swapped is false -- no cross-talk between the calls."""
+    import torch
+    blobs, cs, ps = batch
+    L = kz.kzg.lib()
+    dev = torch.device("cuda", settings.device)
+    n = 64
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(ps[:n])), dtype=torch.uint8).to(dev)
+    sw = list(ps[:n]); sw[7], sw[40] = sw[40], sw[7]
+    tsw = torch.frombuffer(bytearray(b"".join(sw)), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    T, R = 4, 10
+    errors = []
+    before = settings.host_hashed_calls
+    gate = threading.Barrier(T)
+
+    def work(k):
+        ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
+        gate.wait()
+        for r in range(R):
+            honest = (k + r) % 2 == 0
+            rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), (tp if honest else tsw).data_ptr(), n, 1, settings.handle)
+            if rc != 0 or st[0] != 0 or bool(ok[0]) is not honest:
+                errors.append((k, r, rc, st[0], bool(ok[0]), honest))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert settings.host_hashed_calls - before == T * R
+
+
+def test_load_free_cycles_release_device_memory(kz, setup_bytes, batch):
+    """Thirty load -> a few calls (host-buffer, device-resident, submit / collect) -> free cycles: the device memory the process holds does not creep
+    (workspaces, streams, the chunk events of the device-resident host route, tickets, the host threads all go with the handle)."""
+    import torch
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    L = kz.kzg.lib()
+    dev = torch.device("cuda", 0)
+    n = 8
+    tb = torch.frombuffer(bytearray(b"".join(blobs[:n])), dtype=torch.uint8).to(dev)
+    tc = torch.frombuffer(bytearray(b"".join(cs[:n])), dtype=torch.uint8).to(dev)
+    tp = torch.frombuffer(bytearray(b"".join(ps[:n])), dtype=torch.uint8).to(dev)
+    B, Cm, Pr = [kz.Blob(b) for b in blobs[:n]], [kz.KzgCommitment(c) for c in cs[:n]], [kz.KzgProof(p) for p in ps[:n]]
+    torch.cuda.synchronize()
+
+    def cycle():
+        s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], msm_bits=8, self_test=0)
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B, Cm, Pr, s) is True
+        ok = (C.c_bool * 1)(); st = (C.c_int * 1)()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, st, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 1, s.handle) == 0 and ok[0]
+        tk = C.c_void_p()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device_submit(C.byref(tk), tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), n, 1, s.handle) == 0
+        assert L.kzg355_verify_collect(tk, ok, st) == 0 and ok[0]
+        s.free()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(30):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, f"device memory crept by {(free0 - free1) >> 20} MiB over 30 load / free cycles"
