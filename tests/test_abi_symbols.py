@@ -128,3 +128,32 @@ def test_load_ex_checks_counts_before_any_device_work(lib):
     assert lib.kzg355_load_trusted_setup_ex(bytes(48 * 4095), 4095, bytes(96 * 65), 65, None, 0, C.byref(o), C.byref(h)) == 5
     if not torch.cuda.is_available():
         assert lib.kzg355_load_trusted_setup_ex(bytes(48 * 4096), 4096, bytes(96 * 65), 65, None, 0, None, C.byref(h)) == 6
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(lib, tmp_path):
+    """The boundary is a C ABI: include/kzg355.h compiles as C11 with -pedantic (what a cgo / bindgen / ctypes consumer sees), and a C program that calls
+    through it links against libkzg355.so and -- without a GPU -- gets KZG355_NO_DEVICE from the load, never a fallback."""
+    import torch
+    src = tmp_path / "consumer.c"
+    src.write_text('#include "kzg355.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    kzg355_options o; kzg355_options_default(&o);\n'
+                   '    if (o.struct_size != sizeof o || o.device != -1 || o.self_test != 1) return 10;\n'
+                   '    static unsigned char g1[48 * 4096], g2[96 * 65];\n'
+                   '    kzg355_settings *s = 0;\n'
+                   '    int rc = kzg355_load_trusted_setup(g1, 4095, g2, 65, &s);      /* wrong count: BADARGS / INVALID_TRUSTED_SETUP before any device work */\n'
+                   '    if (rc == KZG355_OK || s) return 11;\n'
+                   '    rc = kzg355_load_trusted_setup(g1, 4096, g2, 65, &s);          /* all-zero bytes are no valid points; without a GPU: NO_DEVICE */\n'
+                   '    printf("%s|%d\\n", kzg355_version(), rc);\n'
+                   '    return rc == KZG355_OK ? 12 : 0;\n'
+                   '}\n')
+    exe = tmp_path / "consumer"
+    so_dir = os.path.join(ROOT, "kzg_rust_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L" + so_dir, "-lkzg355", "-Wl,-rpath," + so_dir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    ver, rc = r.stdout.strip().rsplit("|", 1)
+    assert ver.startswith("kzg355")
+    if not torch.cuda.is_available():
+        assert int(rc) == 6, rc                                   # KZG355_NO_DEVICE
