@@ -127,6 +127,18 @@ class PowerSampler:
                 "note": "nominal-issue fractions in roofline.alu are priced at 2.4 GHz; at the clock the card actually sustains under its power cap they are 2400 / sclk higher"}
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """the run's ONE JSON line, to the process's real stdout (main() points file descriptor 1 at stderr for everything else)"""
+    sys.stdout.flush()
+    data = (json.dumps(line) + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def launcher_command(n, argv, port):
     """The command the driver itself uses for N > 1 (task statement): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -202,12 +214,23 @@ def main():
         # `python bench.py --gpus N` the way the N = 1 run is started: this process becomes the launcher.  It has made no GPU call and
         # imported neither torch nor libkzg355.so; the N ranks are CHILD processes (no exec of a process that has touched the GPU).
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    # ONE JSON line on stdout, whatever the libraries under this process print: RCCL announces its version on STDOUT when a communicator is created, gloo
+    # reports its connections there -- so file descriptor 1 is pointed at stderr for the life of the run and the line goes to the real stdout at the end.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     if os.environ.get("KZG355_BENCH_ECHO"):
         # test hook (tests/test_bench_launcher.py, no GPU): every rank reports how it was started; rank 0 prints the line
         if rank == 0:
-            print(json.dumps({"metric": "echo", "argv": sys.argv[1:], "world": world, "gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                              "exchange": args.exchange, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+            emit({"metric": "echo", "argv": sys.argv[1:], "world": world, "gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                  "exchange": args.exchange, "master_addr": os.environ.get("MASTER_ADDR")})
         raise SystemExit(int(os.environ.get("KZG355_BENCH_ECHO_RC", "0")) if rank == world - 1 else 0)
+    # Rehearsal hook (never set by the driver): KZG355_BENCH_FORCE_DIST=1 with one rank under torch.distributed.run makes the N = 1 run take the N > 1 code path --
+    # process group on the real backend (nccl = RCCL), parity gate, both exchange forms through their collectives, the in-library leg -- on the one-GPU box:
+    # RCCL refuses two ranks on one card, so a one-rank group is as much of the nccl path as that box can exercise.
+    multi = world > 1 or (bool(os.environ.get("KZG355_BENCH_FORCE_DIST")) and "WORLD_SIZE" in os.environ)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     # 24 hardware queues instead of the HIP runtime's 4 (concurrent small calls are chains on several streams each): the variable
@@ -222,13 +245,13 @@ def main():
     # Rehearsal hooks for a one-GPU box (never set by the driver): KZG355_BENCH_BACKEND=gloo and KZG355_BENCH_ONE_GPU=1 run the N-rank
     # code path (sharding, the all-to-all, the status merge, max-over-ranks timing) with every rank on device 0; the line says so.
     backend = os.environ.get("KZG355_BENCH_BACKEND", "nccl")
-    rehearsal = backend != "nccl" or bool(os.environ.get("KZG355_BENCH_ONE_GPU"))
+    rehearsal = backend != "nccl" or bool(os.environ.get("KZG355_BENCH_ONE_GPU")) or (multi and world == 1)
     if os.environ.get("KZG355_BENCH_ONE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("KZG355_DEVICE", str(local_rank))
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         try:
@@ -262,7 +285,7 @@ def main():
     if args.sweep:
         line = run_sweep(args, kz, L, s, dev, random_blob)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit(line)
         s.free()
         return
 
@@ -328,22 +351,22 @@ def main():
         elif args.op == "proof":
             rc = L.kzg355_compute_blob_kzg_proof_many_device(out48, st, t_blobs.data_ptr(), t_c.data_ptr(), nb, s.handle)
             assert rc == 0 and out48.raw[:48 * nb] == proofs[:48 * nb]
-        elif world == 1 and args.host_inputs:
+        elif not multi and args.host_inputs:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many(ok, stg, h_blobs.ctypes.data_as(C.c_char_p), commitments, proofs, n_local, g, s.handle)
             assert rc == 0, rc
             assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
-        elif world == 1 and not args.sharded_path:
+        elif not multi and not args.sharded_path:
             rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
             assert rc == 0, rc
             assert bytes(ok)[:g] == b"\x01" * g, "a verification returned false on honest inputs"     # (one memcmp: a Python loop over 8192 verdicts costs ~1 ms per step)
         else:
             # stage 1 on the local shard -> ONE all-to-all of the 160-byte records + decoded points (RCCL over xGMI) -> stage 2 on this rank's share of the batches
-            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, exchange=mode_now[0], timings=exchange_acc)
+            oks, sts = verify_blob_kzg_proof_batch_sharded(t_blobs[:nb * BLOB], t_c[:nb * 48], t_p[:nb * 48], n_local, g, engine, exchange=mode_now[0], timings=exchange_acc, force_exchange=multi and world == 1)
             assert all(oks) and not any(sts), "a verification returned false on honest inputs"
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -358,7 +381,7 @@ def main():
 
     # --pipeline D: one host thread keeps D launch sets in flight (submit / collect halves of the same entry point; every set on its own
     # stream of the handle, so the narrow tail of one set runs under the wide kernels of the next)
-    pipeline = args.pipeline if (args.pipeline > 1 and args.op == "verify" and world == 1 and not args.host_inputs and not args.sharded_path) else 1
+    pipeline = args.pipeline if (args.pipeline > 1 and args.op == "verify" and not multi and not args.host_inputs and not args.sharded_path) else 1
     pending, free_slots = [], [((C.c_bool * Cc)(), (C.c_int * Cc)()) for _ in range(pipeline)]
 
     def collect_oldest():
@@ -383,7 +406,7 @@ def main():
             run_steps(Cc)                              # synchronous: returns when this step's verdicts are on the host
 
     parity = None
-    if world > 1 and args.op == "verify" and not args.no_parity_gate:
+    if multi and args.op == "verify" and not args.no_parity_gate:
         # the only place real-xGMI parity can ever be checked: the sharded path on the real ranks against the committed fixture / the single-device run
         parity = parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, backend)
 
@@ -412,7 +435,7 @@ def main():
         dt = time.perf_counter() - t0
         power = sampler.stop() if sampler else None
         s.set_kernel_timing(False)
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -422,7 +445,7 @@ def main():
         if exchange_acc:
             mine = {k: round(v / K, 3) for k, v in exchange_acc.items()}
             per_rank = [mine]
-            if world > 1:
+            if multi:
                 per_rank = [None] * world
                 dist.all_gather_object(per_rank, mine)
             exchange_stats = {"mode": mode, "per_rank_ms_per_step": per_rank,
@@ -439,7 +462,7 @@ def main():
         return {"mode": mode, "dt": dt, "step_ms": step_ms, "power": power, "exchange_stats": exchange_stats, "stats": stats,
                 "blobs_per_s": K * Cc * n_local * world / dt}
 
-    sharded = world > 1 or args.sharded_path
+    sharded = multi or args.sharded_path
     modes = ["allgather", "alltoall"] if (sharded and args.exchange == "both" and args.op == "verify") else [mode_now[0]]
     runs = {m: timed_region(m) for m in modes}              # (the same K and W for each form, back to back)
     best = max(runs.values(), key=lambda r: r["blobs_per_s"])
@@ -493,17 +516,17 @@ def main():
 
     host_inputs = None
     mid_size = None
-    if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
+    if rank == 0 and not multi and args.op == "verify" and not args.host_inputs and not args.no_host_leg:
         host_inputs = host_leg(L, s, t_blobs, commitments, proofs, n_local, min(Cc, 1024))
         if pipeline == 1 and Cc >= 1024 and not args.sharded_path:
             mid_size = mid_size_leg(L, s, t_blobs, t_c, t_p, n_local)
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
 
     msm_form_at_end = s.msm_form
     msm_legs = None
-    if rank == 0 and world == 1 and args.op == "verify" and not args.host_inputs and not args.no_msm_legs and not args.sharded_path:
+    if rank == 0 and not multi and args.op == "verify" and not args.host_inputs and not args.no_msm_legs and not args.sharded_path:
         # BASELINE configs[1] and [2] in the same driver-timed run: the verify handle and its launch sets are released first (69 GB of blobs,
         # the table the untimed setup built), then a handle with the widest MSM table that fits serves both legs
         msm_form_verify_setup = s.msm_form
@@ -517,7 +540,7 @@ def main():
         s = None
 
     in_library = None
-    if world > 1 and args.op == "verify" and not args.no_in_library_leg:
+    if multi and args.op == "verify" and not args.no_in_library_leg:
         # The multi-GPU path a Rust / C caller actually gets: ONE handle over all N devices inside rank 0's process.  The other ranks
         # give their GPUs back first and wait on a HOST-side barrier (gloo) -- an RCCL barrier would keep a kernel spinning on every card.
         t_blobs = t_c = t_p = None
@@ -554,12 +577,12 @@ def main():
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
             "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
-                                   + ("" if world == 1 else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
+                                   + ("" if not multi else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
                                       + ("all-to-all of the 160-B records + decoded points (stage 2 split by batch)" if value_exchange == "alltoall" else
                                          "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)")),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
-                       "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else msm_form_at_end, **({"rehearsal": f"{world} ranks on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and world > 1 else {}),
+                       "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else msm_form_at_end, **({"rehearsal": f"{world} rank(s) on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and multi else {}),
                        "step_ms": {"median": round(statistics.median(step_ms), 4), "min": round(min(step_ms), 4), "mean": round(dt * 1e3 / K, 4)},
                        "latency_ms_single_batch": None if args.no_latency else round(latency_ms, 3), "latency_ms_single_batch_min": None if args.no_latency else round(min(lat), 3),
                        "host_inputs": host_inputs, "mid_size_sets": mid_size, "power": power},
@@ -592,10 +615,10 @@ def main():
         if in_library:
             line["config"].update(in_library)
         flatten_scalars(line, host_inputs, mid_size, power, msm_legs)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if s is not None:
         s.free()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
         if rank == 0 and in_library and "timed out" in str(in_library.get("in_library_error", "")):
             sys.stdout.flush(); sys.stderr.flush()
@@ -631,12 +654,12 @@ def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, ba
     gathered = None
     for mode in ("allgather", "alltoall"):
         cap = {}
-        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, 1, engine, exchange=mode, capture=cap)
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, 1, engine, exchange=mode, capture=cap, force_exchange=world == 1)
         if ok != [True] or st != [0]:
             problems.append(f"{mode}: honest batch gave {ok} / {st}")
         if mode == "allgather":
             gathered = cap.get("records")
-        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tsw, n_local, 1, engine, exchange=mode)
+        ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tsw, n_local, 1, engine, exchange=mode, force_exchange=world == 1)
         if ok != [False] or st != [0]:
             problems.append(f"{mode}: swapped twin gave {ok} / {st}")
     out = {}
