@@ -296,7 +296,9 @@ struct HostFront {
     const uint8_t *d_commitments = nullptr;
     size_t n_blobs = 0;
     bool from_device = false;
+    std::shared_ptr<std::atomic<int>> failed;   // device-resident form: a worker could not wait for its chunk (the digests are then not to be used)
     void finish() { if (running) { running = false; pool->finish(job); job.reset(); } }
+    bool ok() const { return !failed || failed->load() == 0; }
     ~HostFront() { finish(); }
 };
 

@@ -184,6 +184,7 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
             if (hf->from_device) { if ((rc = host_hash_from_device(s, w, hf, d_blobs))) return rc; }
             else HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
             hf->finish();
+            if (!hf->ok()) return KZG355_DEVICE_ERROR;
             HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * n, hipMemcpyHostToDevice, w->stream));
             tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, nullptr, (int)n, w->z.as<Fr>(), nullptr, nullptr,
                     w->stream); tm.end();

@@ -33,8 +33,11 @@ int host_hash_from_device(kzg355_settings *s, Workspace *w, HostFront *hf, const
     hipEvent_t evs[8];
     for (size_t c = 0; c < 8; c++) evs[c] = w->ev_d2h[c];
     struct Ev8 { hipEvent_t e[8]; } ev8; memcpy(ev8.e, evs, sizeof evs);
+    hf->failed = std::make_shared<std::atomic<int>>(0);
+    std::shared_ptr<std::atomic<int>> failed = hf->failed;
     auto job = [=](size_t k) {
-        (void)hipEventSynchronize(ev8.e[(2 * k) / per]);          // (chunks hold whole pairs: both blobs of the pair are behind this event)
+        // (chunks hold whole pairs: both blobs of the pair are behind this event)
+        if (hipEventSynchronize(ev8.e[(2 * k) / per]) != hipSuccess) { (void)hipGetLastError(); failed->store(1); return; }
         kzg_host::challenge_digests(dig + 64 * k, hb + BB * 2 * k, BB, hcm + 96 * k, nb - 2 * k < 2 ? nb - 2 * k : 2, n_fe, impl);
     };
     hf->job = s->host_pool->begin((nb + 1) / 2, job);
@@ -134,6 +137,7 @@ int run_stage1(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blo
         if (hf->from_device) { if ((rc = host_hash_from_device(s, w, hf, d_blobs))) return rc; }
         else if (hf->h_blobs) HIPCHK(hipMemcpyAsync(const_cast<uint8_t *>(d_blobs), hf->h_blobs, hf->bytes, hipMemcpyHostToDevice, w->stream));
         hf->finish();                                             // (h_blobs == null: the caller has queued the copies of its blobs itself)
+        if (!hf->ok()) return KZG355_DEVICE_ERROR;
         HIPCHK(hipMemcpyAsync(w->digests.p, w->h_digests.p, 32 * (size_t)n_total, hipMemcpyHostToDevice, w->stream));
         tm.begin("challenge_from_digest"); launch_challenges_from_digests(w->digests.as<uint8_t>(), d_c, d_p, n_total, w->z.as<Fr>(), w->zpow.as<Fr>(),
                 d_records, w->stream); tm.end();
