@@ -1143,6 +1143,17 @@ def run_sweep(args, kz, L, s, dev, random_blob):
                                                "sample": "per-n / per-op figures under config; oracle -O3 -march=native, restatement in portable C, not blst"}}
 
 
+def cpu_model():
+    """the host CPU's model name ("print nproc, CPU model" next to the CPU baseline)"""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
     """The CPU oracle (kind "port": the build's restatement of the reference algorithm, NOT blst) on the host cores of
     this box: verify_blob_kzg_proof_batch over the same first 64-blob batch, single thread like the reference."""
@@ -1224,7 +1235,7 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
                       + (": Montgomery products with mulx / adcx / adox, SHA-256 with the SHA extensions (the portable-C form of the same code: portable_c_value)" if fast else
                          " (portable C: this host has no BMI2 + ADX; blst's asm is likely 1.5-3x faster per core)"),
             "primitives": "mulx/adcx/adox + sha-ni" if fast else "portable C", "portable_c_value": portable,
-            "host_cpus": os.cpu_count(), "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
                           "note": "same work, one call per thread, ~5 s per trial; best of the trials"}}
 
 
