@@ -167,7 +167,10 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
         raise ValueError(f"exchange must be alltoall or allgather, not {mode!r}")
     dev = local_blobs.device
     t0 = time.perf_counter()
-    if hasattr(engine, "shard_records_words") and local_blobs.is_cuda and (world > 1 or (force_exchange and dist.is_initialized())):
+    # (words_on_host: a CPU stand-in engine of tests/test_sharded_gloo.py that keeps its per-batch words in host tensors -- the SAME orchestration, so that
+    # the exchange, the merge and the failure handling the N-GPU run uses are exercised without a GPU)
+    words_path = hasattr(engine, "shard_records_words") and (local_blobs.is_cuda or getattr(engine, "words_on_host", False))
+    if words_path and (world > 1 or (force_exchange and dist.is_initialized())):
         return _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local, groups, engine, group, mode, timings, world, capture)
     rec, pts, st_local = engine.shard_records(local_blobs, local_commitments, local_proofs, n_local, groups)
     t0 = _tick(timings, "stage1_ms", t0)
@@ -281,11 +284,17 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
     t0 = time.perf_counter()
     # [0:G] stage-1 status of this rank's shard, [G:2G] 1 + ok + 256 * stage-2 status of this rank's share of the batches (0 elsewhere)
     code = torch.zeros(2 * groups, dtype=torch.int32, device=dev)
-    torch.cuda.current_stream(dev).synchronize()                   # the fill is on torch's stream, the engine writes on its own
+    on_gpu = dev.type == "cuda"
+    if on_gpu:
+        torch.cuda.current_stream(dev).synchronize()               # the fill is on torch's stream, the engine writes on its own
     rec, pts = engine.shard_records_words(local_blobs, local_commitments, local_proofs, n_local, groups, code[:groups])
     t0 = _tick(timings, "stage1_ms", t0)
 
     def collective(fn, out_numel, send, *splits):
+        if on_host and not on_gpu:                                 # host tensors over gloo: as they are
+            got = torch.empty(out_numel, dtype=send.dtype)
+            fn(got, send, *splits, group=group)
+            return got
         if on_host:                                                # gloo: staged through host memory (CPU tests, rehearsals on one GPU)
             host = torch.empty(out_numel, dtype=send.dtype)
             fn(host, send.cpu(), *splits, group=group)
@@ -301,7 +310,8 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
         recs = per_src[:, :groups * rec_b].reshape(world, groups, rec_b).permute(1, 0, 2).contiguous().view(-1)
         points = per_src[:, groups * rec_b:groups * (rec_b + pts_b)].reshape(world, groups, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
         st1 = per_src[:, groups * (rec_b + pts_b):].contiguous().view(torch.int32).view(world, groups).max(dim=0).values
-        torch.cuda.synchronize(dev)                                # the permutes ran on torch's stream, the engine has its own
+        if on_gpu:
+            torch.cuda.synchronize(dev)                            # the permutes ran on torch's stream, the engine has its own
         t0 = _tick(timings, "exchange_ms", t0)
         if capture is not None:
             capture["records"], capture["share"] = recs, (0, groups)
@@ -335,7 +345,8 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
             per_src = got.view(world, mine * (rec_b + pts_b))      # from rank i: [records of my batches | points of my batches]
             recs = per_src[:, :mine * rec_b].reshape(world, mine, rec_b).permute(1, 0, 2).contiguous().view(-1)
             points = per_src[:, mine * rec_b:].reshape(world, mine, 2, n_local * POINT).permute(1, 2, 0, 3).contiguous().view(-1)
-            torch.cuda.synchronize(dev)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
             t0 = _tick(timings, "exchange_ms", t0)
             if capture is not None:
                 capture["records"], capture["share"] = recs, (g_lo, g_hi)
@@ -353,6 +364,9 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
     st1, enc = merged[:groups], merged[groups:]
     status = np.where(st1 != 0, st1, enc >> 8)
     _tick(timings, "merge_ms", t0)
-    if (status >= 6).any():                                        # KZG355_NO_DEVICE / NO_MEMORY / DEVICE_ERROR on some rank: every rank has the same merged words
-        raise RuntimeError(f"sharded verification: engine failure on a rank, merged per-batch statuses {sorted(set(status[status >= 6].tolist()))}")
+    # KZG355_NO_DEVICE / NO_MEMORY / DEVICE_ERROR on some rank, in either stage (a stage-2 failure of a batch that already carries a stage-1 Err must not hide
+    # behind it): every rank has the same merged words
+    device_level = np.concatenate([st1[st1 >= 6], (enc >> 8)[(enc >> 8) >= 6]])
+    if device_level.size:
+        raise RuntimeError(f"sharded verification: engine failure on a rank, merged per-batch statuses {sorted(set(device_level.tolist()))}")
     return (((enc & 0xFF) == 2) & (status == 0)).tolist(), status.tolist()

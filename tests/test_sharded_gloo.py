@@ -52,6 +52,30 @@ class OracleEngine:
         return ok, st
 
 
+class OracleWordsEngine(OracleEngine):
+    """The interface HipEngine gives the N-GPU run (shard_records_words / verify_records_words: per-batch results left as int32 words in a tensor the
+    collectives carry) played by the oracle on HOST tensors: `_sharded_device_words` -- the exchange, the permutes into transcript order, the merge, the
+    failure word of the all-gather form -- runs on CPU exactly as `bench.py --gpus N` runs it.  fail_stage2_on: the rank whose stage 2 reports a whole-call
+    device failure (status 7 in every word), as an out-of-memory there would."""
+    words_on_host = True
+
+    def __init__(self, fail_stage2_on=None):
+        super().__init__()
+        self.fail_stage2_on = fail_stage2_on
+
+    def shard_records_words(self, blobs, commitments, proofs, n_local, groups, words):
+        rec, _, st = self.shard_records(blobs, commitments, proofs, n_local, groups)
+        words.copy_(torch.tensor(st, dtype=torch.int32))
+        return rec, torch.zeros(groups * 2 * n_local * 112, dtype=torch.uint8)      # (decoded points: opaque to the orchestration; the oracle's stage 2 decodes the records)
+
+    def verify_records_words(self, records, points, n, groups, words):
+        if self.fail_stage2_on is not None and dist.get_rank() == self.fail_stage2_on:
+            words.fill_(1 + 256 * 7)
+            return
+        ok, st = self.verify_records(records, None, n, groups)
+        words.copy_(torch.tensor([1 + int(o) + 256 * int(c) for o, c in zip(ok, st)], dtype=torch.int32))
+
+
 def _inputs(n_total):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle.oracle import Oracle
@@ -65,7 +89,7 @@ def _inputs(n_total):
     return blobs, cs, ps
 
 
-def _worker(rank, world, port, blobs, cs, ps, q, exchange):
+def _worker(rank, world, port, blobs, cs, ps, q, exchange, engine_kind="records"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -84,7 +108,7 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     tb = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[0])), dtype=torch.uint8)
     tc = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[1])), dtype=torch.uint8)
     tp = torch.frombuffer(bytearray(b"".join(x for bt in batches for x in bt[2])), dtype=torch.uint8)
-    eng = OracleEngine()
+    eng = OracleEngine() if engine_kind == "records" else OracleWordsEngine()
     timings = {}
     ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange, timings=timings)
     assert timings.get("stage1_ms", 0) > 0 and "exchange_ms" in timings and "merge_ms" in timings, timings
@@ -102,12 +126,27 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange):
     if rank == 0:
         bad[:48] = torch.frombuffer(bytearray(bytes([0x9A]) + b"\xff" * 47), dtype=torch.uint8)
     ok3, st3 = verify_blob_kzg_proof_batch_sharded(one(tb, 131072), one(tc, 48), bad, n_local, 1, eng, exchange=exchange)
-    q.put((rank, ok, st, (ok1, st1, ok2, st2, ok3, st3)))
+    raised = None
+    if engine_kind == "words":
+        # a whole-call failure of ONE rank's stage 2 must raise on EVERY rank in both forms (the all-gather form replicates stage 2: only its failure word tells
+        # the others) -- and the ranks must still be in step afterwards
+        try:
+            verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, OracleWordsEngine(fail_stage2_on=world - 1), exchange=exchange)
+            raised = False
+        except RuntimeError:
+            raised = True
+        cap = {}
+        ok4, st4 = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange, capture=cap)
+        assert ok4 == ok and st4 == st
+        lo_g, hi_g = cap.get("share", (0, 0))
+        assert cap.get("records") is None or cap["records"].numel() == (hi_g - lo_g) * n_local * world * 160      # the gathered batches, whole
+    q.put((rank, ok, st, (ok1, st1, ok2, st2, ok3, st3), raised))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "alltoall"), (2, "allgather"), (8, "alltoall"), (8, "allgather")])
-def test_sharded_verify_gloo(world, exchange):
+@pytest.mark.parametrize("world,exchange,engine_kind", [(2, "alltoall", "records"), (2, "allgather", "records"), (8, "alltoall", "records"), (8, "allgather", "records"),
+                                                       (2, "alltoall", "words"), (2, "allgather", "words"), (4, "allgather", "words"), (4, "alltoall", "words")])
+def test_sharded_verify_gloo(world, exchange, engine_kind):
     """both exchanges: the all-to-all with stage 2 split by batch, and BASELINE.json's single all-gather with stage 2 replicated; at world 8
     (config 5's rank count) the three batches fall to ranks 2, 5 and 7 -- five ranks with an empty share of the batches"""
     blobs, cs, ps = _inputs(N_LOCAL * world)
@@ -116,14 +155,15 @@ def test_sharded_verify_gloo(world, exchange):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, blobs, cs, ps, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, blobs, cs, ps, q, exchange, engine_kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, st, single in res:                          # identical verdicts on every rank
+    for rank, ok, st, single, raised in res:                  # identical verdicts on every rank
+        assert raised is (True if engine_kind == "words" else None), (rank, raised)
         assert ok == [True, False, False], (rank, ok)
         assert st[0] == 0 and st[1] == 0 and st[2] != 0, (rank, st)
         ok1, st1, ok2, st2, ok3, st3 = single
