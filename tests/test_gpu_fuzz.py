@@ -3,7 +3,7 @@
 profiles/r04/).  Pass rule as the reference's vector loops (src/lib.rs:189-201): Ok(true) / Ok(false) / Err of every batch equals the
 oracle's, commitments and proofs are byte-exact.
 
-  * 400 mutated batches of 1..12 blobs x 3 routes (one host-buffer call per batch, *_many on host buffers, device-resident submit / collect),
+  * 400 mutated batches of 1..12 blobs x 4 routes (one host-buffer call per batch, *_many on host buffers, device-resident submit / collect, device-resident synchronous calls),
     once per dispatch form: the defaults (few batches: pre-shifted / windowed lincomb, two-wave segmented pairing), then the forms only LARGE
     launch sets take by themselves, forced through the KZG355_* test overrides -- the bucket lincomb ending in one Horner chain per class,
     the final exponentiation's hard part twelve lanes per check, three Miller segments per pair;
@@ -62,7 +62,7 @@ def test_verify_fuzz_three_routes(verify_cases, form):
         bad = fv.run_routes(kz, s, cases, want)
     finally:
         s.free()
-    assert bad == (0, 0, 0), f"{form}: mismatches per route (single calls, *_many, submit / collect) {bad} of {len(cases)} batches"
+    assert bad == (0, 0, 0, 0), f"{form}: mismatches per route (single calls, *_many, submit / collect, synchronous device-resident) {bad} of {len(cases)} batches"
 
 
 @pytest.fixture(scope="module")

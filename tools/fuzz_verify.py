@@ -2,8 +2,9 @@
 """Randomised differential run of verify_blob_kzg_proof_batch against the CPU oracle.  N mutated batches of 1..12 blobs drawn from a pool of honest
 (blob, commitment, proof) triples -- honest, a field element pushed to r / r - 1 / 2^256 - 1, a blob byte flipped, proofs swapped, a commitment
 replaced by another blob's / by infinity / by a random x (off-curve or outside G1), flag bits or a byte of a proof corrupted -- through THREE routes of
-the product: one host-buffer call per batch, all batches of equal size in one *_many call, and the same on device-resident inputs through the
-submit / collect pair.  Ok(true) / Ok(false) / Err must agree with the oracle for every batch on every route (pass rule of src/lib.rs:189-201).
+the product: one host-buffer call per batch, all batches of equal size in one *_many call, the same on device-resident inputs through the
+submit / collect pair (device hash), and -- round 5 -- through the synchronous device-resident call in chunks of at most 512 blobs (the route that copies
+the blobs back and hashes them on the host).  Ok(true) / Ok(false) / Err must agree with the oracle for every batch on every route (pass rule of src/lib.rs:189-201).
 As a tool: minutes of oracle time at the default N (profiles/r04/verify_fuzz.txt: 30,000 batches); tests/test_gpu_fuzz.py runs the same functions
 with a fixed seed and a few hundred batches inside `pytest -m gpu`, once per dispatch form.
 usage: fuzz_verify.py [N]"""
@@ -93,7 +94,8 @@ def oracle_verdicts(cases, workers=None):
 
 
 def run_routes(kz, s, cases, want):
-    """mismatch counts of the three routes: (one host-buffer call per batch, *_many on host buffers, device-resident submit / collect)"""
+    """mismatch counts of the four routes: (one host-buffer call per batch, *_many on host buffers, device-resident submit / collect, device-resident
+    synchronous calls of at most 512 blobs: the host-hash route of kzg355_verify_blob_kzg_proof_batch_many_device)"""
     import torch
     L = kz.kzg.lib(); dev = torch.device("cuda", s.device)
     bad1 = 0
@@ -106,7 +108,8 @@ def run_routes(kz, s, cases, want):
     by_n = {}
     for i, c in enumerate(cases):
         by_n.setdefault(len(c[0]), []).append(i)
-    bad2 = bad3 = 0
+    bad2 = bad3 = bad4 = 0
+    before = s.host_hashed_calls
     for n, ids in sorted(by_n.items()):
         G = len(ids)
         fb = b"".join(b for i in ids for b in cases[i][0]); fc = b"".join(x for i in ids for x in cases[i][1]); fp = b"".join(x for i in ids for x in cases[i][2])
@@ -124,7 +127,16 @@ def run_routes(kz, s, cases, want):
         for k, i in enumerate(ids):
             got = None if st3[k] else bool(ok3[k])
             bad3 += got != want[i]
-    return bad1, bad2, bad3
+        per = max(1, 512 // n)                                   # batches per synchronous call: <= 512 blobs, so every one of them takes the host-hash route
+        for g0 in range(0, G, per):
+            g = min(per, G - g0)
+            ok4 = (C.c_bool * g)(); st4 = (C.c_int * g)()
+            L.kzg355_verify_blob_kzg_proof_batch_many_device(ok4, st4, tb.data_ptr() + 131072 * n * g0, tc.data_ptr() + 48 * n * g0, tp.data_ptr() + 48 * n * g0, n, g, s.handle)
+            for k in range(g):
+                got = None if st4[k] else bool(ok4[k])
+                bad4 += got != want[ids[g0 + k]]
+    run_routes.host_hashed_device_calls = s.host_hashed_calls - before
+    return bad1, bad2, bad3, bad4
 
 
 def main():
@@ -136,10 +148,10 @@ def main():
     t0 = time.time()
     want = oracle_verdicts(cases)
     print(f"oracle: {N} batches in {time.time() - t0:.1f} s: {want.count(True)} true, {want.count(False)} false, {want.count(None)} Err", flush=True)
-    bad1, bad2, bad3 = run_routes(kz, s, cases, want)
+    bad1, bad2, bad3, bad4 = run_routes(kz, s, cases, want)
     print(f"route 1 (one call per batch, host buffers): {bad1} mismatches; route 2 (*_many, host buffers): {bad2} mismatches; "
-          f"route 3 (device-resident, submit / collect): {bad3} mismatches", flush=True)
-    assert bad1 == 0 and bad2 == 0 and bad3 == 0
+          f"route 3 (device-resident, submit / collect): {bad3} mismatches; route 4 (device-resident, synchronous calls of <= 512 blobs: host-hash route): {bad4} mismatches", flush=True)
+    assert bad1 == 0 and bad2 == 0 and bad3 == 0 and bad4 == 0
     print("every verdict of every route agrees with the oracle")
 
 
