@@ -198,9 +198,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="launch sets in flight (device-resident verify, 1 GPU): >1 submits every step with kzg355_verify_blob_kzg_proof_batch_many_device_submit and "
                          "collects the oldest once this many are queued -- mid-size sets (--batches-per-step 1024) kept in flight from one thread")
-    ap.add_argument("--exchange", choices=["both", "alltoall", "allgather"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "both"),
-                    help="N > 1: both (default) = K timed steps of each form back to back, `value` = the better one (config.value_exchange names it); "
-                         "alltoall = stage 2 split by batch; allgather = BASELINE north_star's single all-gather with stage 2 replicated")
+    ap.add_argument("--exchange", choices=["both", "alltoall", "allgather", "allgather_split"], default=os.environ.get("KZG355_BENCH_EXCHANGE", "both"),
+                    help="N > 1: both (default) = K timed steps of EVERY form back to back, `value` = the best one (config.value_exchange names it); "
+                         "alltoall = stage 2 split by batch; allgather = BASELINE north_star's single all-gather with stage 2 replicated; "
+                         "allgather_split = the same all-gather with stage 2 split by batch")
     ap.add_argument("--no-parity-gate", action="store_true", help="N > 1: skip the byte-exact check of the sharded path on the real ranks before the timed steps")
     ap.add_argument("--no-in-library-leg", action="store_true", help="N > 1: skip the timing of the library's own multi-device handle (kzg355_load_trusted_setup_devices) on rank 0")
     ap.add_argument("--sweep", action="store_true",
@@ -463,7 +464,7 @@ def main():
                 "blobs_per_s": K * Cc * n_local * world / dt}
 
     sharded = multi or args.sharded_path
-    modes = ["allgather", "alltoall"] if (sharded and args.exchange == "both" and args.op == "verify") else [mode_now[0]]
+    modes = ["allgather", "allgather_split", "alltoall"] if (sharded and args.exchange == "both" and args.op == "verify") else [mode_now[0]]
     runs = {m: timed_region(m) for m in modes}              # (the same K and W for each form, back to back)
     best = max(runs.values(), key=lambda r: r["blobs_per_s"])
     dt, step_ms, power, exchange_stats, stats = best["dt"], best["step_ms"], best["power"], best["exchange_stats"], best["stats"]
@@ -578,8 +579,9 @@ def main():
             "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if not multi else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
-                                      + ("all-to-all of the 160-B records + decoded points (stage 2 split by batch)" if value_exchange == "alltoall" else
-                                         "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)")),
+                                      + {"alltoall": "all-to-all of the 160-B records + decoded points (stage 2 split by batch)",
+                                         "allgather": "one all-gather of the 160-B records + decoded points (stage 2 replicated: BASELINE north_star's form)",
+                                         "allgather_split": "one all-gather of the 160-B records + decoded points (BASELINE north_star's collective), stage 2 split by batch"}[value_exchange]),
                        "batch_size": n_local * world, "batches_per_step": Cc, "blobs_per_step": Cc * n_local * world,
                        "field_elements_per_blob": 4096, "sets_in_flight": pipeline, "inputs": "host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "resident in HBM",
                        "msm_form": msm_legs["verify_setup_msm_form"] if msm_legs else msm_form_at_end, **({"rehearsal": f"{world} rank(s) on ONE GPU, backend {backend}: code-path check, not a measurement"} if rehearsal and multi else {}),
@@ -608,7 +610,7 @@ def main():
                 for k in ("stage1_ms", "exchange_ms", "stage2_ms", "merge_ms"):
                     if r["exchange_stats"]:
                         cfg[f"{k}_{m}"] = r["exchange_stats"][k]
-            if len(runs) == 2:
+            if len(runs) > 1:
                 cfg["exchange_by_mode"] = {m: r["exchange_stats"] for m, r in runs.items()}
         if parity:
             line["config"].update(parity)
@@ -652,7 +654,7 @@ def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, ba
     torch.cuda.synchronize()
     problems = []
     gathered = None
-    for mode in ("allgather", "alltoall"):
+    for mode in ("allgather", "allgather_split", "alltoall"):
         cap = {}
         ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, 1, engine, exchange=mode, capture=cap, force_exchange=world == 1)
         if ok != [True] or st != [0]:
@@ -686,7 +688,7 @@ def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, ba
                 problems.append("r / proof_lincomb / rhs differ from tests/golden/batch512.json")
             out = {"parity_gate": "passed" if not problems else "FAILED: " + "; ".join(problems), "parity_gate_blobs": n,
                    "parity_gate_r": r_sh.hex(), "parity_gate_against": ("tests/golden/batch512.json (oracle-derived r, proof_lincomb, rhs) and " if n == fx["n"] else "")
-                   + "the single-device run of the same batch on rank 0: records, r, proof_lincomb, rhs byte-exact; verdicts true / false in both exchange forms"}
+                   + "the single-device run of the same batch on rank 0: records, r, proof_lincomb, rhs byte-exact; verdicts true / false in all three exchange forms"}
     flag = torch.tensor([1 if problems else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()):

@@ -151,6 +151,10 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
                    one small all-reduce(MAX) spreads the verdicts and merges the statuses;
       "allgather"  BASELINE.json's north_star form: ONE all-gather of every rank's records (+ points + stage-1 statuses), then EVERY rank
                    runs stage 2 on all batches (replicated: no second collective, world x the stage-2 work).
+      "allgather_split"  the same single all-gather, but stage 2 is NOT replicated: every rank verifies its share of the batches out of the gathered
+                   buffer and one small all-reduce(MAX) spreads the verdict words, as in "alltoall" -- north_star's collective with the all-to-all's
+                   partition of the work (what it costs over "alltoall" is the traffic: every rank receives world x what it needs).  Engines without the
+                   words interface take "allgather" for it (same verdicts).
     timings (dict or None): accumulates stage1_ms / exchange_ms / stage2_ms / merge_ms of this rank, so that a scaling curve can be
     attributed (bench.py reports them per rank in config.exchange).
     capture (dict or None; device-words path only): receives "records" -- the gathered records this rank's stage 2 ran on, in transcript order
@@ -163,8 +167,8 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     if n_local == 0:
         return [True] * groups, [0] * groups                       # kzg.rs:653-655
     mode = exchange or "alltoall"
-    if mode not in ("alltoall", "allgather"):
-        raise ValueError(f"exchange must be alltoall or allgather, not {mode!r}")
+    if mode not in ("alltoall", "allgather", "allgather_split"):
+        raise ValueError(f"exchange must be alltoall, allgather or allgather_split, not {mode!r}")
     dev = local_blobs.device
     t0 = time.perf_counter()
     # (words_on_host: a CPU stand-in engine of tests/test_sharded_gloo.py that keeps its per-batch words in host tensors -- the SAME orchestration, so that
@@ -186,7 +190,7 @@ def verify_blob_kzg_proof_batch_sharded(local_blobs, local_commitments, local_pr
     rec2 = rec.view(groups, rec_b)
     pts2 = None if pts is None else pts.view(groups, pts_b)
     on_host = _on_host(group) and rec.is_cuda
-    if mode == "allgather":
+    if mode in ("allgather", "allgather_split"):
         # ONE all-gather: [records | points | stage-1 statuses (int32 per batch)] of every rank to every rank
         st_bytes = torch.from_numpy(np.asarray(st_local, dtype=np.int32).view(np.uint8).copy())
         parts = [rec.reshape(-1)] + ([pts.reshape(-1)] if pts is not None else [])
@@ -303,7 +307,36 @@ def _sharded_device_words(local_blobs, local_commitments, local_proofs, n_local,
         fn(got, send, *splits, group=group)
         return got
 
-    if mode == "allgather":
+    if mode == "allgather_split":
+        send = torch.cat([rec, pts, code[:groups].view(torch.uint8)])
+        per = send.numel()
+        per_src = collective(dist.all_gather_into_tensor, world * per, send).view(world, per)
+        shares = [((groups * r) // world, (groups * (r + 1)) // world) for r in range(world)]
+        g_lo, g_hi = shares[rank]
+        mine = g_hi - g_lo
+        code[:groups] = per_src[:, groups * (rec_b + pts_b):].contiguous().view(torch.int32).view(world, groups).max(dim=0).values     # stage-1 statuses, merged: the same on every rank
+        if mine > 0:                                               # only this rank's batches are permuted into transcript order
+            recs = per_src[:, :groups * rec_b].reshape(world, groups, rec_b)[:, g_lo:g_hi].permute(1, 0, 2).contiguous().view(-1)
+            points = per_src[:, groups * rec_b:groups * (rec_b + pts_b)].reshape(world, groups, 2, n_local * POINT)[:, g_lo:g_hi].permute(1, 2, 0, 3).contiguous().view(-1)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            t0 = _tick(timings, "exchange_ms", t0)
+            if capture is not None:
+                capture["records"], capture["share"] = recs, (g_lo, g_hi)
+            engine.verify_records_words(recs, points, n_local * world, mine, code[groups + g_lo:groups + g_hi])
+            t0 = _tick(timings, "stage2_ms", t0)
+        else:
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            t0 = _tick(timings, "exchange_ms", t0, dev)
+        if on_host:
+            host = code.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+            merged = host.numpy().astype(np.int64)
+        else:
+            dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)
+            merged = code.cpu().numpy().astype(np.int64)
+    elif mode == "allgather":
         send = torch.cat([rec, pts, code[:groups].view(torch.uint8)])
         per = send.numel()
         per_src = collective(dist.all_gather_into_tensor, world * per, send).view(world, per)

@@ -44,7 +44,7 @@ def _worker(rank, world, port, blobs, cs, ps, q):
     torch.cuda.synchronize()
     eng = HipEngine(s)
     res = []
-    for exchange in ("alltoall", "allgather"):             # stage 2 split by batch / BASELINE.json's single all-gather with stage 2 replicated
+    for exchange in ("alltoall", "allgather", "allgather_split"):      # stage 2 split by batch / BASELINE.json's single all-gather with stage 2 replicated / the all-gather with stage 2 split
         ok, st = verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, eng, exchange=exchange)
         ok1, st1 = verify_blob_kzg_proof_batch_sharded(tb[:n_local * 131072], tc[:n_local * 48], tp[:n_local * 48], n_local, 1, eng, exchange=exchange)    # one batch: rank 0's share is empty
         res.append((exchange, ok, st, ok1, st1))
@@ -58,7 +58,7 @@ def _worker(rank, world, port, blobs, cs, ps, q):
             else:
                 super().verify_records_words(records, points, n, groups, words)
     raised = []
-    for exchange in ("alltoall", "allgather"):
+    for exchange in ("alltoall", "allgather", "allgather_split"):
         try:
             verify_blob_kzg_proof_batch_sharded(tb, tc, tp, n_local, GROUPS, FailingStage2(s), exchange=exchange)
             raised.append(False)
@@ -103,7 +103,7 @@ def test_sharded_driver_two_ranks_on_the_hip_engine():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, per_exchange, raised, ok_after, st_after in res:
-        assert raised == [True, True], (rank, raised)
+        assert raised == [True, True, True], (rank, raised)
         assert ok_after == [True, False, False] and st_after[:2] == [0, 0], (rank, ok_after, st_after)
         for exchange, ok, st, ok1, st1 in per_exchange:
             assert ok == [True, False, False], (rank, exchange, ok)
