@@ -821,6 +821,23 @@ def run_msm_legs(kz, L, torch, dev, g1, g2, t_blobs, t_c, commitments, proofs, n
         d = {"blobs_per_s": round(rate, 1), "ms_per_launch": round(dt * 1e3 / steps, 3), "kernel_ms": kms,
              "algorithmic_bytes_per_blob": b_alg, "g1_sweep_hbm_frac": round(rate * b_alg / (HBM_PEAK_GBPS * 1e9), 5),
              "traffic_bytes_per_blob": round(traffic) if traffic else None, "traffic_over_algorithmic": round(traffic / b_alg, 2) if traffic else None, "traffic_source": src}
+        # the MSM kernel (and the quotient kernel of the proof leg) against the floor of its own instruction mix, as roofline.alu does for the verify kernels
+        mix_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "inst_mix.json")))
+        mix = json.load(open(mix_files[-1]))["per_kernel"] if mix_files else {}
+        for fam, key in (("msm_wide", "msm"), ("quotient", "quotient")):
+            if fam not in kms:
+                continue
+            f, per = newest_profile("sq", KERNEL_NAMES[fam], op)
+            cands = [k for k in KERNEL_NAMES[fam] if per and k in per and k in mix]
+            if op == "proof" and fam == "msm_wide":
+                cands = [k for k in cands if "true" in k] or cands     # the quotient arrives as scalars in the blob format since round 5: <false> either way; keep whichever ran
+            if not cands:
+                continue
+            k0 = max(cands, key=lambda k: per[k].get("launches", 0) * per[k].get("blobs_per_launch", 0))
+            insts = per[k0]["valu_wave_insts_per_blob"]
+            achieved_ns = kms[fam] * 1e6 * N_SIMD / (insts * n)
+            d[f"{key}_frac_of_mix_floor"] = round(mix[k0]["mix_floor_ns"] / achieved_ns, 4)
+            d[f"{key}_wave_insts_per_blob"] = round(insts, 1)
         if rows_per_blob:
             d["rows_per_blob"] = round(rows_per_blob)
             d["rows_per_s"] = round(rows_per_blob * rate)
@@ -859,6 +876,8 @@ def flatten_scalars(line, host_inputs, mid_size, power, msm_legs):
         cfg["commit_table_gb"] = msm_legs["table_gb"]
         cfg["commit_blobs_per_launch"] = msm_legs["blobs_per_launch"]
         cfg["proof_quotient_ms"] = msm_legs["proof"]["kernel_ms"].get("quotient")
+        cfg["commit_msm_frac_of_mix_floor"] = msm_legs["commit"].get("msm_frac_of_mix_floor")
+        cfg["proof_quotient_frac_of_mix_floor"] = msm_legs["proof"].get("quotient_frac_of_mix_floor")
         cfg["msm_legs"] = msm_legs
     if roof:
         per = roof.get("per_kernel") or {}
