@@ -367,6 +367,32 @@ def test_device_resident_host_route_crossover(kz, setup_bytes, batch):
         s.free()
 
 
+def test_device_resident_host_route_at_600_blobs_equals_the_device_hash(kz, setup_bytes, batch):
+    """the route at a size that needs its eight chunks in earnest (600 blobs = 75 MiB back over PCIe, 10 batches of 60; host_hash_device_max_blobs = 1024):
+    the records of the host-hashed and of the device-hashed run are the same bytes, and so are the verdicts of the whole call"""
+    import torch
+    blobs, cs, ps = batch
+    g1, g2 = setup_bytes
+    s = kz.KzgSettings.load_trusted_setup_ex([g1[48 * i:48 * i + 48] for i in range(4096)], [g2[96 * i:96 * i + 96] for i in range(65)], host_hash_device_max_blobs=1024)
+    try:
+        npg, groups = 60, 10
+        idx = [(7 * k) % 67 for k in range(npg * groups)]
+        Bl, Cm, Pr = [blobs[i] for i in idx], [cs[i] for i in idx], [ps[i] for i in idx]
+        rc, st, rec_host, (tb, tc, tp) = _device_records(kz, s, Bl, Cm, Pr, npg, groups)
+        assert rc == 0 and st == [0] * groups and s.host_hashed_calls == 1
+        s.set_host_hash(-1)
+        rc, st, rec_dev, _ = _device_records(kz, s, Bl, Cm, Pr, npg, groups)
+        assert rc == 0 and st == [0] * groups and s.host_hashed_calls == 1
+        assert rec_host == rec_dev
+        s.set_host_hash(0)
+        L = kz.kzg.lib()
+        ok = (C.c_bool * groups)(); stg = (C.c_int * groups)()
+        assert L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, tb.data_ptr(), tc.data_ptr(), tp.data_ptr(), npg, groups, s.handle) == 0
+        assert all(ok[i] for i in range(groups)) and s.host_hashed_calls == 2
+    finally:
+        s.free()
+
+
 def test_handle_freed_with_a_ticket_out_is_released_by_the_last_collect(kz, setup_bytes, batch):
     """kzg355_free_trusted_setup with a submitted set not collected used to free what the ticket points into.  The free is deferred
     to the collect of the last ticket; the collect still returns the set's verdicts."""
