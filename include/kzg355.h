@@ -121,7 +121,7 @@ typedef struct kzg355_options {
                                   one, queued behind the NEXT set's Fiat-Shamir kernel                                   KZG355_SUBMIT=sets|pipeline */
     int host_hash_device_max_blobs; /* DEVICE-RESIDENT verify / blob-proof calls (the *_device entry points) of up to this many blobs copy their blobs back
                                   to the host (8 MiB = 0.16 ms per 64) and hash the challenges on the host threads instead of the 3.7 ms device
-                                  chain: 0 = 512, -1 never; host_hash = -1 turns it off as well                          KZG355_HOST_HASH_DEVICE_MAX */
+                                  chain: 0 = 1024 (measured crossover ~1500: profiles/r05/device_host_hash_crossover.txt), -1 never; host_hash = -1 turns it off as well                          KZG355_HOST_HASH_DEVICE_MAX */
 } kzg355_options;
 void kzg355_options_default(kzg355_options *options);
 void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */

@@ -186,8 +186,10 @@ struct kzg355_settings {
     // (17.1 against 18.4 ms), level at 8192
     int host_hash_max = 4096;
     // device-resident verify / blob-proof calls of up to this many blobs copy them BACK and hash on the host threads (0.16 ms of D2H per 64 blobs + ~35 us x
-    // blobs / threads against the 3.7 ms device chain); KZG355_HOST_HASH_DEVICE_MAX, 0 in the options = 512, -1 never
-    int host_hash_device_max = 512;
+    // blobs / threads against the 3.7 ms device chain); KZG355_HOST_HASH_DEVICE_MAX, 0 in the options = 1024, -1 never.  Measured
+    // (profiles/r05/device_host_hash_crossover.txt, ms per call, host route / device hash): 64 blobs 2.0 / 5.6, 512: 3.3 / 6.1, 1024: 4.8 / 6.3, 1536: 6.6 /
+    // 6.5, 2048: 8.3 / 6.9
+    int host_hash_device_max = 1024;
     // batch challenge r of lone small calls hashed on the host (records copied back): 0 by size, -1 never (KZG355_HOST_RHASH=off)
     int host_rhash = 0;
     int host_rhash_loaded = 0;       // ... as the handle was loaded: kzg355_settings_set_host_hash(-1) forces -1, any other mode puts this back

@@ -336,7 +336,7 @@ def test_device_resident_small_calls_take_the_host_route(mode, kz, settings, bat
 
 
 def test_device_resident_host_route_crossover(kz, setup_bytes, batch):
-    """the route is taken up to host_hash_device_max_blobs only (default 512; here 8), and never while submitted sets are in flight"""
+    """the route is taken up to host_hash_device_max_blobs only (default 1024; here 8), and never while submitted sets are in flight"""
     import torch
     blobs, cs, ps = batch
     g1, g2 = setup_bytes
