@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(64) k_quotient_prep(const Fr *z_in, int n, Quo
 // The tree form: 4096 >> LG threads per blob, 2^LG leaves (consecutive positions of the bit-reversed domain: 32 x 2^LG bytes of the blob) per lane,
 // walked in groups of four leaves = one 128-byte line.  Pass 1: inverses down the tree, u_i = p_i / (z - w_i), the inverse parked in q's slot;
 // the blob's two sums; pass 2: q_i = (y - p_i) / (z - w_i).  (quot_core.h)
-template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(const uint8_t *blobs, const QuotPrep *prep, const Fr *roots, Fr *y_out, uint8_t *q_out, int *err) {
+template <int LG> __global__ void __launch_bounds__(4096 >> LG, LG == 4 ? 2 : 1) k_quotient_tree(const uint8_t *blobs, const QuotPrep *prep, const Fr *roots,
+        Fr *y_out, uint8_t *q_out, int *err) {
     constexpr int TPB = 4096 >> LG, NW = TPB / 64, L = LG - 2, D0 = 12 - LG, GROUPS = 1 << L;
     static_assert(LG >= 2 && LG <= 6 && (TPB % 64) == 0, "2^LG leaves per lane, whole waves per blob");
     __shared__ __attribute__((aligned(16))) uint32_t red[NW][2][NFR + 1];
@@ -207,10 +208,13 @@ template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(
         if (L == 0) inv10 = inv0;
         else fr_select(inv10, (g & 1) != 0, c[L > 0 ? L - 1 : 0][0], c[L > 0 ? L - 1 : 0][1]);
         const int a10 = (tid << L) + g;
+        uint4 cur[8];                                             // the group's 128-byte line, requested as one burst at the top of the group's work
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = blob[8 * a10 + k];
         uint32_t pw[4][8];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint4 a = blob[8 * a10 + 2 * j], b = blob[8 * a10 + 2 * j + 1];
+            const uint4 a = cur[2 * j], b = cur[2 * j + 1];
             pw[j][7] = bswap32(a.x); pw[j][6] = bswap32(a.y); pw[j][5] = bswap32(a.z); pw[j][4] = bswap32(a.w);
             pw[j][3] = bswap32(b.x); pw[j][2] = bswap32(b.y); pw[j][1] = bswap32(b.z); pw[j][0] = bswap32(b.w);
         }
@@ -272,9 +276,12 @@ template <int LG> __global__ void __launch_bounds__(4096 >> LG) k_quotient_tree(
 #pragma unroll 1
     for (int g = 0; g < GROUPS; g++) {
         const int a10 = (tid << L) + g;
+        uint4 cb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cb[k] = blob[8 * a10 + k];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint4 a = blob[8 * a10 + 2 * j], b = blob[8 * a10 + 2 * j + 1];
+            const uint4 a = cb[2 * j], b = cb[2 * j + 1];
             const uint4 ia = q[8 * a10 + 2 * j], ib = q[8 * a10 + 2 * j + 1];
             uint32_t pw[8], iw[8], qw[8];
             pw[7] = bswap32(a.x); pw[6] = bswap32(a.y); pw[5] = bswap32(a.z); pw[4] = bswap32(a.w);
@@ -319,7 +326,8 @@ void launch_status_words(const int *d_err, const int *d_ok, int32_t *d_words, in
 size_t quotient_scratch_bytes(int n) { return sizeof(QuotPrep) * (size_t)n + sizeof(int) * ((size_t)n + 4); }
 // d_q: n x 131,072 bytes -- the quotient of every blob in the BLOB format (4096 canonical 32-byte big-endian integers), 16-byte aligned;
 // d_scratch: quotient_scratch_bytes(n).  form: 0 by size, 2 / 4 / 6 = 2^form leaves per lane
-int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q, void *d_scratch, int *d_err, hipStream_t st, int form) {
+int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q, void *d_scratch, int *d_err, hipStream_t st,
+        int form) {
     if (n <= 0) return 0;
     QuotPrep *prep = reinterpret_cast<QuotPrep *>(d_scratch);
     int *count = reinterpret_cast<int *>(prep + n), *list = count + 4;
