@@ -1,45 +1,58 @@
 // eval_core.h -- the arithmetic core of k_eval (k_verify.hip): evaluation of a blob polynomial given by its 4096 values at
-// the bit-reversed roots of unity (reference src/kzg.rs:346-389) as a radix-4 tree over the domain.  Host + device: the same
-// source is driven lane by lane on the device and serially by tests/native/hd_probe.cpp.
+// the bit-reversed roots of unity (reference src/kzg.rs:346-389) as a binary tree over the domain with no inversion and no special case.
+// Host + device: the same source is driven lane by lane on the device and serially by tests/native/hd_probe.cpp.
 //
-//   y = (1/N) sum_i p_i w_i prod_{j != i} (z - w_j)          (no inversion: prod_j (z - w_j) = z^N - 1)
+// With w / (z - w) = z / (z - w) - 1 and prod_j (z - w_j) = z^N - 1 the reference's formula becomes
+//     y = (z^N - 1) / N * sum_i p_i w_i / (z - w_i) = ( z * Ntop - (z^N - 1) * sum_i p_i ) / N,     Ntop = sum_i p_i prod_{j != i} (z - w_j)
+// a polynomial identity in z: for z = w_m the second term vanishes and Ntop = p_m N / w_m, so y = p_m -- what the reference's branch
+// kzg.rs:360-362 returns; nothing is ever divided.  Ntop is the numerator of sum_i p_i / (z - w_i) over the common denominator, built up
+// the tree of quot_core.h: in bit-reversal order the first 2^d roots are the 2^d-th roots of unity, node (d, a), a < 2^d, owns the
+// factor z^(N / 2^d) - roots[a], and its children's factors are z^k -+ s with s = roots[2a], k = N / 2^(d+1).  The fractions
+// n0 / (z^k - s) + n1 / (z^k + s) of the two children add up to
+//     n = n0 (z^k + s) + n1 (z^k - s) = z^k (n0 + n1) + s (n0 - n1)
+// over the node's factor: TWO limb products that share ONE Montgomery reduction (mont_mul2_lazy), z^k a per-blob value (uniform over the
+// wave that owns the blob), s a constant of the tree.  4095 nodes per blob: 2 x 4095 limb-product passes + 4095 reductions, against
+// 5 + 5 per four values (6825 of each per blob) in the radix-4 Horner form of rounds 3-5, and a third of its additions.
+// The leaves are the values themselves (plain integers), sum_i p_i rides along as a carry-swept sum per lane.
 //
-// In bit-reversal order positions 4k..4k+3 hold  w, -w, iw, -iw  (w = w_{4k}, i = w^(N/4)): the four roots of x^4 = rho,
-// rho = w^4.  For such a group
-//     D = prod_j (z - w_j) = z^4 - rho
-//     N = sum_j p_j w_j prod_{l != j} (z - w_l) = sum_j p_j w_j (z^3 + w_j z^2 + w_j^2 z + w_j^3)
-//       = rho ( F_0 + t F_3 + t^2 F_2 + t^3 F_1 ),     t = z / w,   F_m = sum_j p_j c_j^m,  c = (1, -1, i, -i)
-// (a 4-point DFT of the values: one product by i).  Write N = rho h.  Round 3, second form: the same step repeats one level up.
-// Four neighbouring groups 4m..4m+3 have rho_k = rho' c_k (again the four roots of X^4 = rho'^4, now in X = z^4), and the sum of
-// their fractions N_k / D_k over the common denominator prod_k (Z - rho_k) = Z^4 - rho'^4, Z = z^4, has the numerator
-//     sum_k rho_k h_k prod_{l != k} (Z - rho_l) = sum_k h_k (rho_k Z^3 + rho_k^2 Z^2 + rho_k^3 Z + rho_k^4)
-//       = rho'^4 ( G_0 + T G_3 + T^2 G_2 + T^3 G_1 ),   T = Z / rho',   G_m = sum_k h_k c_k^m
-// -- the SAME node function applied to the four h of the level below, with z^4 for z.  Six levels take 4096 values to one h, the
-// last "rho" is w_0^4096 = 1 and the last denominator is z^4096 - 1 = prod_j (z - w_j): y = h_top / N.  No denominator is ever
-// formed.  A node costs five products (i D', T, three Horner steps) for four children: 1365 nodes x 5 = 6825 products per blob,
-// against 7.5 per group + the merge of the lanes' pairs (~7900) for the running (P, S, H) fold this replaces, 14 per group for
-// the value-at-a-time form, and ~3 x 4096 + a 4096-long batch inversion in the reference.  z inside the domain needs no special
-// case: all of this is polynomial identity (for z = w_m the reference's branch kzg.rs:360-362 returns p_m, and so does this).
+// The device deals the tree in groups of three nodes: a group takes four neighbouring children (128 bytes of the blob at level 1) to
+// their grandparent, so six levels of groups -- 1024, 256, 64, 16, 4, 1 groups -- cover the twelve levels of nodes.  Level l uses
+// z^(4^(l-1)) for its two lower nodes and its square for the upper one, and three roots per group (EvalGroup; one flat table).
 //
-// Domains: T and i are Montgomery residues; the values enter as plain integers, so every h and y are plain.
-// All products are lazy (mont_mul_lazy: result < r (1 + a b / (70.7 r^2)), not reduced below r) and the sums are plain limb
-// additions, so a node's output is about four times its inputs' bound: in units of r, with inputs < c,
-//     A, B < 2c;  C, D' = a - b + KC r < c + KC;  i D' < 1 + (c + KC)/70.7;  F_0 < 4c;  F_2 = A - B + KF2 r < 2c + KF2;
-//     F_1 < c + KC + 2.3;  F_3 = C - i D' + 3 r < c + KC + 3;   h = ((F_1 T + F_2) T + F_3) T + F_0 < 4c + 1.1 + F-terms / 70
-// KC >= c and KF2 >= 2c keep the differences positive.  Levels 1-3 (in a lane / across lanes through LDS): c = 1 -> 5.2 -> 22.1 ->
-// 90.1; one lazy product by R (Montgomery one) brings that back to < 2.3, then levels 4-6: 2.3 -> 10.4 -> 42.9 -> 174, and the
-// product by 1/N and one canonical product finish.  The top limb holds the excess: 175 r < 2^262.4, top limb < 2^30.4; column
-// sums of the products stay below 2^64 (9 x 2^59.4 + 9 x 2^58).
+// Domains: z^k and the roots are Montgomery residues; the values enter as plain integers, so every n and y are plain.
+// Bounds in units of r (lazy products: result < 1 + (a b + c d) / 70.6): leaves < 2.21 (any 256-bit value -- a non-canonical one is flagged
+// by the caller, the arithmetic stays in range); a node with children < c: A = n0 + n1 < 2c (limbs < 2^30, no carries), B = n0 - n1 + K r
+// < c + K (K = 3 at the leaves, 2 above; carry-free, limbs < 3 * 2^29), z^k, s < 1: n < 1 + (3c + K) / 70.6 = 1.14 from the leaves and
+// 1.08 from then on, at every level.  Column sums of the two products: nine rounds of 2^30 2^29 + 3 * 2^29 2^29 + 2^29 2^29 = 27 * 2^59 <
+// 2^63.8.  sum p: a lane's 64 values add up to < 142 r (top limb < 2^30.1); one lazy product by R mod r brings that below 3.1 before the
+// sixty-four lanes are added (< 200 r), and the last two-product step takes z Ntop + (1 - z^N) sum p < 201 r^2 to < 3.9 r; the product
+// by 1 / N is canonical.
 #pragma once
 #include "field.h"
 
 namespace kzg {
 
-// inverse "roots" of the tree's nodes, one flat table: level l (1..5) node j holds  w_(4^l j) ^ -(4^(l-1))  (Montgomery), w_idx the
-// domain in bit-reversal order; level 6 is the single node with rho' = 1.
-constexpr int EVAL_ZPOWERS = 5;        // z^4, z^16, z^64, z^256, z^1024: the z of levels 2..6, squared up once per blob by the challenge kernel
+// the three roots of a group: level l (1..6), group m (< 4^(6-l)) joins the nodes 4m .. 4m+3 of depth 14 - 2l: sa = roots[4m] and sb = roots[4m + 2]
+// for the two lower nodes, st = roots[2m] for the upper one (roots: the domain in bit-reversal order, Montgomery).  One flat table, level after level.
+struct EvalGroup { Fr sa, sb, st; };
+constexpr int EVAL_ZPOWERS = 12;       // z^2, z^4, ..., z^4096 (entry k - 1 holds z^(2^k)): squared up once per blob by the challenge kernel
 constexpr int EVAL_WAVES = 4;          // blobs (waves) per workgroup of k_eval: the last three levels of the four trees run together on wave 0
-constexpr int EVAL_TAB_L1 = 0, EVAL_TAB_L2 = 1024, EVAL_TAB_L3 = 1280, EVAL_TAB_L4 = 1344, EVAL_TAB_L5 = 1360, EVAL_TAB_ENTRIES = 1364;
+constexpr int EVAL_TAB_L1 = 0, EVAL_TAB_L2 = 1024, EVAL_TAB_L3 = 1280, EVAL_TAB_L4 = 1344, EVAL_TAB_L5 = 1360, EVAL_TAB_L6 = 1364, EVAL_TAB_GROUPS = 1365;
+// The device table keeps the 27 limbs of a group as seven 16-byte pieces (the last limb slot is padding) with the pieces of 64 consecutive groups side by
+// side: piece q of group e at (e / 64) * 7 * 64 + q * 64 + (e % 64), so that the 64 lanes of a wave that take 64 consecutive groups read 1 KiB per load.
+struct EvalPiece { uint32_t w[4]; };
+constexpr int EVAL_TAB_PIECES = ((EVAL_TAB_GROUPS + 63) / 64) * 7 * 64;
+KZG_HD constexpr int eval_tab_piece(int e, int q) { return (e / 64) * 7 * 64 + q * 64 + (e % 64); }
+KZG_HD void eval_group_pack(EvalPiece p[7], const EvalGroup &g) {
+    for (int k = 0; k < 28; k++) p[k / 4].w[k % 4] = k < NFR ? g.sa.l[k] : k < 2 * NFR ? g.sb.l[k - NFR] : k < 3 * NFR ? g.st.l[k - 2 * NFR] : 0u;
+}
+KZG_HD void eval_group_unpack(EvalGroup &g, const EvalPiece p[7]) {
+#pragma unroll
+    for (int k = 0; k < 27; k++) (k < NFR ? g.sa.l[k] : k < 2 * NFR ? g.sb.l[k - NFR] : g.st.l[k - 2 * NFR]) = p[k / 4].w[k % 4];
+}
+KZG_HD constexpr int eval_tab_first(int level) {
+    return level == 1 ? EVAL_TAB_L1 : level == 2 ? EVAL_TAB_L2 : level == 3 ? EVAL_TAB_L3 : level == 4 ? EVAL_TAB_L4 : level == 5 ? EVAL_TAB_L5 : EVAL_TAB_L6;
+}
 
 // K r as normalised limbs (the top limb keeps the excess), at compile time
 template <int K> struct FrMultiple {
@@ -93,47 +106,44 @@ KZG_HD void fr_add_sweep(Fr &r, const Fr &a, const Fr &b) {
     }
 }
 
-// One node of the tree: four children (plain lazy values < KC r with normalised limbs, in bit-reversal order: roots w, -w, iw, -iw of
-// the node's X^4 = w^4), T = (z^(4^(l-1))) / w and imag = w^(N/4), both Montgomery and normalised.  h = F_0 + T F_3 + T^2 F_2 + T^3 F_1,
-// normalised.  Sums that only feed a product (A, B, D', F_1, the Horner partial sums) or the final sweep (F_0) are carry-free.
-template <int KC, int KF2> KZG_HD void eval_node4(Fr &h, const Fr &c0, const Fr &c1, const Fr &c2, const Fr &c3, const Fr &T, const Fr &imag) {
-    Fr A, B, C, Dd, iD, F0, F1, F2, F3;
-    fr_add_raw(A, c0, c1); fr_add_raw(B, c2, c3);                             // limbs < 2^30
-    fr_sub_bias<KC>(C, c0, c1);                                               // normalised: it enters F_3's normalising difference
-    fr_sub_bias_raw<KC>(Dd, c2, c3);                                          // limbs < 3 * 2^29
-    fr_mul_lazy(iD, Dd, imag);
-    fr_add_raw(F0, A, B);                                                     // limbs < 2^31
-    fr_sub_bias<KF2>(F2, A, B);                                               // normalised (int32 range: |A_i - B_i| < 2^30)
-    fr_add_raw(F1, C, iD);                                                    // limbs < 2^30
-    fr_sub_bias<3>(F3, C, iD);
-    fr_mul_lazy(h, F1, T); fr_add_raw(h, h, F2);
-    fr_mul_lazy(h, h, T); fr_add_raw(h, h, F3);
-    fr_mul_lazy(h, h, T); fr_add_sweep(h, h, F0);
+// One node: n = z^k (n0 + n1) + s (n0 - n1), children < K r with normalised limbs (header comment)
+template <int K> KZG_HD void eval_node2(Fr &n, const Fr &n0, const Fr &n1, const Fr &zk, const Fr &s) {
+    Fr A, B;
+    fr_add_raw(A, n0, n1);
+    fr_sub_bias_raw<K>(B, n0, n1);
+    fr_mul2_lazy(n, A, zk, B, s);
 }
-// The six levels with the bias constants their input bounds call for (header comment).  Level 1 takes the blob's values: < r when
-// the blob is valid, anything below 2^256 = 2.21 r otherwise (flagged by the caller; KC = 3 keeps even those differences positive).
-KZG_HD void eval_level1(Fr &h, const uint32_t pw[4][8], const Fr &T, const Fr &imag) {
-    Fr p0, p1, p2, p3;
+// A group above the leaves: four children to their grandparent.  zk = z^k of the two lower nodes, zk2 its square.
+KZG_HD void eval_group(Fr &n, const Fr c[4], const Fr &zk, const Fr &zk2, const EvalGroup &g) {
+    Fr na, nb;
+    eval_node2<2>(na, c[0], c[1], zk, g.sa);
+    eval_node2<2>(nb, c[2], c[3], zk, g.sb);
+    eval_node2<2>(n, na, nb, zk2, g.st);
+}
+// A group of four values (8 little-endian words each): the same with K = 3, and Sp += their sum (carries swept: Sp's limbs stay below 2^29,
+// its top limb keeps the excess)
+KZG_HD void eval_group_leaves(Fr &n, Fr &Sp, const uint32_t pw[4][8], const Fr &z, const Fr &z2, const EvalGroup &g) {
+    Fr p0, p1, p2, p3, A, B, na, nb, S;
     words_to_limbs<NFR, 8>(p0.l, pw[0]); words_to_limbs<NFR, 8>(p1.l, pw[1]);
     words_to_limbs<NFR, 8>(p2.l, pw[2]); words_to_limbs<NFR, 8>(p3.l, pw[3]);
-    eval_node4<3, 5>(h, p0, p1, p2, p3, T, imag);                              // < 5.2 r
+    fr_add_raw(A, p0, p1); fr_sub_bias_raw<3>(B, p0, p1);
+    fr_mul2_lazy(na, A, z, B, g.sa);
+    fr_add_raw(S, p2, p3); fr_sub_bias_raw<3>(B, p2, p3);
+    fr_mul2_lazy(nb, S, z, B, g.sb);
+    fr_add_raw(S, S, A);                                                       // limbs < 2^31
+    fr_add_sweep(Sp, Sp, S);
+    eval_node2<2>(n, na, nb, z2, g.st);
 }
-KZG_HD void eval_level2(Fr &h, const Fr c[4], const Fr &T, const Fr &imag) { eval_node4<6, 11>(h, c[0], c[1], c[2], c[3], T, imag); }     // < 22.1 r
-// level 3 ends with the lazy product by R that brings the bound back down: < 90.1 r -> < 2.3 r
-KZG_HD void eval_level3(Fr &h, const Fr c[4], const Fr &T, const Fr &imag) {
-    Fr t; eval_node4<23, 45>(t, c[0], c[1], c[2], c[3], T, imag);
-    fr_mul_lazy(h, t, fr_one());
-}
-KZG_HD void eval_level4(Fr &h, const Fr c[4], const Fr &T, const Fr &imag) { eval_node4<3, 5>(h, c[0], c[1], c[2], c[3], T, imag); }       // < 10.4 r
-KZG_HD void eval_level5(Fr &h, const Fr c[4], const Fr &T, const Fr &imag) { eval_node4<11, 21>(h, c[0], c[1], c[2], c[3], T, imag); }     // < 42.9 r
-// level 6: T = z^1024 (rho' = 1); y = h / 4096 as the canonical plain integer
-KZG_HD void eval_level6(Fr &y, const Fr c[4], const Fr &z1024, const Fr &imag) {
+// a lane's sum of values back below 3.1 r (its value mod r unchanged): the lazy product by R mod r
+KZG_HD void eval_fold(Fr &s) { Fr t; fr_mul_lazy(t, s, fr_one()); s = t; }
+// y = (z Ntop - (z^N - 1) Sp) / N as the canonical plain integer; Sp the blob's folded sum (< 200 r), zN = z^4096 (canonical)
+KZG_HD void eval_finish(Fr &y, const Fr &ntop, const Fr &Sp, const Fr &z, const Fr &zN) {
     const uint32_t inv4096[NFR] = FR_INV4096_INIT;
     Fr k4096; for (int i = 0; i < NFR; i++) k4096.l[i] = inv4096[i];
-    Fr h, t;
-    eval_node4<44, 87>(h, c[0], c[1], c[2], c[3], z1024, imag);                // < 174 r
-    fr_mul_lazy(t, h, k4096);                                                  // < 3.5 r, plain
-    fr_mul(y, t, fr_one());                                                    // canonical: the chain of lazy products ends here
+    Fr negD, t;
+    fr_sub(negD, fr_one(), zN);                                                // 1 - z^N mod r, canonical
+    fr_mul2_lazy(t, ntop, z, Sp, negD);                                        // < 3.9 r, plain
+    fr_mul(y, t, k4096);                                                       // canonical: the chain of lazy products ends here
 }
 
 }  // namespace kzg

@@ -72,16 +72,15 @@ __global__ void __launch_bounds__(256) k_setup_roots(Fr *roots) {
     roots[brp12((uint32_t)i)] = acc;
 }
 
-// k_eval's radix-4 tree (eval_core.h): level l = 1..5, node j -> w_(4^l j) ^ -(4^(l-1)), one flat table of EVAL_TAB_ENTRIES.
-__global__ void __launch_bounds__(256) k_setup_eval_tab(const Fr *roots, Fr *tab) {
+// k_eval's tree (eval_core.h): level l = 1..6, group m -> the roots of its three nodes, one flat table of EVAL_TAB_GROUPS.
+__global__ void __launch_bounds__(256) k_setup_eval_tab(const Fr *roots, EvalPiece *tab) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= EVAL_TAB_ENTRIES) return;
-    const int level = e < EVAL_TAB_L2 ? 1 : e < EVAL_TAB_L3 ? 2 : e < EVAL_TAB_L4 ? 3 : e < EVAL_TAB_L5 ? 4 : 5;
-    const int first = level == 1 ? EVAL_TAB_L1 : level == 2 ? EVAL_TAB_L2 : level == 3 ? EVAL_TAB_L3 : level == 4 ? EVAL_TAB_L4 : EVAL_TAB_L5;
-    const int j = e - first;
-    Fr v; fr_inv(v, roots[j << (2 * level)]);
-    for (int s = 0; s < 2 * (level - 1); s++) fr_sqr(v, v);
-    tab[e] = v;
+    if (e >= EVAL_TAB_GROUPS) return;
+    const int level = e < EVAL_TAB_L2 ? 1 : e < EVAL_TAB_L3 ? 2 : e < EVAL_TAB_L4 ? 3 : e < EVAL_TAB_L5 ? 4 : e < EVAL_TAB_L6 ? 5 : 6;
+    const int m = e - eval_tab_first(level);
+    EvalPiece p[7];
+    eval_group_pack(p, EvalGroup{roots[4 * m], roots[4 * m + 2], roots[2 * m]});
+    for (int q = 0; q < 7; q++) tab[eval_tab_piece(e, q)] = p[q];
 }
 
 // Fixed-base precomputation: table[w][i] = 2^(8w) * g1_values[i] in affine form, w = 1..31 (window 0 is g1_values).
@@ -108,7 +107,7 @@ int launch_setup(const uint8_t *d_g1_bytes, const uint8_t *d_g2_bytes, DeviceTab
     hipLaunchKernelGGL(k_setup_lagrange_check, dim3(1), dim3(64), 0, st, t.g1_first2, t.lines, t.lines_inf, d_err);
     if (mainnet) {
         hipLaunchKernelGGL(k_setup_roots, dim3(N_FE / 256), dim3(256), 0, st, t.roots);
-        hipLaunchKernelGGL(k_setup_eval_tab, dim3((EVAL_TAB_ENTRIES + 255) / 256), dim3(256), 0, st, t.roots, t.eval_tab);
+        hipLaunchKernelGGL(k_setup_eval_tab, dim3((EVAL_TAB_GROUPS + 255) / 256), dim3(256), 0, st, t.roots, t.eval_tab);
         hipLaunchKernelGGL(k_setup_msm_table, dim3(N_FE / 64), dim3(64), 0, st, t.msm_table);
     }
     const hipError_t e = hipStreamSynchronize(st);

@@ -82,10 +82,10 @@ __device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, co
     const uint32_t dw[8] = {hh[7], hh[6], hh[5], hh[4], hh[3], hh[2], hh[1], hh[0]};
     Fr z; fr_from_words(z, dw);
     z_out[i] = z;
-    if (zpow_out) {                                   // z^4, z^16, z^64, z^256, z^1024 for the levels of k_eval's tree: ten squarings on the lane that
-        Fr p = z;                                     // has z anyway, instead of ten on every wave of the evaluation
+    if (zpow_out) {                                   // z^2, z^4, ..., z^4096 for the levels of k_eval's tree: twelve squarings on the lane that
+        Fr p = z;                                     // has z anyway, instead of twelve on every wave of the evaluation
 #pragma unroll 1
-        for (int k = 0; k < EVAL_ZPOWERS; k++) { fr_sqr(p, p); fr_sqr(p, p); zpow_out[EVAL_ZPOWERS * (size_t)i + k] = p; }
+        for (int k = 0; k < EVAL_ZPOWERS; k++) { fr_sqr(p, p); zpow_out[EVAL_ZPOWERS * (size_t)i + k] = p; }
     }
     if (!records) return;
     uint8_t *rec = records + (size_t)RECORD_BYTES * i;
@@ -225,16 +225,15 @@ __global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *dig
 // ------------------------------------------------------------------------------------------------ evaluation
 // y = p(z) for a polynomial given by its 4096 evaluations at the (bit-reversed) roots of unity (kzg.rs:346-389).
 // The reference evaluates  y = (z^N - 1)/N * sum_i p_i w_i / (z - w_i)  with a 4096-long batch inversion and special-
-// cases z == w_i.  Because  prod_j (z - w_j) = z^N - 1,  the same value is
-//         y = (1/N) * sum_i  p_i w_i * prod_{j != i} (z - w_j)
-// which needs NO inversion and no special case (for z = w_m every term but i = m vanishes and the m-th equals N p_m,
-// which is what kzg.rs:360-362 returns).  The arithmetic is eval_core.h: a radix-4 tree over the domain, five lazy products per
-// node of four children, the same node function at every level with z^(4^(l-1)) for z.
-// One wave per blob.  Step it = 0..15 takes the 64 groups 64 it .. 64 it + 63 (8 KiB of the blob), one level-1 node per lane.
-// The four children of a level-2 node are four NEIGHBOURING lanes of one step, so a lane parks its h in LDS and after every
-// fourth step the 256 parked values are dealt out again, four consecutive ones per lane: 64 level-2 nodes, one per lane.  The same
-// exchange after the loop gives every lane one level-3 node (its four level-2 results go through the same buffer), and levels
-// 4-6 (16, 4, 1 nodes) run replicated across the lanes.  y comes out as the canonical integer with no conversion.
+// cases z == w_i.  eval_core.h turns that into  y = (z Ntop - (z^N - 1) sum_i p_i) / N  with Ntop the numerator of sum_i p_i / (z - w_i)
+// over the common denominator: NO inversion and no special case (a polynomial identity; for z = w_m it gives p_m, which is what
+// kzg.rs:360-362 returns).  Ntop comes up a binary tree over the domain, two limb products and ONE Montgomery reduction per node; the
+// lanes take the nodes three at a time: a group joins four neighbouring children to their grandparent (eval_core.h).
+// One wave per blob.  Step it = 0..15 takes the 64 groups 64 it .. 64 it + 63 (8 KiB of the blob), one level-1 group per lane.
+// The four children of a level-2 group are four NEIGHBOURING lanes of one step, so a lane parks its result in LDS and after every
+// fourth step the 256 parked values are dealt out again, four consecutive ones per lane: 64 level-2 groups, one per lane.  The same
+// exchange after the loop gives every lane one level-3 group (its four level-2 results go through the same buffer), and levels
+// 4-6 (16, 4, 1 groups) run on wave 0 for the workgroup's four blobs.  y comes out as the canonical integer with no conversion.
 // Loads: a lane needs the 128 contiguous bytes of its group, but a load instruction whose lanes are 128 bytes apart touches 64
 // cache lines for 1 KiB.  The wave instead moves its 8 KiB per step with 8 fully coalesced global -> LDS loads
 // (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~2,000 instructions
@@ -251,6 +250,17 @@ __device__ __forceinline__ void eval_issue_tile_loads(const uint4 *blob_step, ui
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(blob_step + 8 * g + (s ^ (g & 7))),
                                          (void __attribute__((address_space(3))) *)(tile + 64 * q), 16, 0, 0);
     }
+}
+// the pieces of group e (eval_core.h: 64 consecutive groups side by side, one 1 KiB row per load for a wave that takes 64 consecutive groups)
+__device__ __forceinline__ void eval_tab_load(EvalPiece p[7], const EvalPiece *tab, int e) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(tab);
+#pragma unroll
+    for (int q = 0; q < 7; q++) { const uint4 v = src[eval_tab_piece(e, q)]; p[q].w[0] = v.x; p[q].w[1] = v.y; p[q].w[2] = v.z; p[q].w[3] = v.w; }
+}
+__device__ __forceinline__ EvalGroup eval_tab_group(const EvalPiece *tab, int e) {
+    EvalPiece p[7]; eval_tab_load(p, tab, e);
+    EvalGroup g; eval_group_unpack(g, p);
+    return g;
 }
 __device__ __forceinline__ void eval_park(uint32_t *hx, int entry, const Fr &h) {
 #pragma unroll
@@ -270,7 +280,7 @@ __device__ __forceinline__ void eval_children(Fr c[4], const uint32_t *hx, int n
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();       // all reads done before the buffer is written again
 }
 // EVAL_WAVES blobs per workgroup, one wave each, with its own tile and exchange buffer; the waves meet once, after level 3.
-__global__ void __launch_bounds__(64 * EVAL_WAVES) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *zpow, const Fr *roots, const Fr *tab, int n_total,
+__global__ void __launch_bounds__(64 * EVAL_WAVES, 2) k_eval(const uint8_t *blobs, const Fr *z_in, const Fr *zpow, const EvalPiece *tab, int n_total,
                                                           int n_per_group, Fr *y_out, uint8_t *records, int *err) {
     __shared__ uint4 tiles[EVAL_WAVES][512];
     __shared__ __attribute__((aligned(16))) uint32_t hxs[EVAL_WAVES][256 * NFR];
@@ -282,13 +292,17 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES) k_eval(const uint8_t *blobs, 
     const uint4 *blob = reinterpret_cast<const uint4 *>(blobs + (size_t)BLOB_BYTES * blob_i);
     eval_issue_tile_loads(blob, tile, lane);
     const Fr z = z_in[blob_i];
-    const Fr imag = roots[2];                                     // position 2 holds w^(N/4)
-    const Fr *zp = zpow + EVAL_ZPOWERS * (size_t)blob_i;          // z^4, z^16, z^64, z^256, z^1024 (k_challenge*)
-    const Fr z4 = zp[0];
-    Fr h2[4];
+    const Fr *zp = zpow + EVAL_ZPOWERS * (size_t)blob_i;          // zp[k - 1] = z^(2^k), k = 1 .. 12 (k_challenge*)
+    const Fr z2 = zp[0];
+    // z^4, z^8 (level 2, after every fourth step) and z^16, z^32 (level 3) wait in LDS: 18 more live registers spilled, and a global load at the
+    // point of use is a full memory latency in front of every level-2 group
+    __shared__ uint32_t zls[EVAL_WAVES][4 * NFR];
+    if (lane < 4 * NFR) zls[wid][lane] = reinterpret_cast<const uint32_t *>(zp + 1)[lane];
+    Fr h2[4], Sp = fr_zero();
     bool bad = false;
     constexpr int STEPS = N_FE / 4 / 64;
-    Fr inv_next = tab[EVAL_TAB_L1 + lane];
+    EvalPiece g_next[7];
+    eval_tab_load(g_next, tab, EVAL_TAB_L1 + lane);
 #pragma unroll 1
     for (int it = 0; it < STEPS; it++) {
         __builtin_amdgcn_s_waitcnt(0);                            // this step's tile (and table entry) have landed
@@ -296,12 +310,13 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES) k_eval(const uint8_t *blobs, 
         uint4 cur[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) cur[j] = tile[8 * lane + (j ^ (lane & 7))];
-        const Fr inv1 = inv_next;
+        EvalGroup g1; eval_group_unpack(g1, g_next);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();   // every lane has its 128 bytes
-        if (it + 1 < STEPS) {                                     // next step's loads fly during this one's products
-            eval_issue_tile_loads(blob + 512 * (it + 1), tile, lane);
-            inv_next = tab[EVAL_TAB_L1 + (it + 1) * 64 + lane];
-        }
+        if (it + 1 < STEPS) eval_issue_tile_loads(blob + 512 * (it + 1), tile, lane);       // next step's loads fly during this one's products
+        // the roots of the NEXT piece of work -- the level-2 group after every fourth step, else the next step's group -- fly during this one's
+        // (unconditional: a load under a branch made the compiler wait for it on the spot to merge the two paths' registers)
+        const int e_l1 = EVAL_TAB_L1 + ((it + 1) & (STEPS - 1)) * 64 + lane, e_l2 = EVAL_TAB_L2 + 64 * (it >> 2) + lane;
+        eval_tab_load(g_next, tab, (it & 3) == 3 ? e_l2 : e_l1);
         uint32_t pw[4][8];
 #pragma unroll
         for (int e = 0; e < 4; e++) {                             // big-endian 32 bytes -> 8 little-endian words
@@ -315,46 +330,59 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES) k_eval(const uint8_t *blobs, 
 #pragma unroll 1
             for (int e = 0; e < 4; e++) bad = bad || !fr_words_canonical(pw[e]);
         }
-        Fr T, h;
-        fr_mul_lazy(T, z, inv1);                                  // z / w_(4g)
-        eval_level1(h, pw, T, imag);
+        Fr h;
+        eval_group_leaves(h, Sp, pw, z, z2, g1);
         eval_park(hx, 64 * (it & 3) + lane, h);                   // group 64 it + lane = entry 64 (it & 3) + lane of this batch of four steps
-        if ((it & 3) == 3) {                                      // level 2: node 64 (it >> 2) + lane = entries 4 lane .. 4 lane + 3
+        if ((it & 3) == 3) {                                      // level 2: group 64 (it >> 2) + lane = entries 4 lane .. 4 lane + 3
             Fr c[4];
             eval_children(c, hx, lane);
-            fr_mul_lazy(T, z4, tab[EVAL_TAB_L2 + 64 * (it >> 2) + lane]);
-            Fr r2; eval_level2(r2, c, T, imag);
+            EvalGroup g2; eval_group_unpack(g2, g_next);
+            eval_tab_load(g_next, tab, it + 1 < STEPS ? e_l1 : EVAL_TAB_L3 + lane);        // the next step's group, or level 3's behind the last step
+            Fr z4, z8;
+#pragma unroll
+            for (int k = 0; k < NFR; k++) { z4.l[k] = zls[wid][k]; z8.l[k] = zls[wid][NFR + k]; }
+            Fr r2; eval_group(r2, c, z4, z8, g2);
 #pragma unroll
             for (int a = 0; a < 4; a++) if ((it >> 2) == a) h2[a] = r2;
         }
     }
     if (bad && blob_raw < n_total) atomicOr(&err[blob_i / n_per_group], ERR_NONCANONICAL_FR);
-    Fr c[4], T, h;
-    // level 3: node n = lane, children the level-2 nodes 4 lane .. 4 lane + 3 (node 64 a + l sits in lane l's h2[a])
+    Fr c[4], h;
+    // level 3: group n = lane, children the level-2 groups 4 lane .. 4 lane + 3 (group 64 a + l sits in lane l's h2[a])
 #pragma unroll
     for (int a = 0; a < 4; a++) eval_park(hx, 64 * a + lane, h2[a]);
     eval_children(c, hx, lane);
-    fr_mul_lazy(T, zp[1], tab[EVAL_TAB_L3 + lane]);
-    eval_level3(h, c, T, imag);
+    EvalGroup g3; eval_group_unpack(g3, g_next);
+    Fr z16, z32;
+#pragma unroll
+    for (int k = 0; k < NFR; k++) { z16.l[k] = zls[wid][2 * NFR + k]; z32.l[k] = zls[wid][3 * NFR + k]; }
+    eval_group(h, c, z16, z32, g3);
+    // the blob's sum of values: every lane's 64 folded below 3.1 r, then added across the wave (< 200 r)
+    eval_fold(Sp);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const Fr o = fr_shfl_down(Sp, off); fr_add_lazy(Sp, Sp, o); }
     // Levels 4, 5, 6 have 16, 4 and 1 nodes per blob: the workgroup's four blobs share ONE wave for them, 16 lanes per blob (a wave
     // on its own would run each of them on all 64 lanes for 16, 4 and 1 distinct results).
     eval_park(hx, lane, h);                                       // this blob's 64 level-3 results: entries 0..63 of its own buffer
+    if (lane == 0) eval_park(hx, 64, Sp);                         // and its sum of values: entry 64
     __syncthreads();
     if (wid != 0) return;
     const int b = lane >> 4, u = lane & 15;                       // blob b of the workgroup, level-4 node u
     const int mine_raw = blockIdx.x * EVAL_WAVES + b, mine = mine_raw < n_total ? mine_raw : n_total - 1;
     const Fr *zq = zpow + EVAL_ZPOWERS * (size_t)mine;
+    Fr Sb;
+#pragma unroll
+    for (int k = 0; k < NFR; k++) Sb.l[k] = hxs[b][NFR * 64 + k];
     eval_children(c, hxs[b], u);
-    fr_mul_lazy(T, zq[2], tab[EVAL_TAB_L4 + u]);
-    eval_level4(h, c, T, imag);
+    eval_group(h, c, zq[5], zq[6], eval_tab_group(tab, EVAL_TAB_L4 + u));
     uint32_t *hx0 = hxs[0];                                       // from here on wave 0's buffer, read only by wave 0: entry 16 b + u, then 4 b + v
     eval_park(hx0, lane, h);
     eval_children(c, hx0, 4 * b + (lane & 3));
-    fr_mul_lazy(T, zq[3], tab[EVAL_TAB_L5 + (lane & 3)]);
-    eval_level5(h, c, T, imag);
+    eval_group(h, c, zq[7], zq[8], eval_tab_group(tab, EVAL_TAB_L5 + (lane & 3)));
     if (u < 4) eval_park(hx0, 4 * b + u, h);
     eval_children(c, hx0, b);
-    Fr y; eval_level6(y, c, zq[4], imag);                         // canonical integer value of y
+    eval_group(h, c, zq[9], zq[10], eval_tab_group(tab, EVAL_TAB_L6));
+    Fr y; eval_finish(y, h, Sb, z_in[mine], zq[11]);              // canonical integer value of y
     if (u == 0 && mine_raw < n_total) {
         if (records) {
             uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
@@ -590,7 +618,7 @@ void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_c
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, const Fr *d_zpow, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_eval, dim3((n_total + EVAL_WAVES - 1) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, st, d_blobs, d_z, d_zpow, t.roots, t.eval_tab, n_total, n_per_group,
+    hipLaunchKernelGGL(k_eval, dim3((n_total + EVAL_WAVES - 1) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, st, d_blobs, d_z, d_zpow, t.eval_tab, n_total, n_per_group,
                        d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,

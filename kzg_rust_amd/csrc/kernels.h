@@ -53,7 +53,7 @@ struct alignas(128) WideRow { Fp x, y; uint32_t pad[4]; };       // one affine p
 struct DeviceTables {
     int n_fe;                // FIELD_ELEMENTS_PER_BLOB of this handle: 4096 (mainnet) or a small power of two (minimal preset: 4)
     Fr *roots;               // [4096] bit-reversal order, Montgomery (kzg.rs:34)
-    Fr *eval_tab;            // [EVAL_TAB_ENTRIES] inverse node roots of k_eval's radix-4 tree, levels 1..5 (eval_core.h)
+    EvalPiece *eval_tab;     // [EVAL_TAB_PIECES] the node roots of k_eval's tree, three per group, levels 1..6, in 16-byte pieces (eval_core.h)
     WideShape wide;          // shape of wide_table
     WideRow *wide_table;        // [22][4096][2048] multiples m * 2^(12w) * g1_values[i], 23.6 GB; null: 8-bit bucket form only
     G1Affine *msm_table;     // [32][4096]: window w holds 2^(8w) * g1_values[i]; window 0 IS g1_values (kzg.rs:37)
@@ -82,7 +82,7 @@ void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_pro
                               int stride = 48);
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only = 0);
 void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
-// d_zpow (may be null): EVAL_ZPOWERS values per blob, z^4, z^16, .. z^1024 (Montgomery) -- what launch_eval needs beside z
+// d_zpow (may be null): EVAL_ZPOWERS values per blob, z^2, z^4, .. z^4096 (Montgomery) -- what launch_eval needs beside z
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, Fr *d_zpow, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
 // the same records / z from digests hashed on the host (32 bytes per blob, host_sha256.h)

@@ -40,7 +40,7 @@ int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, 
     auto fail = [&](int code) { g1b.release(); g2b.release(); err.release(); kzg355_free_trusted_setup(s); return code; };
     s->t.n_fe = (int)n1;
     if ((rc = s->roots.ensure(sizeof(Fr) * n1))) return fail(rc);
-    if (!small && (rc = s->eval_tab.ensure(sizeof(Fr) * EVAL_TAB_ENTRIES))) return fail(rc);
+    if (!small && (rc = s->eval_tab.ensure(sizeof(EvalPiece) * EVAL_TAB_PIECES))) return fail(rc);
     if ((rc = s->msm_table.ensure(sizeof(G1Affine) * n1 * (small ? 1 : MSM_WINDOWS)))) return fail(rc);
     if ((rc = s->lines.ensure(sizeof(LineCoeff) * 3 * N_LINES))) return fail(rc);
     if ((rc = s->lines_inf.ensure(sizeof(int) * 3))) return fail(rc);
@@ -51,7 +51,7 @@ int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, 
     if ((rc = g2b.ensure(96 * n2))) return fail(rc);
     if ((rc = err.ensure(sizeof(int)))) return fail(rc);
     s->t.roots = s->roots.as<Fr>();
-    s->t.eval_tab = s->eval_tab.as<Fr>();
+    s->t.eval_tab = s->eval_tab.as<EvalPiece>();
     s->t.msm_table = s->msm_table.as<G1Affine>();
     s->t.lines = s->lines.as<LineCoeff>();
     s->t.lines_inf = s->lines_inf.as<int>();

@@ -50,11 +50,12 @@ int hd_fr_mul2(uint8_t *out, const uint8_t *a, const uint8_t *b, const uint8_t *
     fr_mul(r, l, fr_one());                     // ... and the canonical product that ends the chain
     fr_to_be32(out, r); return 0;
 }
-// y = p(z) through eval_core.h's radix-4 tree, level by level over arrays (the device deals the same nodes to the lanes of a wave and
-// moves the children through LDS; the node arithmetic and its lazy bounds are this code).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
+// y = p(z) through eval_core.h's binary tree, level of groups by level of groups over arrays (the device deals the same groups to the lanes of a
+// wave and moves the children through LDS; the node arithmetic and its lazy bounds are this code; the sum of the values is folded per "lane" of 64
+// values as on the device).  blob: 4096 x 32 big-endian bytes, z: 32 bytes.
 int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
     constexpr int N_FE = 4096;
-    static Fr roots[N_FE]; static Fr tab[EVAL_TAB_ENTRIES]; static bool ready = false;
+    static Fr roots[N_FE]; static EvalGroup tab[EVAL_TAB_GROUPS]; static bool ready = false;
     if (!ready) {
         const uint32_t rootc[NFR] = FR_ROOT4096_INIT;
         Fr base; for (int k = 0; k < NFR; k++) base.l[k] = rootc[k];
@@ -63,33 +64,26 @@ int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
             uint32_t rev = 0; for (int b = 0; b < 12; b++) rev |= ((i >> b) & 1u) << (11 - b);
             roots[rev] = acc; fr_mul(acc, acc, base);
         }
-        const int first[6] = {0, EVAL_TAB_L1, EVAL_TAB_L2, EVAL_TAB_L3, EVAL_TAB_L4, EVAL_TAB_L5};
-        for (int level = 1; level <= 5; level++)
-            for (int j = 0; j < (N_FE >> (2 * level)); j++) {
-                Fr v; fr_inv(v, roots[j << (2 * level)]);
-                for (int q = 0; q < 2 * (level - 1); q++) fr_sqr(v, v);
-                tab[first[level] + j] = v;
-            }
+        for (int level = 1; level <= 6; level++)
+            for (int m = 0; m < (N_FE >> (2 * level)); m++) tab[eval_tab_first(level) + m] = EvalGroup{roots[4 * m], roots[4 * m + 2], roots[2 * m]};
         ready = true;
     }
     uint32_t w[8]; be32_to_words(w, z_be);
-    Fr z, zp[6]; fr_from_words(z, w);
-    zp[0] = z;
-    for (int l = 1; l < 6; l++) { fr_sqr(zp[l], zp[l - 1]); fr_sqr(zp[l], zp[l]); }      // z^(4^l)
-    const Fr imag = roots[2];
-    static Fr h1[1024], h2[256], h3[64], h4[16], h5[4];
-    Fr T;
+    Fr zp[13]; fr_from_words(zp[0], w);
+    for (int k = 1; k <= 12; k++) fr_sqr(zp[k], zp[k - 1]);                               // z^(2^k)
+    static Fr h[6][1024];
+    Fr lane_sum[64], Sp = fr_zero();
+    for (int l = 0; l < 64; l++) lane_sum[l] = fr_zero();
     for (int g = 0; g < 1024; g++) {
         uint32_t pw[4][8];
         for (int e = 0; e < 4; e++) { be32_to_words(pw[e], blob + 32 * (4 * g + e)); if (!fr_words_canonical(pw[e])) return 1; }
-        fr_mul_lazy(T, zp[0], tab[EVAL_TAB_L1 + g]);
-        eval_level1(h1[g], pw, T, imag);
+        eval_group_leaves(h[0][g], lane_sum[g & 63], pw, zp[0], zp[1], tab[EVAL_TAB_L1 + g]);      // lane g & 63 takes group g in step g >> 6
     }
-    for (int m = 0; m < 256; m++) { fr_mul_lazy(T, zp[1], tab[EVAL_TAB_L2 + m]); eval_level2(h2[m], h1 + 4 * m, T, imag); }
-    for (int n = 0; n < 64; n++) { fr_mul_lazy(T, zp[2], tab[EVAL_TAB_L3 + n]); eval_level3(h3[n], h2 + 4 * n, T, imag); }
-    for (int u = 0; u < 16; u++) { fr_mul_lazy(T, zp[3], tab[EVAL_TAB_L4 + u]); eval_level4(h4[u], h3 + 4 * u, T, imag); }
-    for (int v = 0; v < 4; v++) { fr_mul_lazy(T, zp[4], tab[EVAL_TAB_L5 + v]); eval_level5(h5[v], h4 + 4 * v, T, imag); }
-    Fr y; eval_level6(y, h5, zp[5], imag);
+    for (int l = 0; l < 64; l++) { eval_fold(lane_sum[l]); fr_add_lazy(Sp, Sp, lane_sum[l]); }
+    for (int level = 2; level <= 6; level++)
+        for (int m = 0; m < (N_FE >> (2 * level)); m++)
+            eval_group(h[level - 1][m], h[level - 2] + 4 * m, zp[2 * level - 2], zp[2 * level - 1], tab[eval_tab_first(level) + m]);
+    Fr y; eval_finish(y, h[5][0], Sp, zp[0], zp[12]);
     limbs_to_words<NFR, 8>(w, y.l);
     for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8; out32[4 * i + 3] = v; }
     return 0;
