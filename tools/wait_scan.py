@@ -10,10 +10,11 @@ def main():
     txt = open(sys.argv[1]).read()
     want = sys.argv[2] if len(sys.argv) > 2 else ""
     near = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", txt, flags=re.S | re.M):
-        name, body = m.group(1), m.group(2).split("\n")
-        if want not in name:
+    parts = re.split(r"^(_Z\w+):[^\n]*\n", txt, flags=re.M)          # [preamble, name, body, name, body, ...]; functions called by kernels have labels too
+    for name, text in zip(parts[1::2], parts[2::2]):
+        if want not in name or "s_endpgm" not in text:
             continue
+        body = text[:text.index("s_endpgm")].split("\n")
         insts = [l.strip() for l in body if l.strip() and not l.strip().startswith((";", ".")) or re.match(r"^\.LBB", l.strip())]
         loads = []                                   # instruction index of every outstanding-counter load, in issue order
         hits = []
