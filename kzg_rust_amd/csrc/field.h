@@ -312,7 +312,8 @@ KZG_HD void fp_mul_lz(Fp &r, const Fp &a, const Fp &b) { KZG_FP_CONSTS mont_mul_
 KZG_HD void fp_sqr_lz(Fp &r, const Fp &a) { KZG_FP_CONSTS mont_sqr<NFP, true>(r.l, a.l, FP_MOD, FP_INVW); }
 // r = (a b + c d) / R, lazily, ONE Montgomery reduction for the two products (588 limb products instead of 784).  Operands normalised lazy values
 // with a b + c d < 2^12 p^2 (e.g. a < 6p, b < 10p, c < 4p, d < 2p in the point additions); result < p (1 + 2^-13).
-KZG_HD void fp_mul2_lz(Fp &r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) { KZG_FP_CONSTS mont_mul2_lazy<NFP>(r.l, a.l, b.l, c.l, d.l, FP_MOD, FP_INVW); }
+KZG_HD void fp_mul2_lz(Fp &r, const Fp &a, const Fp &b, const Fp &c, const Fp &d) { KZG_FP_CONSTS mont_mul2_lazy<NFP>(r.l, a.l, b.l, c.l, d.l, FP_MOD,
+        FP_INVW); }
 // r = a + (kp - b), kp a multiple of p above b: limbs normalised (signed carries), the top limb keeps the excess
 KZG_HD void fp_sub_lz(Fp &r, const Fp &a, const Fp &b, const uint32_t *kp) {
     int32_t c = 0;
@@ -331,7 +332,8 @@ KZG_HD void fp_add_lz(Fp &r, const Fp &a, const Fp &b) {
 }
 // value < 64 p -> canonical
 KZG_HD void fp_canon64(Fp &r, const Fp &a) {
-    const uint32_t m32[NFP] = FP_MOD32_INIT, m16[NFP] = FP_MOD16_INIT, m8[NFP] = FP_MOD8_INIT, m4[NFP] = FP_MOD4_INIT, m2[NFP] = FP_MOD2_INIT, m1[NFP] = FP_MOD_INIT;
+    const uint32_t m32[NFP] = FP_MOD32_INIT, m16[NFP] = FP_MOD16_INIT, m8[NFP] = FP_MOD8_INIT, m4[NFP] = FP_MOD4_INIT, m2[NFP] = FP_MOD2_INIT,
+            m1[NFP] = FP_MOD_INIT;
     uint32_t v[NFP], s[NFP];
 #pragma unroll
     for (int i = 0; i < NFP; i++) v[i] = a.l[i];
@@ -463,7 +465,8 @@ KZG_HD void fr_sqr(Fr &r, const Fr &a) { fr_mul(r, a, a); }
 // lazy product: operands < ~2.6 r, result < 1.1 r, not canonical (see mont_mul_lazy)
 KZG_HD void fr_mul_lazy(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul_lazy<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
 // r = a*b + c*d with one reduction (lazy; result < 1.1 r for a*b + c*d < ~5 r^2)
-KZG_HD void fr_mul2_lazy(Fr &r, const Fr &a, const Fr &b, const Fr &c, const Fr &d) { KZG_FR_CONSTS mont_mul2_lazy<NFR>(r.l, a.l, b.l, c.l, d.l, FR_MOD, FR_INVW); }
+KZG_HD void fr_mul2_lazy(Fr &r, const Fr &a, const Fr &b, const Fr &c, const Fr &d) { KZG_FR_CONSTS mont_mul2_lazy<NFR>(r.l, a.l, b.l, c.l, d.l, FR_MOD,
+        FR_INVW); }
 // lazy sum: plain limb addition with carry normalisation, no reduction (value grows; keep chains short)
 KZG_HD void fr_add_lazy(Fr &r, const Fr &a, const Fr &b) {
     uint32_t c = 0;

@@ -490,11 +490,13 @@ KZG_HD void g1a_neg_phi(G1Affine &r, const G1Affine &p) {
 constexpr int W4_ENTRIES = 8;
 KZG_HD void w4_store(uint32_t *tab, int e, int lane, const G1Jac &v) {
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { tab[((e * 3 + 0) * NFP + i) * 64 + lane] = v.x.l[i]; tab[((e * 3 + 1) * NFP + i) * 64 + lane] = v.y.l[i]; tab[((e * 3 + 2) * NFP + i) * 64 + lane] = v.z.l[i]; }
+    for (int i = 0; i < NFP; i++) { tab[((e * 3 + 0) * NFP + i) * 64 + lane] = v.x.l[i]; tab[((e * 3 + 1) * NFP + i) * 64 + lane] = v.y.l[i];
+            tab[((e * 3 + 2) * NFP + i) * 64 + lane] = v.z.l[i]; }
 }
 KZG_HD void w4_load(G1Jac &v, const uint32_t *tab, int e, int lane) {
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { v.x.l[i] = tab[((e * 3 + 0) * NFP + i) * 64 + lane]; v.y.l[i] = tab[((e * 3 + 1) * NFP + i) * 64 + lane]; v.z.l[i] = tab[((e * 3 + 2) * NFP + i) * 64 + lane]; }
+    for (int i = 0; i < NFP; i++) { v.x.l[i] = tab[((e * 3 + 0) * NFP + i) * 64 + lane]; v.y.l[i] = tab[((e * 3 + 1) * NFP + i) * 64 + lane];
+            v.z.l[i] = tab[((e * 3 + 2) * NFP + i) * 64 + lane]; }
 }
 KZG_HD void g1_mul128_w4(G1Jac &r, const G1Affine &p, const uint32_t k[4], uint32_t *tab, int lane) {
     G1Jac t; g1_from_affine(t, p);

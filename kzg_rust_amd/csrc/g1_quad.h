@@ -106,7 +106,8 @@ __device__ __forceinline__ void g1_add_quad(G1Jac &r, const G1Jac &a, const G1Ja
 __device__ __forceinline__ G1Jac g1_shfl_down_w(const G1Jac &v, int delta) {
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 64); r.y.l[i] = __shfl_down(v.y.l[i], delta, 64); r.z.l[i] = __shfl_down(v.z.l[i], delta, 64); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 64); r.y.l[i] = __shfl_down(v.y.l[i], delta, 64); r.z.l[i] = __shfl_down(v.z.l[i],
+            delta, 64); }
     return r;
 }
 

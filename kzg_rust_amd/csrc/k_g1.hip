@@ -16,7 +16,8 @@ namespace kzg {
 
 // ------------------------------------------------------------------------------------------------ points
 // thread j < n_total: commitment j ; j >= n_total: proof j - n_total.
-__device__ __forceinline__ void validate_points_body(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group, G1Affine *pts, int *err, int stride) {
+__device__ __forceinline__ void validate_points_body(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group, G1Affine *pts, int *err,
+        int stride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * n_total) return;
     const bool is_proof = j >= n_total;
@@ -186,13 +187,15 @@ __global__ void __launch_bounds__(64) k_points_from_records(const uint8_t *recor
 __device__ __forceinline__ G1Jac g1_shfl_down8(const G1Jac &v, int delta) {      // within segments of 8 lanes
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 8); r.y.l[i] = __shfl_down(v.y.l[i], delta, 8); r.z.l[i] = __shfl_down(v.z.l[i], delta, 8); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 8); r.y.l[i] = __shfl_down(v.y.l[i], delta, 8); r.z.l[i] = __shfl_down(v.z.l[i],
+            delta, 8); }
     return r;
 }
 __device__ __forceinline__ G1Jac g1_shfl_xor(const G1Jac &v, int mask) {
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask, 64); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask,
+            64); }
     return r;
 }
 __host__ __device__ inline int lincomb_waves_per_group(int n) { return (2 * (3 * n + 1) + 63) / 64; }
@@ -256,7 +259,8 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
 //                 lane and walked back to back in one loop                          -> bucket sums B[class][window][b]
 //   k_lc_horner   one lane per (batch, class, b): Horner over the 26 windows (5 doublings + 1 addition each), then the
 //                 weights b over the 16 lanes of a class (suffix scan + butterfly), to affine
-//   k_lc_wsum + k_lc_hchain_quad   the tail for many batches (from 1024 on: half the instructions of the 16 chains per class): window sums weighted first, one Horner chain per class
+//   k_lc_wsum + k_lc_hchain_quad   the tail for many batches (from 1024 on: half the instructions of the 16 chains per class): window sums weighted first, one
+//   Horner chain per class
 // Window width: the bucket kernel's work is (items x windows) additions -- 4-bit digits 11.6 k per 64-blob batch, 5-bit 9.7 k,
 // 6-bit 8.4 k -- while the Horner tail has one chain per bucket index: 16 lanes per class at 5 bits still leave it a
 // latency-bound kernel of ~one wave per SIMD at 2048 batches; at 6 bits it would be as much work as the buckets.
@@ -405,7 +409,8 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
     __syncthreads();
     int tmax = total, kmax = nmine;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(tmax, off), u = __shfl_xor(kmax, off); tmax = v > tmax ? v : tmax; kmax = u > kmax ? u : kmax; }
+    for (int off = 32; off > 0; off >>= 1) { const int v = __shfl_xor(tmax, off), u = __shfl_xor(kmax, off); tmax = v > tmax ? v : tmax;
+            kmax = u > kmax ? u : kmax; }
     {
         G1X accx = g1x_inf(); bool started = false;  // lazy extended-Jacobian accumulator: 8M + 2S per item, no reductions
         // the list entry two steps ahead and the point one step ahead are in flight during an addition (with the lists in the
@@ -451,7 +456,8 @@ __global__ void __launch_bounds__(256) k_lc_buckets(const G1Affine *items, const
 __device__ __forceinline__ G1Jac g1_shfl_down16(const G1Jac &v, int delta) {     // within segments of 16 lanes
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 16); r.y.l[i] = __shfl_down(v.y.l[i], delta, 16); r.z.l[i] = __shfl_down(v.z.l[i], delta, 16); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_down(v.x.l[i], delta, 16); r.y.l[i] = __shfl_down(v.y.l[i], delta, 16); r.z.l[i] = __shfl_down(v.z.l[i],
+            delta, 16); }
     return r;
 }
 // 256-thread workgroups: four waves, one per SIMD of the CU the workgroup lands on (64-thread workgroups of this latency-bound chain
@@ -513,7 +519,8 @@ __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups,
     if (start < 0) { W[id] = g1_inf(); return; }                 // nothing in this window (no barrier below)
     G1X acc = s[start].raw;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { tot[i][tid] = acc.x.l[i]; tot[NFP + i][tid] = acc.y.l[i]; tot[2 * NFP + i][tid] = acc.zz.l[i]; tot[3 * NFP + i][tid] = acc.zzz.l[i]; }
+    for (int i = 0; i < NFP; i++) { tot[i][tid] = acc.x.l[i]; tot[NFP + i][tid] = acc.y.l[i]; tot[2 * NFP + i][tid] = acc.zz.l[i];
+            tot[3 * NFP + i][tid] = acc.zzz.l[i]; }
 #pragma unroll 1
     for (int b = LC_BUCKETS - 2; b >= 0; b--) {
         if (b >= start) continue;
@@ -521,15 +528,18 @@ __global__ void __launch_bounds__(256, 2) k_lc_wsum(const LcSlot *S, int groups,
         asm volatile("" ::: "memory");                            // the total is fetched only now ...
         G1X sum;
 #pragma unroll
-        for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid]; sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
+        for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid];
+                sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
         g1x_add_lazy2(sum, sum, acc);
 #pragma unroll
-        for (int i = 0; i < NFP; i++) { tot[i][tid] = sum.x.l[i]; tot[NFP + i][tid] = sum.y.l[i]; tot[2 * NFP + i][tid] = sum.zz.l[i]; tot[3 * NFP + i][tid] = sum.zzz.l[i]; }
+        for (int i = 0; i < NFP; i++) { tot[i][tid] = sum.x.l[i]; tot[NFP + i][tid] = sum.y.l[i]; tot[2 * NFP + i][tid] = sum.zz.l[i];
+                tot[3 * NFP + i][tid] = sum.zzz.l[i]; }
         asm volatile("" ::: "memory");                            // ... and is out of the registers before the next bucket comes in
     }
     G1X sum, c;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid]; sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
+    for (int i = 0; i < NFP; i++) { sum.x.l[i] = tot[i][tid]; sum.y.l[i] = tot[NFP + i][tid]; sum.zz.l[i] = tot[2 * NFP + i][tid];
+            sum.zzz.l[i] = tot[3 * NFP + i][tid]; }
     g1x_from_lazy(c, sum, true);
     G1Jac j; g1x_to_jac(j, c);
     W[id] = j;
@@ -567,7 +577,8 @@ __global__ void __launch_bounds__(256) k_lc_hchain_quad(const G1Jac *W, int grou
 //   k_ps_weights   lane per (batch, class, b): the weights b over 16 lanes (suffix scan + butterfly), to affine.
 // ~20 dependent additions after r instead of 125 doublings + 33 additions: 2.0 -> 0.5 ms for one 64-blob batch, and the
 // shifting hides under the hash next to the point validation.  More total work than either other form (every point is doubled
-// 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (fewer than 64 batches of <= 128 blobs; from 64 batches on the bucket form).
+// 125 times whatever its scalars), so it is used only while the card has idle SIMDs to give (fewer than 64 batches of <= 128 blobs; from 64 batches on the
+// bucket form).
 constexpr int PS_MAX_N = 128;                              // blobs per batch the LDS list is sized for
 constexpr int PS_THREADS = 256;                            // one workgroup per (batch, class, bucket): 64 quads
 __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }               // commitments, proofs, -G
@@ -582,7 +593,8 @@ __host__ __device__ inline int ps_points(int n) { return 2 * n + 1; }           
 // is treated as the point at infinity here; the decompression kernel raises the error).
 // (the DPP-quad doubling and addition the chain is walked with: g1_quad.h)
 constexpr int PS_SHIFT_THREADS = 256;
-__global__ void __launch_bounds__(PS_SHIFT_THREADS) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n, int groups, G1Jac *shifts) {
+__global__ void __launch_bounds__(PS_SHIFT_THREADS) k_ps_shift(const G1Affine *pts, const uint8_t *cbytes, const uint8_t *pbytes, int stride, int n,
+        int groups, G1Jac *shifts) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, np = ps_points(n);
     const int role = tid & 3;
     const bool live = (tid >> 2) < np * groups;
@@ -661,7 +673,8 @@ __device__ __forceinline__ void ps_add_present(G1Jac &acc, bool &have, const G1J
 // lane-per-accumulator form had ~6.5 + 6 lane additions three times as deep.  Writes the bucket sum (canonical).
 constexpr int PS_QUADS = PS_THREADS / 4;
 __global__ void __launch_bounds__(PS_THREADS) k_ps_buckets(const G1Jac *shifts, const G1Affine *pts, const int8_t *digits, int n, LcSlot *S) {
-    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];      // item | window << 10 | sign << 15 of this bucket; sized for every pair of the class landing here (27 KB)
+    // item | window << 10 | sign << 15 of this bucket; sized for every pair of the class landing here (27 KB)
+    __shared__ uint16_t list[2 * (2 * PS_MAX_N + 1) * LC_WINDOWS];
     __shared__ int cnt;
     __shared__ G1Jac wsum[4];
     __shared__ int whave[4];
@@ -756,8 +769,10 @@ void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proof
                             hipStream_t st, int stride) {
     if (n_total <= 0) return;
     static const bool one_wave = [] { const char *e = getenv("KZG355_VALIDATE_FORM"); return e && strcmp(e, "1w") == 0; }();      // experiment knob
-    if (one_wave) hipLaunchKernelGGL(k_validate_points_w1, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
-    else hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+    if (one_wave) hipLaunchKernelGGL(k_validate_points_w1, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group,
+            d_pts, d_err, stride);
+    else hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err,
+            stride);
 }
 // Test / audit readback of stage 2 (tests/test_gpu_parity.py): per batch  r (32 bytes big-endian, utils.rs:472) | proof_lincomb (48) |
 // rhs (48), the latter two ZCash-compressed like bytes_from_g1 (utils.rs:221-227).  pair_pts holds -proof_lincomb (utils.rs:198-201).
@@ -772,16 +787,19 @@ __global__ void __launch_bounds__(64) k_dump_intermediates(const uint32_t *scal_
     for (int k = 0; k < 48; k++) o[32 + 48 * which + k] = b[k];
     if (which == 0) {
         const uint32_t *r = scal_a + 8 * ((size_t)g * n + (n > 1 ? 1 : 0));      // a_1 = r (a_0 = 1)
-        for (int k = 0; k < 8; k++) { const uint32_t v = r[7 - k]; o[4 * k] = (uint8_t)(v >> 24); o[4 * k + 1] = (uint8_t)(v >> 16); o[4 * k + 2] = (uint8_t)(v >> 8); o[4 * k + 3] = (uint8_t)v; }
+        for (int k = 0; k < 8; k++) { const uint32_t v = r[7 - k]; o[4 * k] = (uint8_t)(v >> 24); o[4 * k + 1] = (uint8_t)(v >> 16);
+                o[4 * k + 2] = (uint8_t)(v >> 8); o[4 * k + 3] = (uint8_t)v; }
     }
 }
 void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out, hipStream_t st) {
     if (groups <= 0) return;
     hipLaunchKernelGGL(k_dump_intermediates, dim3((2 * groups + 63) / 64), dim3(64), 0, st, d_scal_a, d_pair_pts, n_per_group, groups, d_out);
 }
-void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st, int stride) {
+void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st,
+        int stride) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_decompress_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err, stride);
+    hipLaunchKernelGGL(k_decompress_points, dim3((2 * n_total + 63) / 64), dim3(64), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err,
+            stride);
 }
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only) {
     if (n_total <= 0) return;
@@ -826,8 +844,10 @@ void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, con
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     uint16_t *glists = reinterpret_cast<uint16_t *>(digits + ((ni * LC_DIG_STRIDE + 255) & ~(size_t)255));
     const int nt = 3 * n_per_group + 1;
-    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
-    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists, groups >= chain_from ? 1 : 0);
+    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c,
+            n_per_group, items, digits);
+    if (stage == 0 || stage == 2) hipLaunchKernelGGL(k_lc_buckets, dim3(groups), dim3(256), 0, st, items, digits, n_per_group, S, glists,
+            groups >= chain_from ? 1 : 0);
     if (stage == 0 || stage == 3) {
         if (groups >= chain_from) {
             G1Jac *W = reinterpret_cast<G1Jac *>(glists + lc_glists_entries(n_per_group, groups));
@@ -846,15 +866,19 @@ size_t lincomb_preshift_bytes(int n_per_group, int groups) { return sizeof(G1Jac
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
     if (groups <= 0) return;
     const int total = ps_points(n_per_group) * groups;
-    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, d_pts, (const uint8_t *)nullptr, (const uint8_t *)nullptr, 0, n_per_group, groups, d_shifts);
+    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, d_pts, (const uint8_t *)nullptr,
+            (const uint8_t *)nullptr, 0, n_per_group, groups, d_shifts);
 }
-void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st) {
+void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts,
+        hipStream_t st) {
     if (groups <= 0) return;
     const int total = ps_points(n_per_group) * groups;
-    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, (const G1Affine *)nullptr, d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
+    hipLaunchKernelGGL(k_ps_shift, dim3((4 * total + PS_SHIFT_THREADS - 1) / PS_SHIFT_THREADS), dim3(PS_SHIFT_THREADS), 0, st, (const G1Affine *)nullptr,
+            d_commitments, d_proofs, stride, n_per_group, groups, d_shifts);
 }
 // stage 0: everything; 1: the digits only (needs the decoded points and the r powers, not the shift table); 2: the sums
-void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int n_per_group,
+void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
+        int n_per_group,
                                int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage) {
     if (groups <= 0) return;
     const size_t ni = (size_t)lc_items(n_per_group) * groups;
@@ -862,7 +886,8 @@ void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, con
     LcSlot *S = reinterpret_cast<LcSlot *>(items + ni);
     int8_t *digits = reinterpret_cast<int8_t *>(S + (size_t)2 * LC_WINDOWS * LC_BUCKETS * groups);
     const int nt = 3 * n_per_group + 1;
-    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, items, digits);
+    if (stage == 0 || stage == 1) hipLaunchKernelGGL(k_lc_prep, dim3(groups * ((nt + 63) / 64)), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c,
+            n_per_group, items, digits);
     if (stage == 1) return;
     hipLaunchKernelGGL(k_ps_buckets, dim3(2 * groups * LC_BUCKETS), dim3(PS_THREADS), 0, st, d_shifts, d_pts, digits, n_per_group, S);
     hipLaunchKernelGGL(k_ps_weights, dim3(2 * groups), dim3(64), 0, st, S, groups, d_pair_pts);

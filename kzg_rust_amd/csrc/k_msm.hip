@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digit
             for (int off = 1; off < 64; off <<= 1) {
                 G1Jac o;
 #pragma unroll
-                for (int q = 0; q < NFP; q++) { o.x.l[q] = __shfl_xor(part.x.l[q], off, 64); o.y.l[q] = __shfl_xor(part.y.l[q], off, 64); o.z.l[q] = __shfl_xor(part.z.l[q], off, 64); }
+                for (int q = 0; q < NFP; q++) { o.x.l[q] = __shfl_xor(part.x.l[q], off, 64); o.y.l[q] = __shfl_xor(part.y.l[q], off, 64);
+                        o.z.l[q] = __shfl_xor(part.z.l[q], off, 64); }
                 g1_add(part, part, o);
             }
             // every lane of a wave now holds that wave's total; combine the two waves via the partial-sum slot of lane b-1
@@ -204,7 +205,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_bucket(const uint8_t *digit
 __device__ __forceinline__ G1Jac g1_shfl_xor_w(const G1Jac &v, int mask) {
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask, 64); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask,
+            64); }
     return r;
 }
 // One wave per blob, up to 32 partial sums (a lone blob's MSM is spread over 32 workgroups): quad q adds partials 2q and 2q + 1, then a butterfly over the

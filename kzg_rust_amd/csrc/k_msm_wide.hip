@@ -29,7 +29,8 @@ static_assert(sizeof(WideRow) == 128, "one table row per 128-byte line");
 __device__ __forceinline__ G1Jac g1_shfl_xor_w(const G1Jac &v, int mask) {
     G1Jac r;
 #pragma unroll
-    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask, 64); }
+    for (int i = 0; i < NFP; i++) { r.x.l[i] = __shfl_xor(v.x.l[i], mask, 64); r.y.l[i] = __shfl_xor(v.y.l[i], mask, 64); r.z.l[i] = __shfl_xor(v.z.l[i], mask,
+            64); }
     return r;
 }
 
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256) k_msm_wide_glv(const uint8_t *blobs, cons
         else { load_blob_element_words(s, blobs + (size_t)BLOB_BYTES * blob, i); canon = fr_words_canonical(s); bad = bad || !canon; }
         glv_split_fast(ha, hb, s);
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = canon ? (hsel ? hb[q] : ha[q]) : 0u;      // a non-canonical element (the blob is an Err anyway) must not index past the table
+        // a non-canonical element (the blob is an Err anyway) must not index past the table
+        for (int q = 0; q < 4; q++) v[q] = canon ? (hsel ? hb[q] : ha[q]) : 0u;
         int carry = 0;
         for (int w = 0; w < w_lo; w++) { const int raw = wide_raw_digit128(v, w, ws.bits) + carry; carry = raw >= half; }
 #pragma unroll 1
@@ -284,7 +286,8 @@ int build_wide_table(DeviceTables t, hipStream_t st) {
         for (int i_lo = 0; i_lo < N_FE; i_lo += slice) {
             const int i_n = i_lo + slice <= N_FE ? slice : N_FE - i_lo;
             hipLaunchKernelGGL(k_wide_base, dim3((i_n + 63) / 64), dim3(64), 0, st, t.msm_table, wbase, ws.bits * w, rows_w, i_lo, i_n);
-            hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)i_n * (rows_w / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, wbase, jac, pre, rows_w, i_lo, i_n);
+            hipLaunchKernelGGL(k_wide_rows, dim3((unsigned)(((size_t)i_n * (rows_w / WIDE_SEG) + 63) / 64)), dim3(64), 0, st, wbase, jac, pre, rows_w, i_lo,
+                    i_n);
         }
     }
     const hipError_t e = hipStreamSynchronize(st);
@@ -304,11 +307,14 @@ void launch_msm_wide(const uint8_t *d_blobs, const Fr *d_scalars, DeviceTables t
     int spl, parts; msm_wide_shape(n, &spl, &parts);
     const int wgpb = N_FE / (256 * spl) * parts;
     if (t.wide.glv) {
-        if (d_scalars) hipLaunchKernelGGL(k_msm_wide_glv<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
-        else hipLaunchKernelGGL(k_msm_wide_glv<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
+        if (d_scalars) hipLaunchKernelGGL(k_msm_wide_glv<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err,
+                spl, parts);
+        else hipLaunchKernelGGL(k_msm_wide_glv<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl,
+                parts);
         return;
     }
-    if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
+    if (d_scalars) hipLaunchKernelGGL(k_msm_wide<true>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl,
+            parts);
     else hipLaunchKernelGGL(k_msm_wide<false>, dim3(n * wgpb), dim3(256), 0, st, d_blobs, d_scalars, t.wide_table, t.wide, d_partials, d_err, spl, parts);
 }
 

@@ -1,7 +1,9 @@
 // k_pairing.hip -- the pairing check of verify_kzg_proof_batch (reference src/utils.rs:189-214, called at kzg.rs:625)
 // as a wave-cooperative kernel: one 64-lane wave per batch, Fp12 coefficients spread over the lanes
 // (pairing_coop.h).  ~20x shorter dependent chain than the one-lane-per-batch kernel in k_verify.hip.
-#define KZG_FP_MUL_NOINLINE 1   // tower routines out of line: the interpreter bodies stay small (fully inlined, the kernel was ~6x larger and 25 % slower: 6.4 vs 4.85 ms per 2048 batches)
+// tower routines out of line: the interpreter bodies stay small (fully inlined, the kernel was ~6x larger and 25 % slower: 6.4 vs 4.85 ms per 2048
+// batches)
+#define KZG_FP_MUL_NOINLINE 1
 #include "kernels.h"
 #include "pairing_lanes.h"
 
@@ -29,7 +31,8 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairP
     coop_init(mem, scheds, p1, p2);
     coop_run(mem, prog, 0, n_insn, lines_w + 2 * N_LINES, lines_w, use1, use2, *frob);
     if (f_out) {
-        if (lane < 12) { Fp c; fp_norm_lz(c, mem.f.c[lane]); fp_canon64(c, c); f_out[12 * (size_t)g + lane] = c; }      // canonical: within the next kernel's invariant
+        // canonical: within the next kernel's invariant
+        if (lane < 12) { Fp c; fp_norm_lz(c, mem.f.c[lane]); fp_canon64(c, c); f_out[12 * (size_t)g + lane] = c; }
         return;
     }
     const bool r = coop_is_one(mem, mem.t0);
@@ -39,7 +42,8 @@ __global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairP
 // The hard part of the final exponentiation for many batches: twelve lanes per check, five checks per wave (pairing_lanes.h).  f_in: slot F of
 // every batch as k_pairing_coop left it; prog[pc0 .. pc1): the tail of the pairing program; verdict = (slot T0 == 1).
 constexpr int HARD12_WAVES = 4;
-__global__ void __launch_bounds__(64 * HARD12_WAVES) k_pairing_hard12(const Fp *f_in, int groups, const FrobTables *frob, const CoopInsn *prog, int pc0, int pc1, int *ok) {
+__global__ void __launch_bounds__(64 * HARD12_WAVES) k_pairing_hard12(const Fp *f_in, int groups, const FrobTables *frob, const CoopInsn *prog, int pc0,
+        int pc1, int *ok) {
     __shared__ L12Mem mems[HARD12_WAVES * L12_BATCHES];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / 12, k = lane % 12;
     const int g_raw = (blockIdx.x * HARD12_WAVES + wid) * L12_BATCHES + grp;
@@ -60,7 +64,8 @@ __global__ void __launch_bounds__(64 * HARD12_WAVES) k_pairing_hard12(const Fp *
 // f_in (or null): the Miller loops were made by k_pairing_coop_split, which left their value (12 coefficients per batch) there: wave 0 goes straight
 // to the final exponentiation.
 __global__ void __launch_bounds__(128) k_pairing_coop2(const PairPt *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
-                                                       const FrobTables *frob, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok, const Fp *f_in) {
+                                                       const FrobTables *frob, const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok,
+                                                               const Fp *f_in) {
     __shared__ CoopMem mems[2];
     __shared__ Fp pre[2 * N_LINES * 6];                           // every line of both pairs evaluated at its point, ahead of the loops
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x;
@@ -94,7 +99,8 @@ __global__ void __launch_bounds__(128) k_pairing_coop2(const PairPt *pair_pts, i
 // products over the 2 K partial values.  Measured for a lone check (loops + hand-over + the launch of the second kernel): 0.397 ms on two waves,
 // 0.330 at K = 2, 0.356 at K = 3 (the tree and the imbalance eat the shorter chain); whole check 1.276 -> 1.198 ms at K = 2.
 template <int K> __global__ void __launch_bounds__(128 * K) k_pairing_coop_split(const PairPt *pair_pts, int groups, const LineW *lines_w, const int *lines_inf,
-                                                                                const FrobTables *frob, const CoopInsn *prog, const CoopScheds *scheds, Fp *f_out,
+                                                                                const FrobTables *frob, const CoopInsn *prog, const CoopScheds *scheds,
+                                                                                        Fp *f_out,
                                                                                 MillerSplit sp) {
     __shared__ CoopMem mems[2 * K];
     __shared__ Fp pre[2 * N_LINES * 6];                           // every line of both pairs evaluated at its point, ahead of the loops
@@ -136,7 +142,8 @@ __global__ void __launch_bounds__(256) k_lines_to_w(const LineCoeff *lines, Line
 
 // d_f12 (or null): groups * 12 Fp of scratch; with it and at least hard12_from batches the check is two kernels -- Miller loops and easy part wave-
 // cooperatively, then the hard part twelve lanes per check (k_pairing_hard12)
-void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st, int two_wave_upto, Fp *d_f12, int hard12_from, int miller_segments) {
+void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st, int two_wave_upto, Fp *d_f12, int hard12_from,
+        int miller_segments) {
     if (groups <= 0) return;
     if (groups <= two_wave_upto) {          // several waves per batch while that still leaves the SIMDs a single wave each
         static CoopInsn host_prog[COOP_PROGRAM_MAX];
@@ -145,9 +152,12 @@ void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d
         const int k = d_f12 ? (miller_segments > 0 ? miller_segments : 2) : 1;      // (the segment form hands f over through d_f12)
         if (k >= 2) {
             const MillerSplit sp = miller_split(host_prog, k);
-            if (k == 2) hipLaunchKernelGGL(k_pairing_coop_split<2>, dim3(groups), dim3(256), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog, t.coop_scheds, d_f12, sp);
-            else if (k == 3) hipLaunchKernelGGL(k_pairing_coop_split<3>, dim3(groups), dim3(384), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog, t.coop_scheds, d_f12, sp);
-            else hipLaunchKernelGGL(k_pairing_coop_split<4>, dim3(groups), dim3(512), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog, t.coop_scheds, d_f12, sp);
+            if (k == 2) hipLaunchKernelGGL(k_pairing_coop_split<2>, dim3(groups), dim3(256), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob,
+                    t.pairing_prog, t.coop_scheds, d_f12, sp);
+            else if (k == 3) hipLaunchKernelGGL(k_pairing_coop_split<3>, dim3(groups), dim3(384), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob,
+                    t.pairing_prog, t.coop_scheds, d_f12, sp);
+            else hipLaunchKernelGGL(k_pairing_coop_split<4>, dim3(groups), dim3(512), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob,
+                    t.pairing_prog, t.coop_scheds, d_f12, sp);
         }
         hipLaunchKernelGGL(k_pairing_coop2, dim3(groups), dim3(128), 0, st, d_pair_pts, groups, t.lines_w, t.lines_inf, t.frob, t.pairing_prog,
                            t.pairing_prog_len, t.coop_scheds, d_ok, k >= 2 ? (const Fp *)d_f12 : (const Fp *)nullptr);

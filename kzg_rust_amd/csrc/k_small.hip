@@ -200,7 +200,8 @@ void launch_setup_small(const uint8_t *d_g1_bytes, int n, DeviceTables t, int *d
     hipLaunchKernelGGL(k_small_setup_g1, dim3(1), dim3(64), 0, st, d_g1_bytes, n, t.msm_table, t.g1_first2, d_err);
     hipLaunchKernelGGL(k_small_setup_roots, dim3(1), dim3(64), 0, st, t.roots, n);
 }
-void launch_small_records(const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total, int npg, DeviceTables t, Fr *d_z, uint8_t *d_records, int *d_err, hipStream_t st) {
+void launch_small_records(const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p, int n_total, int npg, DeviceTables t, Fr *d_z, uint8_t *d_records,
+        int *d_err, hipStream_t st) {
     if (n_total <= 0) return;
     hipLaunchKernelGGL(k_small_records, dim3((n_total + 63) / 64), dim3(64), 0, st, d_blobs, d_c, d_p, n_total, npg, t.n_fe, t.roots, d_z, d_records, d_err);
 }
@@ -208,9 +209,11 @@ void launch_small_commit(const uint8_t *d_blobs, int n_blobs, DeviceTables t, ui
     if (n_blobs <= 0) return;
     hipLaunchKernelGGL(k_small_commit, dim3((n_blobs + 63) / 64), dim3(64), 0, st, d_blobs, n_blobs, t.n_fe, t.msm_table, d_out48, d_err);
 }
-void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_z, int n_blobs, DeviceTables t, uint8_t *d_out48, uint8_t *d_y32, int *d_err, hipStream_t st) {
+void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_z, int n_blobs, DeviceTables t, uint8_t *d_out48, uint8_t *d_y32, int *d_err,
+        hipStream_t st) {
     if (n_blobs <= 0) return;
-    hipLaunchKernelGGL(k_small_proof, dim3((n_blobs + 63) / 64), dim3(64), 0, st, d_blobs, d_c, d_z, n_blobs, t.n_fe, t.roots, t.msm_table, d_out48, d_y32, d_err);
+    hipLaunchKernelGGL(k_small_proof, dim3((n_blobs + 63) / 64), dim3(64), 0, st, d_blobs, d_c, d_z, n_blobs, t.n_fe, t.roots, t.msm_table, d_out48, d_y32,
+            d_err);
 }
 
 }  // namespace kzg

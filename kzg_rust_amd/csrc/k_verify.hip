@@ -77,7 +77,8 @@ struct ChallengeReader {
     }
 };
 
-__device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, Fr *zpow_out, uint8_t *records) {
+__device__ __forceinline__ void challenge_finish(const uint32_t hh[8], int i, const uint8_t *cm, const uint8_t *proofs, Fr *z_out, Fr *zpow_out,
+        uint8_t *records) {
     // hash_to_bls_field (utils.rs:250-258): big-endian integer reduced mod r
     const uint32_t dw[8] = {hh[7], hh[6], hh[5], hh[4], hh[3], hh[2], hh[1], hh[0]};
     Fr z; fr_from_words(z, dw);
@@ -594,7 +595,8 @@ __global__ void __launch_bounds__(256) k_rpowers(const uint8_t *records, int n, 
 __global__ void __launch_bounds__(64) k_pairing(const PairPt *pair_pts, const LineCoeff *lines, const int *lines_inf, int groups, int *ok) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
-    G1Affine p1, p2; pairpt_to_affine(p1, pair_pts[2 * (size_t)g]); pairpt_to_affine(p2, pair_pts[2 * (size_t)g + 1]);      // (this A/B kernel works on affine points)
+    // (this A/B kernel works on affine points)
+    G1Affine p1, p2; pairpt_to_affine(p1, pair_pts[2 * (size_t)g]); pairpt_to_affine(p2, pair_pts[2 * (size_t)g + 1]);
     if (lines_inf[2]) p1 = g1a_inf();          // e(P, infinity) = 1
     if (lines_inf[0]) p2 = g1a_inf();
     Fp12 f;
@@ -607,18 +609,22 @@ void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, con
                        hipStream_t st, int form) {
     if (n_total <= 0) return;
     const int wgs = (n_total + 63) / 64;
-    if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
-    else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
+    if (form == 2 || (form == 0 && wgs <= 512)) hipLaunchKernelGGL(k_challenge, dim3(wgs), dim3(128), 0, st, d_blobs, d_commitments, d_proofs, n_total, d_z,
+            d_zpow, d_records);
+    else hipLaunchKernelGGL(k_challenge_1w, dim3((n_total + CH1W_THREADS - 1) / CH1W_THREADS), dim3(CH1W_THREADS), 0, st, d_blobs, d_commitments, d_proofs,
+            n_total, d_z, d_zpow, d_records);
 }
 void launch_challenges_from_digests(const uint8_t *d_digests, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, Fr *d_z, Fr *d_zpow,
                                     uint8_t *d_records, hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_challenge_from_digest, dim3((n_total + 63) / 64), dim3(64), 0, st, d_digests, d_commitments, d_proofs, n_total, d_z, d_zpow, d_records);
+    hipLaunchKernelGGL(k_challenge_from_digest, dim3((n_total + 63) / 64), dim3(64), 0, st, d_digests, d_commitments, d_proofs, n_total, d_z, d_zpow,
+            d_records);
 }
 void launch_eval(const uint8_t *d_blobs, const Fr *d_z, const Fr *d_zpow, DeviceTables t, int n_total, int n_per_group, Fr *d_y, uint8_t *d_records, int *d_err,
                  hipStream_t st) {
     if (n_total <= 0) return;
-    hipLaunchKernelGGL(k_eval, dim3((n_total + EVAL_WAVES - 1) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, st, d_blobs, d_z, d_zpow, t.eval_tab, n_total, n_per_group,
+    hipLaunchKernelGGL(k_eval, dim3((n_total + EVAL_WAVES - 1) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, st, d_blobs, d_z, d_zpow, t.eval_tab, n_total,
+            n_per_group,
                        d_y, d_records, d_err);
 }
 void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int check_zy, uint32_t *d_scal_a, uint32_t *d_scal_b,
@@ -630,7 +636,8 @@ void launch_rpowers(const uint8_t *d_records, int n_per_group, int groups, int c
     // from one wave per SIMD on (lanes_from, default 1024 batches), hash with a lane per batch first (k_rhash_lanes)
     const int lanes = (!have_digest && n_per_group > 1 && groups >= lanes_from) ? 1 : 0;
     if (lanes) hipLaunchKernelGGL(k_rhash_lanes, dim3((groups + 63) / 64), dim3(64), 0, st, d_records, n_per_group, groups, d_scal_c, n_fe);
-    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b, d_scal_c, d_err, n_fe, lanes || have_digest);
+    hipLaunchKernelGGL(k_rpowers, dim3((groups + wpw - 1) / wpw), dim3(64 * wpw), 0, st, d_records, n_per_group, groups, check_zy, d_scal_a, d_scal_b,
+            d_scal_c, d_err, n_fe, lanes || have_digest);
 }
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st) {
     if (groups <= 0) return;

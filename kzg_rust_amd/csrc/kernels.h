@@ -81,7 +81,8 @@ void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proof
 void launch_decompress_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err, hipStream_t st,
                               int stride = 48);
 void launch_subgroup_points(const G1Affine *d_pts, int n_total, int n_per_group, int *d_err, hipStream_t st, int commitments_only = 0);
-void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */, hipStream_t st);
+void launch_dump_intermediates(const uint32_t *d_scal_a, const PairPt *d_pair_pts, int n_per_group, int groups, uint8_t *d_out /* [groups][128] */,
+        hipStream_t st);
 // d_zpow (may be null): EVAL_ZPOWERS values per blob, z^2, z^4, .. z^4096 (Montgomery) -- what launch_eval needs beside z
 void launch_challenges(const uint8_t *d_blobs, const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total,
                        Fr *d_z, Fr *d_zpow, uint8_t *d_records, hipStream_t st, int form = 0 /* 0 by size, 1 one wave, 2 two waves */);
@@ -115,12 +116,15 @@ bool lincomb_preshift_fits(int n_per_group, int groups);
 size_t lincomb_preshift_bytes(int n_per_group, int groups);
 void launch_lincomb_preshift(const G1Affine *d_pts, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
 // the same chains straight from the compressed inputs (x only: they do not wait for the square root of the decompression)
-void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts, hipStream_t st);
+void launch_lincomb_preshift_bytes(const uint8_t *d_commitments, const uint8_t *d_proofs, int stride, int n_per_group, int groups, G1Jac *d_shifts,
+        hipStream_t st);
 void launch_lincomb_preshifted(const G1Affine *d_pts, const G1Jac *d_shifts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
-                               int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st, int stage = 0 /* 1: digits only; 2: sums only */);
+                               int n_per_group, int groups, void *d_scratch, PairPt *d_pair_pts, hipStream_t st,
+                                       int stage = 0 /* 1: digits only; 2: sums only */);
 void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st,
                     int two_wave_upto = 256 /* batches up to which the two Miller loops of a check run on two waves */,
-                    Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */, int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */,
+                    Fp *d_f12 = nullptr /* groups * 12 Fp of scratch */,
+                            int hard12_from = 0 /* batches from which the hard part runs twelve lanes per check; 0: never */,
                     int miller_segments = 0 /* few batches: segments per Miller loop, 2 waves each (1: the two-wave kernel; 0: the default, 2) */);
 size_t pairing_f12_bytes(int groups);
 void launch_pairing_lane(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d_ok, hipStream_t st);   // one lane per batch (A/B, tests)
@@ -145,18 +149,22 @@ void launch_msm_finalize(const G1Jac *d_partials, int n, uint8_t *d_out48 /* [n]
 constexpr int SMALL_N_MIN = 4, SMALL_N_MAX = 64;
 void launch_lagrange_from_monomial(const uint8_t *d_mono, int n, uint8_t *d_out /* n*48 */, int *d_err, hipStream_t st);
 void launch_setup_small(const uint8_t *d_g1_bytes, int n, DeviceTables t, int *d_err, hipStream_t st);
-void launch_small_records(const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p /* may be null */, int n_total, int npg, DeviceTables t, Fr *d_z /* may be null */,
+void launch_small_records(const uint8_t *d_blobs, const uint8_t *d_c, const uint8_t *d_p /* may be null */, int n_total, int npg, DeviceTables t,
+        Fr *d_z /* may be null */,
                           uint8_t *d_records /* may be null */, int *d_err /* per group */, hipStream_t st);
 void launch_small_commit(const uint8_t *d_blobs, int n_blobs, DeviceTables t, uint8_t *d_out48, int *d_err /* per blob */, hipStream_t st);
 // proofs at d_z (Montgomery, one per blob) or, if d_c != null, at each blob's own Fiat-Shamir challenge; d_y32 (32-byte y per blob) may be null
-void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_z, int n_blobs, DeviceTables t, uint8_t *d_out48, uint8_t *d_y32, int *d_err, hipStream_t st);
+void launch_small_proof(const uint8_t *d_blobs, const uint8_t *d_c, const Fr *d_z, int n_blobs, DeviceTables t, uint8_t *d_out48, uint8_t *d_y32, int *d_err,
+        hipStream_t st);
 
 // ---- k_prove.hip
 // quotient polynomial q(X) = (p(X) - y)/(X - z) in evaluation form (kzg.rs:461-523) for n blobs; also y.
 // d_q: the quotient of every blob in the BLOB format (n x 131,072 bytes: 4096 canonical 32-byte big-endian integers; 16-byte aligned) -- the fixed-base MSM
-// reads it like a blob; d_scratch: quotient_scratch_bytes(n) of device memory; form: 0 by size, 2 / 4 / 6 = 2^form leaves per lane.  Non-zero: a HIP call failed.
+// reads it like a blob; d_scratch: quotient_scratch_bytes(n) of device memory; form: 0 by size, 2 / 4 / 6 = 2^form leaves per lane.  Non-zero: a HIP call
+// failed.
 size_t quotient_scratch_bytes(int n);
-int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q /* [n][131072] */, void *d_scratch, int *d_err, hipStream_t st,
+int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n, Fr *d_y, uint8_t *d_q /* [n][131072] */, void *d_scratch, int *d_err,
+        hipStream_t st,
                     int form = 0);
 void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err /* per element, ERR_NONCANONICAL_FR */, hipStream_t st);
 void launch_fr_to_bytes(const Fr *d_in, int n, uint8_t *d_out32, hipStream_t st);

@@ -47,7 +47,8 @@ constexpr uint32_t EVEN_MASK = 0x555u;
 constexpr uint32_t FULL_MASK = 0xfffu;
 
 constexpr int COOP_MAX_TERMS = 10;
-constexpr int COOP_T_FULL = 9, COOP_T_SPARSE = 6;       // terms per coefficient the combination walks: product / square <= 9; line product, cyclotomic square <= 6
+// terms per coefficient the combination walks: product / square <= 9; line product, cyclotomic square <= 6
+constexpr int COOP_T_FULL = 9, COOP_T_SPARSE = 6;
 // Phase 2 of a product type (the "combination"): coefficient k = sum_t coef[k][t] * partial[lane[k][t]] + kp[k] * p.  The multiple
 // of p keeps the value positive -- one more p than the negative terms need, so that the value is at least p and the top limb of the
 // limb-parallel form below can never go negative; partials are < 1.04 p, so every coefficient stays below 32 p: the lazy bound of an
@@ -231,7 +232,8 @@ inline bool build_coop_schedules(CoopScheds &out) {
     term(1, 16 + 6, -12); term(1, 16 + 7, -12); term(1, 24 + 1, 1);
     term(7, 16 + 4, 6); term(7, 16 + 5, -6); term(7, 16 + 6, 6); term(7, 16 + 7, 6); term(7, 24 + 7, 1);
     ok = coop_comb_finish(cy.comb) && ok;
-    ok = ok && mul.comb.nmax <= (uint32_t)COOP_T_FULL && sqr.comb.nmax <= (uint32_t)COOP_T_FULL && lin.comb.nmax <= (uint32_t)COOP_T_SPARSE && cy.comb.nmax <= (uint32_t)COOP_T_SPARSE;
+    ok = ok && mul.comb.nmax <= (uint32_t)COOP_T_FULL && sqr.comb.nmax <= (uint32_t)COOP_T_FULL && lin.comb.nmax <= (uint32_t)COOP_T_SPARSE &&
+            cy.comb.nmax <= (uint32_t)COOP_T_SPARSE;
     return ok;
 }
 
@@ -497,7 +499,8 @@ KZG_HD void coop_fp6_inv(CoopMem &m, Fp12W &x, Fp *V) {
 #undef KZG_FP2P_A
 #undef KZG_FP2P_B
     // rows are 1-based indices into red, signed.  With P_k = (r[4k] - r[4k+1], r[4k+2] + r[4k+3]) and xi (m0, m1) = (m0 - m1, m0 + m1):
-    static const int8_t l0[6][COOP_LIN_W] = {{1, 2}, {2}, {3, 4}, {4}, {5, 6}, {6}};                                  // a_j = (lo + hi, hi) from w^(2j), w^(2j+6)
+    // a_j = (lo + hi, hi) from w^(2j), w^(2j+6)
+    static const int8_t l0[6][COOP_LIN_W] = {{1, 2}, {2}, {3, 4}, {4}, {5, 6}, {6}};
     static const int8_t l2[6][COOP_LIN_W] = {{1, -2, -5, 6, 7, 8}, {3, 4, -5, 6, -7, -8},                            // A = P0 - xi P1
                                              {9, -10, -11, -12, -13, 14}, {9, -10, 11, 12, -15, -16},                // B = xi P2 - P3
                                              {17, -18, -21, 22}, {19, 20, -23, -24}};                                // C = P4 - P5
@@ -540,11 +543,13 @@ KZG_HD void coop_frob2(Fp12W &dst, const Fp12W &a, const Fp *tab) {
 // them; spelled out as straight-line code the kernel was >0.5 MB of instructions (far beyond the 64 KB instruction
 // cache).  Instead the check is a flat list of instructions over 8 Fp12 slots, built once by build_pairing_program()
 // on the host, and the kernel is a small interpreter with ONE body per opcode.
-enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_EVEN, OP_LINE_EVAL, OP_CONJ, OP_FROB1, OP_FROB2, OP_FP6INV, OP_COPY, OP_CYC_SQR };
+enum : uint8_t { OP_SET_ONE, OP_SQR, OP_MUL, OP_MUL_LINE0, OP_MUL_LINE1, OP_MUL_EVEN, OP_LINE_EVAL, OP_CONJ, OP_FROB1, OP_FROB2, OP_FP6INV, OP_COPY,
+        OP_CYC_SQR };
 struct CoopInsn { uint8_t op, dst, a, b; };
 enum : uint8_t { S_F = 0, S_T0 = 1, S_T1 = 2, S_T2 = 3, S_T3 = 4, S_T4 = 5, S_L0 = 6, S_L1 = 7 };
 constexpr int COOP_PROGRAM_MAX = 1024;
-constexpr int COOP_LINE_CHUNK = 5;       // line steps evaluated at once inside the Miller loop: 5 steps x 2 pairs x 6 coefficients = 60 lanes, 60 Fp = the slots t0 .. t4
+// line steps evaluated at once inside the Miller loop: 5 steps x 2 pairs x 6 coefficients = 60 lanes, 60 Fp = the slots t0 .. t4
+constexpr int COOP_LINE_CHUNK = 5;
 
 // hard_start (or null): receives the index of the first instruction of the hard part of the final exponentiation -- from there on the program only
 // uses the slots F, T0, T1, T2 and the operations COPY, CYC_SQR, MUL, CONJ, FROB1, FROB2 (pairing_lanes.h runs that tail twelve lanes per check)
@@ -670,11 +675,13 @@ KZG_HD void coop_run(CoopMem &m, const CoopInsn *prog, int pc0, int pc1, const L
         Fp12W &dst = coop_slot(m, in.dst);
         const Fp12W &a = coop_slot(m, in.a);
         if (in.op == OP_MUL || in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1 || in.op == OP_MUL_EVEN) {   // one body for every product
-            const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2) || (pc >= line_pc_end && (in.op == OP_MUL_LINE0 || in.op == OP_MUL_LINE1));
+            const bool skip = (in.op == OP_MUL_LINE0 && !use1) || (in.op == OP_MUL_LINE1 && !use2) || (pc >= line_pc_end && (in.op == OP_MUL_LINE0 ||
+                    in.op == OP_MUL_LINE1));
             const uint32_t mask = in.op == OP_MUL ? FULL_MASK : in.op == OP_MUL_EVEN ? EVEN_MASK : LINE_MASK;
             const Fp *bs = mask != LINE_MASK ? nullptr                                     // the line as its six evaluated coefficients:
                            : pre ? pre + ((in.op == OP_MUL_LINE1 ? N_LINES : 0) + cur_line) * 6      // all made ahead of the loop (two-wave kernel)
-                                 : coop_line_buf(m) + ((cur_line % COOP_LINE_CHUNK) * 2 + (in.op == OP_MUL_LINE1 ? 1 : 0)) * 6;      // or five steps at a time (OP_LINE_EVAL)
+                                 // or five steps at a time (OP_LINE_EVAL)
+                                 : coop_line_buf(m) + ((cur_line % COOP_LINE_CHUNK) * 2 + (in.op == OP_MUL_LINE1 ? 1 : 0)) * 6;
             if (!skip) coop_product(m, mask == LINE_MASK ? m.sc.line : m.sc.mul, dst, a, coop_slot(m, in.b), mask, bs);
             continue;
         }

@@ -105,7 +105,8 @@ KZG_HD void l12_cyc_sqr(Fp12W &dst, const Fp12W &a) {
         l12_lin(s3, S, 3, z, 0);                                    // 3 S
         l12_lin(t2, ak, 2, z, 0);                                   // 2 a_k   <= 4p
         if (rw.row == L12_A || rw.row == L12_B) fp_sub_lz(o, s3, t2, m4);                              // 3 S - 2 a_k + 4p          <= 7.1 p
-        else if (rw.row == L12_DP) { const uint32_t m16[NFP] = FP_MOD16_INIT; Fp s12; l12_lin(s12, s3, 4, z, 0); fp_sub_lz(o, t2, s12, m16); }   // 2 a_k - 12 S + 16p  <= 20 p
+        // 2 a_k - 12 S + 16p  <= 20 p
+        else if (rw.row == L12_DP) { const uint32_t m16[NFP] = FP_MOD16_INIT; Fp s12; l12_lin(s12, s3, 4, z, 0); fp_sub_lz(o, t2, s12, m16); }
         else { Fp s6; l12_lin(s6, s3, 2, z, 0); fp_add_lz(o, s6, t2); }                                // 6 S + 2 a_k               <= 10.2 p
         l12_below_2p(o);
         outv[L12_AT(k)] = o;

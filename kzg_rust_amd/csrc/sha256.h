@@ -69,7 +69,8 @@ KZG_HD void sha256_bytes(uint8_t out[32], const uint8_t *msg, uint64_t len) {
         for (int i = 0; i < 16; i++) w[i] = load_be32(tail + o + 4 * i);
         sha256_block(s, w);
     }
-    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(s.h[i] >> 24); out[4 * i + 1] = (uint8_t)(s.h[i] >> 16); out[4 * i + 2] = (uint8_t)(s.h[i] >> 8); out[4 * i + 3] = (uint8_t)s.h[i]; }
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(s.h[i] >> 24); out[4 * i + 1] = (uint8_t)(s.h[i] >> 16); out[4 * i + 2] = (uint8_t)(s.h[i] >> 8);
+            out[4 * i + 3] = (uint8_t)s.h[i]; }
 }
 
 // digest words (big-endian word order: h[0] is most significant) -> 8 little-endian words of the 256-bit integer

@@ -1,7 +1,9 @@
 // Host build (g++) of the DEVICE math headers under kzg_rust_amd/csrc, exposed through a tiny C ABI so
 // that tests/test_device_math_host.py can compare them with the CPU oracle on the build box (no GPU).
 // Test infrastructure only: this file is never part of libkzg355.so.
-#define KZG_G1_ADD_MUL2 1      // the fixed-base MSM's form of the lazy mixed addition (two products under one reduction); the other form is the batch linear combination's, checked on the GPU
+// the fixed-base MSM's form of the lazy mixed addition (two products under one reduction); the other form is the batch linear combination's, checked
+// on the GPU
+#define KZG_G1_ADD_MUL2 1
 #include "../../kzg_rust_amd/csrc/field.h"
 #include "../../kzg_rust_amd/csrc/tower.h"
 #include "../../kzg_rust_amd/csrc/g1.h"
@@ -85,7 +87,8 @@ int hd_eval_poly(uint8_t *out32, const uint8_t *blob, const uint8_t *z_be) {
             eval_group(h[level - 1][m], h[level - 2] + 4 * m, zp[2 * level - 2], zp[2 * level - 1], tab[eval_tab_first(level) + m]);
     Fr y; eval_finish(y, h[5][0], Sp, zp[0], zp[12]);
     limbs_to_words<NFR, 8>(w, y.l);
-    for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8; out32[4 * i + 3] = v; }
+    for (int i = 0; i < 8; i++) { const uint32_t v = w[7 - i]; out32[4 * i] = v >> 24; out32[4 * i + 1] = v >> 16; out32[4 * i + 2] = v >> 8;
+            out32[4 * i + 3] = v; }
     return 0;
 }
 // y and the quotient q_i = (p_i - y) / (w_i - z) through quot_core.h, the way k_quotient_tree<lg> deals the tree to its lanes: 4096 >> lg "lanes", each
@@ -242,7 +245,8 @@ int hd_glv_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be) {
 int hd_w4_mul(uint8_t *out, const uint8_t *p, const uint8_t *k_be16) {
     G1Affine pa, ra; G1Jac r; uint32_t k[4];
     if (g1_decompress(pa, p)) return 1;
-    for (int i = 0; i < 4; i++) k[i] = ((uint32_t)k_be16[4 * (3 - i)] << 24) | ((uint32_t)k_be16[4 * (3 - i) + 1] << 16) | ((uint32_t)k_be16[4 * (3 - i) + 2] << 8) | k_be16[4 * (3 - i) + 3];
+    for (int i = 0; i < 4; i++) k[i] = ((uint32_t)k_be16[4 * (3 - i)] << 24) | ((uint32_t)k_be16[4 * (3 - i) + 1] << 16) | ((uint32_t)k_be16[4 * (3 - i) +
+            2] << 8) | k_be16[4 * (3 - i) + 3];
     std::vector<uint32_t> tab(W4_ENTRIES * 3 * NFP * 64);
     g1_mul128_w4(r, pa, k, tab.data(), 5);
     g1_to_affine(ra, r); g1_compress_affine(out, ra); return 0;
@@ -384,7 +388,8 @@ int hd_pairings_verify_coop_segments(int *ok, const uint8_t *p1, const uint8_t *
         coop_init(*m[w], &sc, pa, pb);
         const int pair = w & 1, seg = w >> 1;
         if (seg > 0) coop_set_one(m[w]->f);
-        coop_run(*m[w], prog, sp.pc_start[seg], COOP_MILLER_INSNS, w1.data(), w2.data(), pair == 0 && use1, pair == 1 && use2, ft, pre.data(), sp.pc_lines_end[seg]);
+        coop_run(*m[w], prog, sp.pc_start[seg], COOP_MILLER_INSNS, w1.data(), w2.data(), pair == 0 && use1, pair == 1 && use2, ft, pre.data(),
+                sp.pc_lines_end[seg]);
     }
     for (int stride = 1; stride < 2 * K; stride <<= 1)
         for (int w = 0; w + stride < 2 * K; w += 2 * stride) {
