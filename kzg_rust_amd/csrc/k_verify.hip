@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES, 2) k_eval(const uint8_t *blob
     // z^4, z^8 (level 2, after every fourth step) and z^16, z^32 (level 3) wait in LDS: 18 more live registers spilled, and a global load at the
     // point of use is a full memory latency in front of every level-2 group
     __shared__ uint32_t zls[EVAL_WAVES][4 * NFR];
-    if (lane < 4 * NFR) zls[wid][lane] = reinterpret_cast<const uint32_t *>(zp + 1)[lane];
+    const uint32_t zl_word = reinterpret_cast<const uint32_t *>(zp + 1)[lane < 4 * NFR ? lane : 0];       // parked behind the first step's wait for its tile
     Fr h2[4], Sp = fr_zero();
     bool bad = false;
     constexpr int STEPS = N_FE / 4 / 64;
@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES, 2) k_eval(const uint8_t *blob
     for (int it = 0; it < STEPS; it++) {
         __builtin_amdgcn_s_waitcnt(0);                            // this step's tile (and table entry) have landed
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (it == 0 && lane < 4 * NFR) zls[wid][lane] = zl_word;
         uint4 cur[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) cur[j] = tile[8 * lane + (j ^ (lane & 7))];
@@ -358,6 +359,17 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES, 2) k_eval(const uint8_t *blob
 #pragma unroll
     for (int k = 0; k < NFR; k++) { z16.l[k] = zls[wid][2 * NFR + k]; z32.l[k] = zls[wid][3 * NFR + k]; }
     eval_group(h, c, z16, z32, g3);
+    // What wave 0 will need for levels 4-6 of the workgroup's four blobs (blob b = lane / 16): requested here, by every wave (no branch around a
+    // load: k_eval's header), so that the answers arrive under the sum below and the barrier instead of in front of each level
+    const int b = lane >> 4, u = lane & 15;                       // blob b of the workgroup, level-4 node u
+    const int mine_raw = blockIdx.x * EVAL_WAVES + b, mine = mine_raw < n_total ? mine_raw : n_total - 1;
+    const Fr *zq = zpow + EVAL_ZPOWERS * (size_t)mine;
+    Fr zt[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) zt[k] = zq[5 + k];                // z^64 .. z^4096
+    const Fr zmine = z_in[mine];
+    EvalPiece gp4[7], gp5[7], gp6[7];
+    eval_tab_load(gp4, tab, EVAL_TAB_L4 + u); eval_tab_load(gp5, tab, EVAL_TAB_L5 + (lane & 3)); eval_tab_load(gp6, tab, EVAL_TAB_L6);
     // the blob's sum of values: every lane's 64 folded below 3.1 r, then added across the wave (< 200 r)
     eval_fold(Sp);
 #pragma unroll
@@ -368,22 +380,22 @@ __global__ void __launch_bounds__(64 * EVAL_WAVES, 2) k_eval(const uint8_t *blob
     if (lane == 0) eval_park(hx, 64, Sp);                         // and its sum of values: entry 64
     __syncthreads();
     if (wid != 0) return;
-    const int b = lane >> 4, u = lane & 15;                       // blob b of the workgroup, level-4 node u
-    const int mine_raw = blockIdx.x * EVAL_WAVES + b, mine = mine_raw < n_total ? mine_raw : n_total - 1;
-    const Fr *zq = zpow + EVAL_ZPOWERS * (size_t)mine;
     Fr Sb;
 #pragma unroll
     for (int k = 0; k < NFR; k++) Sb.l[k] = hxs[b][NFR * 64 + k];
     eval_children(c, hxs[b], u);
-    eval_group(h, c, zq[5], zq[6], eval_tab_group(tab, EVAL_TAB_L4 + u));
+    EvalGroup gt; eval_group_unpack(gt, gp4);
+    eval_group(h, c, zt[0], zt[1], gt);
     uint32_t *hx0 = hxs[0];                                       // from here on wave 0's buffer, read only by wave 0: entry 16 b + u, then 4 b + v
     eval_park(hx0, lane, h);
     eval_children(c, hx0, 4 * b + (lane & 3));
-    eval_group(h, c, zq[7], zq[8], eval_tab_group(tab, EVAL_TAB_L5 + (lane & 3)));
+    eval_group_unpack(gt, gp5);
+    eval_group(h, c, zt[2], zt[3], gt);
     if (u < 4) eval_park(hx0, 4 * b + u, h);
     eval_children(c, hx0, b);
-    eval_group(h, c, zq[9], zq[10], eval_tab_group(tab, EVAL_TAB_L6));
-    Fr y; eval_finish(y, h, Sb, z_in[mine], zq[11]);              // canonical integer value of y
+    eval_group_unpack(gt, gp6);
+    eval_group(h, c, zt[4], zt[5], gt);
+    Fr y; eval_finish(y, h, Sb, zmine, zt[6]);                    // canonical integer value of y
     if (u == 0 && mine_raw < n_total) {
         if (records) {
             uint32_t yw[8]; limbs_to_words<NFR, 8>(yw, y.l);
