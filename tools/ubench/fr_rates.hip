@@ -10,7 +10,10 @@
 #include "eval_core.h"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int OP> __global__ void __launch_bounds__(256) bench(unsigned *sink, int iters) {
+#ifndef FR_RATES_WAVES
+#define FR_RATES_WAVES 1      // -DFR_RATES_WAVES=3 / 4: the register budget of three / four waves per SIMD (168 / 128), so that those columns are real
+#endif
+template <int OP> __global__ void __launch_bounds__(256, FR_RATES_WAVES) bench(unsigned *sink, int iters) {
     extern __shared__ unsigned pad[];
     const unsigned a0 = threadIdx.x * 2654435761u + 1, a1 = a0 ^ 0x9e3779b9u;
     uint32_t pw[4][8];
