@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64) k_challenge_from_digest(const uint8_t *dig
 // 4-6 (16, 4, 1 groups) run on wave 0 for the workgroup's four blobs.  y comes out as the canonical integer with no conversion.
 // Loads: a lane needs the 128 contiguous bytes of its group, but a load instruction whose lanes are 128 bytes apart touches 64
 // cache lines for 1 KiB.  The wave instead moves its 8 KiB per step with 8 fully coalesced global -> LDS loads
-// (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~2,000 instructions
+// (global_load_lds_dwordx4: no VGPR staging, so the next step's data is in flight during this step's ~1,250 instructions
 // without costing registers -- staging it in VGPRs spilled to scratch, and waiting for a scratch reload waits for every older
 // load too: 59 % of the wave cycles were s_waitcnt).  The LDS side of such a load is linear (lane L of instruction q lands in
 // slot 64 q + L), so the bank-spreading XOR is applied on the global side: slot 8 g + s receives chunk 8 g + (s ^ (g & 7)) of
@@ -257,11 +257,6 @@ __device__ __forceinline__ void eval_tab_load(EvalPiece p[7], const EvalPiece *t
     const uint4 *src = reinterpret_cast<const uint4 *>(tab);
 #pragma unroll
     for (int q = 0; q < 7; q++) { const uint4 v = src[eval_tab_piece(e, q)]; p[q].w[0] = v.x; p[q].w[1] = v.y; p[q].w[2] = v.z; p[q].w[3] = v.w; }
-}
-__device__ __forceinline__ EvalGroup eval_tab_group(const EvalPiece *tab, int e) {
-    EvalPiece p[7]; eval_tab_load(p, tab, e);
-    EvalGroup g; eval_group_unpack(g, p);
-    return g;
 }
 __device__ __forceinline__ void eval_park(uint32_t *hx, int entry, const Fr &h) {
 #pragma unroll
