@@ -146,7 +146,8 @@ def _worker(rank, world, port, blobs, cs, ps, q, exchange, engine_kind="records"
 
 @pytest.mark.parametrize("world,exchange,engine_kind", [(2, "alltoall", "records"), (2, "allgather", "records"), (8, "alltoall", "records"), (8, "allgather", "records"),
                                                        (2, "alltoall", "words"), (2, "allgather", "words"), (4, "allgather", "words"), (4, "alltoall", "words"),
-                                                       (2, "allgather_split", "words"), (4, "allgather_split", "words"), (2, "allgather_split", "records")])
+                                                       (2, "allgather_split", "words"), (4, "allgather_split", "words"), (2, "allgather_split", "records"),
+                                                       (3, "alltoall", "words"), (3, "allgather_split", "words")])      # an odd world: one batch per rank
 def test_sharded_verify_gloo(world, exchange, engine_kind):
     """both exchanges: the all-to-all with stage 2 split by batch, and BASELINE.json's single all-gather with stage 2 replicated; at world 8
     (config 5's rank count) the three batches fall to ranks 2, 5 and 7 -- five ranks with an empty share of the batches"""
