@@ -79,7 +79,8 @@ int kzg355_load_trusted_setup_devices(const uint8_t *g1_bytes, size_t n1, const 
  * numeric field unless stated otherwise.  The dispatch thresholds default to multiples of the device's compute-unit count -- the
  * measured crossovers of the 256-CU MI355X scaled to the device at hand.  The KZG355_* environment variables named
  * below are TEST / EXPERIMENT overrides: only kzg355_load_trusted_setup, _devices and _file read them (through
- * kzg355_options_from_env); kzg355_load_trusted_setup_ex takes what it is given and reads no environment. */
+ * kzg355_options_from_env, the library's one reader of the environment beside the KZG355_DEBUG* switches and KZG355_DEVICES, all in csrc/options.hip);
+ * kzg355_load_trusted_setup_ex takes what it is given and reads no environment. */
 typedef struct kzg355_options {
     size_t struct_size;        /* sizeof(kzg355_options) as the caller compiled it */
     int device;                /* device ordinal; -1: the calling thread's current device                                   KZG355_DEVICE */
@@ -122,6 +123,11 @@ typedef struct kzg355_options {
     int host_hash_device_max_blobs; /* DEVICE-RESIDENT verify / blob-proof calls (the *_device entry points) of up to this many blobs copy their blobs back
                                   to the host (8 MiB = 0.16 ms per 64) and hash the challenges on the host threads instead of the 3.7 ms device
                                   chain: 0 = 1024 (measured crossover ~1500: profiles/r05/device_host_hash_crossover.txt), -1 never; host_hash = -1 turns it off as well                          KZG355_HOST_HASH_DEVICE_MAX */
+    int quotient_form;         /* k_quotient_tree's leaves per lane as a power of two: 0 by size (2 below 512 blobs, else 4); 2 / 4 / 6 pin one (tuning knob
+                                  and test hook)                                                                          KZG355_QUOTIENT_FORM */
+    int miller_segments;       /* few batches: segments per Miller loop of the multi-wave pairing form, two waves each: 0 = 2; 1 .. 4   KZG355_MILLER_SEGMENTS */
+    int force_multi;           /* test hook: a device list of ONE device still builds the multi-device handle (replica list, exchange)    KZG355_FORCE_MULTI=1 */
+    int force_sharded;         /* test hook: a multi-device handle cuts EVERY batch into per-device blocks, whatever the batch count     KZG355_FORCE_SHARDED=1 */
 } kzg355_options;
 void kzg355_options_default(kzg355_options *options);
 void kzg355_options_from_env(kzg355_options *options);     /* defaults, then the KZG355_* overrides listed above */
@@ -167,6 +173,21 @@ int kzg355_compute_blob_kzg_proof_many(uint8_t *out /* n*48 */, int *status, con
 int kzg355_verify_blob_kzg_proof_batch_many(bool *ok /* groups */, int *status /* groups */, const uint8_t *blobs, const uint8_t *commitments,
                                             const uint8_t *proofs, size_t n_per_group, size_t groups, const kzg355_settings *s);
 
+/* n independent verify_kzg_proof calls (kzg.rs:1039 -> 429-443; benches/kzg_benches.rs:70-81 times one per call): ok[i] / status[i] per check
+ * (status may be NULL), the inputs of check i at commitments + 48 i, zs + 32 i, ys + 32 i, proofs + 48 i.  A bad point or a non-canonical z / y is
+ * that check's KZG355_BADARGS; the others are unaffected.  Returns the first non-OK status.  One set of kernel launches per 2^17 checks: four
+ * scalar-multiplication ladder lanes and twelve pairing lanes per check instead of a 1.9 ms latency-bound chain per call. */
+int kzg355_verify_kzg_proof_many(bool *ok /* n */, int *status /* n or NULL */, const uint8_t *commitments /* n*48 */, const uint8_t *zs /* n*32 */,
+                                 const uint8_t *ys /* n*32 */, const uint8_t *proofs /* n*48 */, size_t n, const kzg355_settings *s);
+/* n independent verify_blob_kzg_proof calls (kzg.rs:1050 -> 547-569): = kzg355_verify_blob_kzg_proof_batch_many with one blob per batch (the
+ * batch equation with r^0 = 1 is the single check, kzg.rs:658-660). */
+int kzg355_verify_blob_kzg_proof_many(bool *ok /* n */, int *status /* n or NULL */, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs,
+                                      size_t n, const kzg355_settings *s);
+/* n independent compute_kzg_proof calls (kzg.rs:1021 -> 446-457): proof i and y_i = p_i(z_i) for blob i at the caller's point zs + 32 i.  A
+ * non-canonical z_i or blob is that unit's KZG355_BADARGS; outputs of a unit are written only on its KZG355_OK. */
+int kzg355_compute_kzg_proof_many(uint8_t *proofs_out /* n*48 */, uint8_t *ys_out /* n*32 */, int *status /* n or NULL */, const uint8_t *blobs,
+                                  const uint8_t *zs /* n*32 */, size_t n, const kzg355_settings *s);
+
 /* ---- device-resident inputs (what bench.py times: blobs already in HBM) ----------------------- */
 /* As above, but d_* are DEVICE pointers (hipMalloc / torch tensors .data_ptr()) on the settings' device.
  * ok / status are host pointers.  Synchronous: returns when the verdicts are on the host. */
@@ -187,6 +208,13 @@ int kzg355_blob_to_kzg_commitment_many_device(uint8_t *out /* host n*48 */, int 
                                               const kzg355_settings *s);
 int kzg355_compute_blob_kzg_proof_many_device(uint8_t *out /* host n*48 */, int *status, const uint8_t *d_blobs, const uint8_t *d_commitments,
                                               size_t n, const kzg355_settings *s);
+
+/* The *_many forms of the single-proof functions on device memory: d_records = n records C_i | z_i | y_i | proof_i of KZG355_BYTES_PER_RECORD bytes
+ * (16-byte aligned; = kzg355_verify_records_checked_device with one record per batch); d_blobs / d_zs as the host forms lay them out.  (n independent
+ * verify_blob_kzg_proof checks on device memory are kzg355_verify_blob_kzg_proof_batch_many_device with n_per_group = 1.) */
+int kzg355_verify_kzg_proof_many_device(bool *ok /* host n */, int *status /* host n or NULL */, const uint8_t *d_records, size_t n, const kzg355_settings *s);
+int kzg355_compute_kzg_proof_many_device(uint8_t *proofs_out /* host n*48 */, uint8_t *ys_out /* host n*32 */, int *status, const uint8_t *d_blobs,
+                                         const uint8_t *d_zs /* n*32 */, size_t n, const kzg355_settings *s);
 
 /* ---- sharded verification (one process per GPU; the exchange between the two stages is the caller's
  *      exchange of the 160-byte records, e.g. torch.distributed over RCCL) --------------------------- */

@@ -161,6 +161,67 @@ struct Kzg {
         if (rc) return from_status(rc, "verify_blob_kzg_proof_batch");
         return ok;
     }
+
+    // ---- throughput extensions (no reference counterpart): many independent single-proof units per call; one Result per unit, an Err of the
+    // call itself only for whole-call failures (no device, out of memory, a length mismatch)
+    static bool whole_call_failed(int rc, const std::vector<int> &st) {
+        if (rc == KZG355_INTERNAL || rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return true;
+        if (rc == KZG355_OK) return false;
+        for (int x : st) if (x) return false;
+        return true;
+    }
+    static Result<std::vector<Result<bool>>> verify_kzg_proof_many(const std::vector<KzgCommitment> &cs, const std::vector<Bytes32> &zs,
+                                                                   const std::vector<Bytes32> &ys, const std::vector<KzgProof> &ps, const KzgSettings &s) {
+        const size_t n = cs.size();
+        if (zs.size() != n || ys.size() != n || ps.size() != n) return Error{Error::BadArgs, "length mismatch"};
+        std::vector<uint8_t> c(n * 48 + 1), z(n * 32 + 1), y(n * 32 + 1), p(n * 48 + 1);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&c[i * 48], cs[i].data(), 48); std::memcpy(&z[i * 32], zs[i].data(), 32);
+            std::memcpy(&y[i * 32], ys[i].data(), 32); std::memcpy(&p[i * 48], ps[i].data(), 48);
+        }
+        std::unique_ptr<bool[]> ok(new bool[n + 1]());
+        std::vector<int> st(n, 0);
+        int rc = kzg355_verify_kzg_proof_many(ok.get(), st.data(), c.data(), z.data(), y.data(), p.data(), n, s.raw());
+        if (whole_call_failed(rc, st)) return from_status(rc, "verify_kzg_proof_many");
+        std::vector<Result<bool>> out;
+        for (size_t i = 0; i < n; i++) { if (st[i]) out.emplace_back(from_status(st[i], "verify")); else out.emplace_back(ok[i]); }
+        return out;
+    }
+    static Result<std::vector<Result<bool>>> verify_blob_kzg_proof_many(const std::vector<Blob> &blobs, const std::vector<KzgCommitment> &cs,
+                                                                        const std::vector<KzgProof> &ps, const KzgSettings &s) {
+        const size_t n = blobs.size();
+        if (cs.size() != n || ps.size() != n) return Error{Error::BadArgs, "length mismatch"};
+        std::vector<uint8_t> b(n * BYTES_PER_BLOB + 1), c(n * 48 + 1), p(n * 48 + 1);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&b[i * BYTES_PER_BLOB], blobs[i].data(), BYTES_PER_BLOB); std::memcpy(&c[i * 48], cs[i].data(), 48);
+            std::memcpy(&p[i * 48], ps[i].data(), 48);
+        }
+        std::unique_ptr<bool[]> ok(new bool[n + 1]());
+        std::vector<int> st(n, 0);
+        int rc = kzg355_verify_blob_kzg_proof_many(ok.get(), st.data(), b.data(), c.data(), p.data(), n, s.raw());
+        if (whole_call_failed(rc, st)) return from_status(rc, "verify_blob_kzg_proof_many");
+        std::vector<Result<bool>> out;
+        for (size_t i = 0; i < n; i++) { if (st[i]) out.emplace_back(from_status(st[i], "verify")); else out.emplace_back(ok[i]); }
+        return out;
+    }
+    static Result<std::vector<Result<std::pair<KzgProof, Bytes32>>>> compute_kzg_proof_many(const std::vector<Blob> &blobs, const std::vector<Bytes32> &zs,
+                                                                                           const KzgSettings &s) {
+        const size_t n = blobs.size();
+        if (zs.size() != n) return Error{Error::BadArgs, "length mismatch"};
+        std::vector<uint8_t> b(n * BYTES_PER_BLOB + 1), z(n * 32 + 1), pr(n * 48 + 1), ys(n * 32 + 1);
+        for (size_t i = 0; i < n; i++) { std::memcpy(&b[i * BYTES_PER_BLOB], blobs[i].data(), BYTES_PER_BLOB); std::memcpy(&z[i * 32], zs[i].data(), 32); }
+        std::vector<int> st(n, 0);
+        int rc = kzg355_compute_kzg_proof_many(pr.data(), ys.data(), st.data(), b.data(), z.data(), n, s.raw());
+        if (whole_call_failed(rc, st)) return from_status(rc, "compute_kzg_proof_many");
+        std::vector<Result<std::pair<KzgProof, Bytes32>>> out;
+        for (size_t i = 0; i < n; i++) {
+            if (st[i]) { out.emplace_back(from_status(st[i], "proof")); continue; }
+            KzgProof p; Bytes32 y;
+            std::memcpy(p.bytes.data(), &pr[i * 48], 48); std::memcpy(y.bytes.data(), &ys[i * 32], 32);
+            out.emplace_back(std::make_pair(p, y));
+        }
+        return out;
+    }
 };
 
 }  // namespace kzg355

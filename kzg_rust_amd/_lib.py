@@ -17,7 +17,8 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_size_t)] + [(name, C.c_int) for name in (
         "device", "msm_bits", "msm_require_wide", "self_test", "host_threads", "host_hash", "host_hash_max_blobs", "host_sha", "host_rhash", "host_rhash_max_records", "challenge_form",
         "lincomb_form", "pairing_lane", "pairing_two_wave_upto", "lc_chain_from", "rhash_lanes_from", "beside_max_blobs", "split_parts",
-        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "msm_glv", "msm_eager", "pairing_hard12_from", "submit_sets", "host_hash_device_max_blobs")]
+        "split_streams", "chunk_mb", "chunks_in_flight", "staging_ring", "exchange", "verify_only", "msm_glv", "msm_eager", "pairing_hard12_from", "submit_sets", "host_hash_device_max_blobs", "quotient_form",
+        "miller_segments", "force_multi", "force_sharded")]
 
 
 def load():
@@ -55,6 +56,11 @@ def load():
         "kzg355_blob_to_kzg_commitment_many": [u8p, ip, u8p, sz, vp],
         "kzg355_compute_blob_kzg_proof_many": [u8p, ip, u8p, u8p, sz, vp],
         "kzg355_verify_blob_kzg_proof_batch_many": [bp, ip, u8p, u8p, u8p, sz, sz, vp],
+        "kzg355_verify_kzg_proof_many": [bp, ip, u8p, u8p, u8p, u8p, sz, vp],
+        "kzg355_verify_blob_kzg_proof_many": [bp, ip, u8p, u8p, u8p, sz, vp],
+        "kzg355_compute_kzg_proof_many": [u8p, u8p, ip, u8p, u8p, sz, vp],
+        "kzg355_verify_kzg_proof_many_device": [bp, ip, vp, sz, vp],
+        "kzg355_compute_kzg_proof_many_device": [u8p, u8p, ip, vp, vp, sz, vp],
         "kzg355_verify_blob_kzg_proof_batch_many_device": [bp, ip, vp, vp, vp, sz, sz, vp],
         "kzg355_blob_to_kzg_commitment_many_device": [u8p, ip, vp, sz, vp],
         "kzg355_compute_blob_kzg_proof_many_device": [u8p, ip, vp, vp, sz, vp],
@@ -121,4 +127,6 @@ EXPORTED_SYMBOLS = [
     "kzg355_options_default", "kzg355_options_from_env", "kzg355_load_trusted_setup_ex", "kzg355_debug_verify_sharded_intermediates",
     "kzg355_verify_blob_kzg_proof_batch_many_device_submit", "kzg355_verify_collect", "kzg355_settings_msm_shape", "kzg355_settings_build_msm_table",
     "kzg355_verify_shard_records_points_words_device", "kzg355_verify_records_points_words_device",
+    "kzg355_verify_kzg_proof_many", "kzg355_verify_blob_kzg_proof_many", "kzg355_compute_kzg_proof_many", "kzg355_verify_kzg_proof_many_device",
+    "kzg355_compute_kzg_proof_many_device",
 ]

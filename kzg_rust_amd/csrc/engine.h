@@ -36,11 +36,14 @@
 
 using namespace kzg;
 
+// KZG355_DEBUG / KZG355_DEBUG_PIPE (debug switches; read once, in options.hip like every other environment variable)
+namespace kzg355_impl { bool debug_errors(); bool debug_pipe(); }
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) {                                                                        \
-            if (getenv("KZG355_DEBUG")) fprintf(stderr, "kzg355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            if (::kzg355_impl::debug_errors()) fprintf(stderr, "kzg355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             return _e == hipErrorOutOfMemory ? KZG355_NO_MEMORY                                       \
                    : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? KZG355_NO_DEVICE : KZG355_DEVICE_ERROR; \
         }                                                                                              \
@@ -146,7 +149,7 @@ struct kzg355_settings {
     bool lane_pairing = false;
     int split_parts = 1, split_streams = 2;   // KZG355_SPLIT=parts[,streams]: device-resident verify calls as several overlapped launch sets (default: one)
     int challenge_form = 0;   // 0 by size, 1 one-wave kernel, 2 two-wave kernel (KZG355_CHALLENGE=1w|2w)
-    int quotient_form = 0;    // k_quotient_tree: 0 by size, 2 / 4 / 6 = 2^form leaves per lane (KZG355_QUOTIENT_FORM: tuning knob and test hook, not an option)
+    int quotient_form = 0;    // k_quotient_tree: 0 by size, 2 / 4 / 6 = 2^form leaves per lane (kzg355_options.quotient_form: tuning knob and test hook)
     // batches per launch set from which the bucket form ends in one Horner chain per class (KZG355_LC_CHAIN_FROM).  Round 4, with the chain walked by quads and
     // sets kept in flight (blobs/s, three sets in flight, 16 chains per class against one): 512 batches 2.81 M either way, 1024 3.99 -> 4.03 M, 2048 4.14 ->
     // 4.26 M, 4096 4.25 -> 4.36 M (profiles/r04/chain_from_sweep.txt); one set at a time it is within +-2 % from 512 to 4096
@@ -158,7 +161,7 @@ struct kzg355_settings {
     int beside_max_blobs = 16384;  // blobs per launch set up to which the point kernels run on side streams beside the hash chain (64 per CU)
     int cu_count = 256;            // compute units of the device: the thresholds above and below are multiples of it (load_on_device)
     int pairing_two_wave_upto = 256;     // batches per launch set up to which a pairing runs its two Miller loops on two waves (1 per CU)
-    // ... and on how many segments per loop (k_pairing_coop_split; 0: launch_pairing's default; KZG355_MILLER_SEGMENTS=1..4)
+    // ... and on how many segments per loop (k_pairing_coop_split; 0: launch_pairing's default; kzg355_options.miller_segments = 1..4)
     int miller_segments = 0;
     // batches per launch set from which the final exponentiation's hard part runs twelve lanes per check (16 per CU; KZG355_PAIRING_HARD12_FROM, 0: never)
     int pairing_hard12_from = 4096;
@@ -173,9 +176,9 @@ struct kzg355_settings {
     std::atomic<int> tickets_out{0};                              // submitted and not yet collected
     // kzg355_free_trusted_setup came while tickets were out (the caller's bug): the handle stays alive until the last of them is collected (under pipe_mu)
     bool free_deferred = false;
-    bool own_side_streams = true;    // side streams per workspace (round 4; KZG355_SIDE=shared: one pair per handle, round 3's form) -- measured with
-                                     // 4 threads of n = 64 calls: median call 5.0-7.9 ms shared, 3.6-5.2 ms own (4 hardware queues), 2.5-3.9 ms own with 8
-                                     // queues
+    // side streams are per workspace (round 4; measured with 4 threads of n = 64 calls: median call 5.0-7.9 ms with one pair per handle, 3.6-5.2 ms own with 4
+    // hardware queues, 2.5-3.9 ms with 8); the handle's shared pair is the fallback when a stream cannot be created
+    bool force_sharded = false;      // test hook (kzg355_options.force_sharded): a multi-device handle shards every batch
     std::atomic<int> calls_in_flight{0};   // host-buffer calls inside host_pipeline right now
     int hw_queues = 4;                     // GPU_MAX_HW_QUEUES as the process has it when the handle is loaded (the runtime's default is 4)
     // 0 by size; 1: every submitted set on its workspace's own stream; 2: two-stage software pipeline over pipe_main / pipe_tail (KZG355_SUBMIT=sets|pipeline)
@@ -281,7 +284,7 @@ inline bool is_small(const kzg355_settings *s) { return s->t.n_fe != N_FE; }
 inline size_t blob_bytes_of(const kzg355_settings *s) { return (size_t)32 * s->t.n_fe; }
 
 // which form the batch linear combination takes (KZG355_LINCOMB pins it: 1 window, 2 bucket, 3 pre-shifted)
-enum { LC_FORM_WINDOW = 1, LC_FORM_BUCKET = 2, LC_FORM_PRESHIFT = 3 };
+enum { LC_FORM_WINDOW = 1, LC_FORM_BUCKET = 2, LC_FORM_PRESHIFT = 3, LC_FORM_SINGLE = 4 /* one record per batch, many batches: never pinned, chosen by shape */ };
 
 // ---- stage drivers (all asynchronous on w->stream) -------------------------------------------------
 // Host-hashed challenges of a small host-buffer call (host_sha256.h): a job on the handle's host threads is writing the digests of
@@ -316,11 +319,13 @@ struct HostFront {
 //                     for host memory bandwidth; kept for hosts where page locking is expensive.
 // Results are collected in chunk order; a failure waits for everything in flight before the workspaces go back to the pool.
 struct HostCall {
-    int kind;                        // 0 verify, 1 commit, 2 blob proof
+    int kind;                        // 0 verify, 1 commit, 2 blob proof, 3 proof at a given z per blob (compute_kzg_proof: `commitments` is null, zs / ys_out set)
     const uint8_t *blobs, *commitments, *proofs;
     size_t npg;                      // blobs per unit
     bool *ok; uint8_t *out48; int *status;
     uint8_t *records_out = nullptr;  // verify, single-chunk calls only (kzg355_debug_verify_host_records): the stage-1 records, copied back after the chunk
+    const uint8_t *zs = nullptr;     // kind 3: units x 32 bytes, the evaluation points (kzg.rs:446-457)
+    uint8_t *ys_out = nullptr;       // kind 3: units x 32 bytes, y = p(z) of every unit whose status is OK
 };
 
 // ---- shared functions (definitions: see the file list at the top)
@@ -356,9 +361,13 @@ int verify_many_device_impl(bool *ok, int *status, const uint8_t *d_blobs, const
 int ensure_wide_table(kzg355_settings *s);
 int msm_to_host(kzg355_settings *s, Workspace *w, Timed &tm, int n, const uint8_t *d_blobs, const Fr *d_scalars);
 int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, int n);
-int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, HostFront *hf = nullptr);
-int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n);
-int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs);
+// d_zs (device, n x 32 bytes, or null): proofs at these points instead of each blob's Fiat-Shamir challenge (compute_kzg_proof; d_c is then null), and
+// the n values y = p(z) go back next to the proofs (msm_op_collect's ys_out)
+int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, HostFront *hf = nullptr,
+                   const uint8_t *d_zs = nullptr);
+int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n, uint8_t *ys_out = nullptr);
+int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs,
+                            const uint8_t *d_zs = nullptr, uint8_t *ys_out = nullptr);
 int stage_to_device(Workspace *w, DevBuf &dst, const uint8_t *src, size_t bytes);
 int stage_via_pinned(kzg355_settings *s, Workspace *w, PinBuf &pin, size_t pin_off, DevBuf &dst, const uint8_t *src, size_t bytes);
 int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs);
@@ -416,6 +425,7 @@ struct kzg355_ticket {
 
 namespace kzg355_impl {
 kzg355_options options_of(const kzg355_options *opt);
+std::vector<int> env_device_list();      // KZG355_DEVICES=0,1,...: the device list of kzg355_load_trusted_setup (options.hip)
 int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, int dev_or_minus1, const kzg355_options &opt, kzg355_settings **out);
 void free_single(kzg355_settings *s);
 std::vector<kzg355_settings *> replicas_of(kzg355_settings *s);

@@ -31,7 +31,7 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
     auto refuse = [&](int code) { for (size_t i = 0; i < groups; i++) status[i] = code; return code; };
     if (n_local > (size_t)1 << 24 || groups > (size_t)1 << 24 || n_local * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
     if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || !d_blobs || ((uintptr_t)d_blobs & 15) || !d_commitments ||
-            !d_proofs) return refuse(KZG355_BADARGS);
+            !d_proofs || ((uintptr_t)d_words & 3)) return refuse(KZG355_BADARGS);      // (before anything is queued: a refusal leaves no work in flight)
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
@@ -53,7 +53,6 @@ static int shard_records_impl(uint8_t *d_records, uint8_t *d_points, int *status
                          via_host ? &hf : nullptr))) return rc;
     if ((rc = join_side(w))) return rc;
     if (d_words) {                                                // statuses stay on the device: no copy back, the caller reads them after its merge
-        if ((uintptr_t)d_words & 3) return KZG355_BADARGS;
         launch_status_words(w->err.as<int>(), nullptr, d_words, (int)groups, w->stream);
         HIPCHK(hipStreamSynchronize(w->stream));
         w->in_flight = false;
@@ -82,7 +81,7 @@ static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8
     if (n == 0) return refuse(KZG355_BADARGS);                   // verify_kzg_proof_batch: n == 0 is an error (kzg.rs:588-592)
     if (n > (size_t)1 << 24 || groups > (size_t)1 << 24 || n * groups > (size_t)1 << 24) return refuse(KZG355_BADARGS);
     // the kernels read the records 16 bytes at a time
-    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3)) return refuse(KZG355_BADARGS);
+    if (!d_records || ((uintptr_t)d_records & 15) || ((uintptr_t)d_points & 3) || ((uintptr_t)d_words & 3)) return refuse(KZG355_BADARGS);
     WsGuard g(cs);
     if (!g.w) return KZG355_NO_DEVICE;
     kzg355_settings *s = g.s; Workspace *w = g.w;
@@ -115,7 +114,6 @@ static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8
     }
     // 1 + ok + 256 * status per batch, left on the device (the sharded path's all-reduce takes them from there)
     if (d_words) {
-        if ((uintptr_t)d_words & 3) return KZG355_BADARGS;
         launch_status_words(w->err.as<int>(), w->ok.as<int>(), d_words, G, w->stream);
         HIPCHK(hipStreamSynchronize(w->stream));
         w->in_flight = false;
@@ -134,6 +132,35 @@ static int verify_records_impl(bool *ok, int *status, uint8_t *dump, const uint8
         if (status) status[i] = st;
         if (st == KZG355_OK) ok[i] = w->h_ok.as<int>()[i] != 0;
         else if (first == KZG355_OK) first = st;
+    }
+    return first;
+}
+
+// n independent verify_kzg_proof checks from host arrays, on the one device of `cs` (a replica of a multi-device handle included).  The four arrays
+// become the 160-byte records C | z | y | proof (the layout stage 2 reads: utils.rs:454-463) in a pinned slot, in launch sets of at most 2^17 checks
+// (21 MB of records, ~0.8 GB of scratch); the staging workspace only lends its buffers, the checks run on a second one.
+int verify_proofs_on_one_device(bool *ok, int *status, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys, const uint8_t *proofs, size_t n,
+                                const kzg355_settings *cs) {
+    WsGuard g(cs);
+    if (!g.w) return KZG355_NO_DEVICE;
+    Workspace *w = g.w;
+    const size_t SET = (size_t)1 << 17;
+    int first = KZG355_OK, rc;
+    for (size_t lo = 0; lo < n; lo += SET) {
+        const size_t cnt = n - lo < SET ? n - lo : SET;
+        if ((rc = w->h_records.ensure((size_t)RECORD_BYTES * cnt)) || (rc = w->records.ensure((size_t)RECORD_BYTES * cnt))) return rc;
+        uint8_t *rec = w->h_records.as<uint8_t>();
+        for (size_t i = 0; i < cnt; i++, rec += RECORD_BYTES) {
+            memcpy(rec, commitments + 48 * (lo + i), 48); memcpy(rec + 48, zs + 32 * (lo + i), 32); memcpy(rec + 80, ys + 32 * (lo + i), 32);
+            memcpy(rec + 112, proofs + 48 * (lo + i), 48);
+        }
+        w->in_flight = true;
+        HIPCHK(hipMemcpyAsync(w->records.p, w->h_records.p, (size_t)RECORD_BYTES * cnt, hipMemcpyHostToDevice, w->stream));
+        HIPCHK(hipStreamSynchronize(w->stream));
+        w->in_flight = false;
+        rc = verify_records_impl(ok + lo, status ? status + lo : nullptr, nullptr, w->records.as<uint8_t>(), 1, cnt, 1, cs);
+        if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR || rc == KZG355_INTERNAL) return rc;
+        if (rc != KZG355_OK && first == KZG355_OK) first = rc;
     }
     return first;
 }
@@ -385,6 +412,60 @@ int kzg355_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_
     int st = status_from_err(w->h_err.as<int>()[0]);
     if (st == KZG355_OK) *ok = w->h_ok.as<int>()[0] != 0;
     return st;
+}
+
+// ---- *_many forms of the single-proof functions (the reference benches one proof per call, benches/kzg_benches.rs:58-91; a GPU wants many)
+int kzg355_verify_kzg_proof_many_device(bool *ok, int *status, const uint8_t *d_records, size_t n, const kzg355_settings *cs) {
+    // n "batches" of one record each, full input validation: verify_kzg_proof (kzg.rs:429-443) per record
+    return verify_records_impl(ok, status, nullptr, d_records, 1, n, 1, cs);
+}
+
+int kzg355_verify_kzg_proof_many(bool *ok, int *status, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys, const uint8_t *proofs, size_t n,
+                                 const kzg355_settings *cs) {
+    if (!cs || !ok) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (!commitments || !zs || !ys || !proofs || n > (size_t)1 << 24) return KZG355_BADARGS;
+    if (cs->multi && cs->multi->rep.size() > 1 && n >= cs->multi->rep.size()) {      // independent checks: contiguous ranges per device
+        MultiDev *m = cs->multi;
+        return fan_out(m->rep.size(), n, [&](size_t d, size_t i0, size_t cnt) -> int {
+            if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
+            return verify_proofs_on_one_device(ok + i0, status ? status + i0 : nullptr, commitments + 48 * i0, zs + 32 * i0, ys + 32 * i0, proofs + 48 * i0, cnt,
+                    m->rep[d]);
+        });
+    }
+    return verify_proofs_on_one_device(ok, status, commitments, zs, ys, proofs, n, cs);
+}
+
+int kzg355_verify_blob_kzg_proof_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t *commitments, const uint8_t *proofs, size_t n,
+                                      const kzg355_settings *cs) {
+    // n batches of one blob: the batch equation with r^0 = 1 is verify_blob_kzg_proof's check (kzg.rs:547-569, 658-660)
+    return kzg355_verify_blob_kzg_proof_batch_many(ok, status, blobs, commitments, proofs, 1, n, cs);
+}
+
+int kzg355_compute_kzg_proof_many_device(uint8_t *proofs_out, uint8_t *ys_out, int *status, const uint8_t *d_blobs, const uint8_t *d_zs, size_t n,
+                                         const kzg355_settings *cs) {
+    if (!d_zs || !ys_out) return KZG355_BADARGS;
+    return msm_op_many_device_impl(proofs_out, status, d_blobs, nullptr, n, cs, d_zs, ys_out);
+}
+
+int kzg355_compute_kzg_proof_many(uint8_t *proofs_out, uint8_t *ys_out, int *status, const uint8_t *blobs, const uint8_t *zs, size_t n,
+                                  const kzg355_settings *cs) {
+    if (!cs || !proofs_out || !ys_out) return KZG355_BADARGS;
+    if (n == 0) return KZG355_OK;
+    if (!blobs || !zs || n > (size_t)1 << 20) return KZG355_BADARGS;
+    if (cs->multi && cs->multi->rep.size() > 1 && n >= cs->multi->rep.size()) {
+        MultiDev *m = cs->multi;
+        const size_t BB = blob_bytes_of(cs);
+        return fan_out(m->rep.size(), n, [&](size_t d, size_t i0, size_t cnt) -> int {
+            if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
+            HostCall hc{3, blobs + BB * i0, nullptr, nullptr, 1, nullptr, proofs_out + 48 * i0, status ? status + i0 : nullptr};
+            hc.zs = zs + 32 * i0; hc.ys_out = ys_out + 32 * i0;
+            return host_pipeline(hc, cnt, m->rep[d]);
+        });
+    }
+    HostCall hc{3, blobs, nullptr, nullptr, 1, nullptr, proofs_out, status};
+    hc.zs = zs; hc.ys_out = ys_out;
+    return host_pipeline(hc, n, cs);
 }
 
 int kzg355_blob_to_kzg_commitment_many(uint8_t *out, int *status, const uint8_t *blobs, size_t n, const kzg355_settings *cs) {

@@ -67,14 +67,14 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         const size_t u0 = pend[slot].u0, cnt = pend[slot].cnt;
         pend[slot].cnt = 0;
         int rc = hc.kind == 0 ? verify_collect(w, tms[slot], hc.ok + u0, hc.status ? hc.status + u0 : nullptr, (int)cnt)
-                              : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt);
+                              : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt, hc.ys_out ? hc.ys_out + 32 * u0 : nullptr);
         if (hc.records_out && hc.kind == 0 && hipMemcpy(hc.records_out + (size_t)RECORD_BYTES * hc.npg * u0, w->records.p, (size_t)RECORD_BYTES * hc.npg * cnt,
                 hipMemcpyDeviceToHost) != hipSuccess) return KZG355_DEVICE_ERROR;
         if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return rc;
         if (rc != KZG355_OK && first == KZG355_OK) first = rc;
         return KZG355_OK;
     };
-    const bool dbg = getenv("KZG355_DEBUG_PIPE") != nullptr;
+    const bool dbg = debug_pipe();
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_wait = 0, t_stage = 0, t_enq = 0, t_alloc = 0;
     std::vector<hipEvent_t> dev_ev;                                  // debug only: H2D start / H2D end / kernels end per chunk
@@ -124,11 +124,13 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
             if (hc.commitments && (rc = stage_via_pinned(s, w, w->h_stage_cp, 0, w->commitments, hc.commitments + 48 * off, 48 * nb))) return rc;
             if (hc.proofs && (rc = stage_via_pinned(s, w, w->h_stage_cp, 48 * nb, w->proofs, hc.proofs + 48 * off, 48 * nb))) return rc;
         }
+        if (hc.kind == 3 && (rc = stage_to_device(w, w->small, hc.zs + 32 * off, 32 * nb))) return rc;      // the evaluation points (kzg.rs:446-457)
         t_stage += now() - t0; t0 = now();
         HostFront *hfp = hf.running ? &hf : nullptr;
         if (hc.kind == 0) rc = verify_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), w->commitments.as<uint8_t>(), w->proofs.as<uint8_t>(), (int)hc.npg,
                 (int)cnt, 0, 0, hfp, nchunks == 1);
-        else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt, hfp);
+        else rc = msm_op_enqueue(s, w, tms[slot], w->blobs.as<uint8_t>(), hc.kind == 2 ? w->commitments.as<uint8_t>() : nullptr, cnt, hfp,
+                hc.kind == 3 ? w->small.as<uint8_t>() : nullptr);
         if (rc) return rc;
         if (dbg && !direct) (void)hipEventRecord(dev_ev[3 * k + 2], w->stream);
         t_enq += now() - t0;

@@ -9,8 +9,6 @@
 #endif
 #include "kernels.h"
 #include "g1_quad.h"
-#include <cstdlib>
-#include <cstring>
 
 namespace kzg {
 
@@ -35,12 +33,6 @@ __device__ __forceinline__ void validate_points_body(const uint8_t *commitments,
 }
 __global__ void __launch_bounds__(256, 2) k_validate_points(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
                                                          G1Affine *pts, int *err, int stride) {
-    validate_points_body(commitments, proofs, n_total, n_per_group, pts, err, stride);
-}
-// VERDICT r4 item 9, one time-boxed attempt: the same body at ONE wave per SIMD, so that the 86 registers the two-wave form spills to scratch fit the
-// 512-register budget (the allocator parks them in AGPRs).  KZG355_VALIDATE_FORM=1w selects it; the measurement is in DESIGN.md section 8.
-__global__ void __launch_bounds__(256, 1) k_validate_points_w1(const uint8_t *commitments, const uint8_t *proofs, int n_total, int n_per_group,
-                                                            G1Affine *pts, int *err, int stride) {
     validate_points_body(commitments, proofs, n_total, n_per_group, pts, err, stride);
 }
 
@@ -246,6 +238,48 @@ __global__ void __launch_bounds__(64) k_lincomb_finish(const G1Jac *partials, in
     for (int wv = 0; wv < wpg; wv++) { G1Jac v = partials[((size_t)g * wpg + wv) * 2 + c]; g1_add(acc, acc, v); }
     PairPt a; pairpt_from_jac(a, acc, c == 0);                // pairings_verify negates its first G1 argument (utils.rs:198-201)
     pair_pts[2 * (size_t)g + c] = a;
+}
+
+// ------------------------------------------------------------------------------------------------ lincomb, one record per check
+// MANY independent single-proof checks (verify_kzg_proof kzg.rs:409-426, verify_blob_kzg_proof kzg.rs:547-569; the *_many entry points): with one
+// record per "batch" the equation has r^0 = 1, so proof_lincomb IS the proof and rhs = C + [z] proof + [y](-G) -- two scalar multiplications, GLV-
+// split into four 128-bit ladders on four neighbouring lanes: 16 checks per wave.  (k_lincomb_terms with n = 1 walks two more ladders for the
+// scalars a_0 = 1 and keeps 8 of its 64 lanes busy.)  scal_b[g] = z, scal_c[g] = y as k_rpowers leaves them for n = 1.
+__global__ void __launch_bounds__(64) k_lincomb_single(const G1Affine *pts, const uint32_t *scal_b, const uint32_t *scal_c, int groups, PairPt *pair_pts,
+                                                        uint32_t *wtabs) {
+    const int lane = threadIdx.x, q = lane & 3;
+    const int g_raw = blockIdx.x * 16 + (lane >> 2);
+    const bool live = g_raw < groups;
+    const int g = live ? g_raw : groups - 1;                      // idle quads redo the last check (every lane takes part in the shuffles)
+    uint32_t *wtab = wtabs + (size_t)blockIdx.x * (W4_ENTRIES * 3 * NFP * 64);
+    const G1Affine *gp = pts + 2 * (size_t)g;                     // [0] commitment, [1] proof
+    G1Affine p; uint32_t k[8];
+    if (q < 2) { p = gp[1]; for (int w = 0; w < 8; w++) k[w] = scal_b[8 * (size_t)g + w]; }      // [z] proof       (kzg.rs:415-418 moved to the G1 side)
+    else {                                                                                        // [y] (-G)        (kzg.rs:421)
+        const uint32_t gx[NFP] = G1_GEN_X_INIT, gy[NFP] = G1_GEN_Y_INIT;
+        for (int w = 0; w < NFP; w++) { p.x.l[w] = gx[w]; p.y.l[w] = gy[w]; }
+        fp_neg(p.y, p.y);
+        for (int w = 0; w < 8; w++) k[w] = scal_c[8 * (size_t)g + w];
+    }
+    uint32_t ka[4], kb[4];
+    glv_split_fast(ka, kb, k);                                    // (z, y leave k_rpowers reduced below r < 2^255)
+    if (q & 1) { G1Affine t; g1a_neg_phi(t, p); p = t; }
+    G1Jac m;
+    g1_mul128_w4(m, p, (q & 1) ? kb : ka, wtab, lane);
+    // the four ladders of a check, then its commitment: one loop, one inlined instance of the complete addition
+    G1Jac c; g1_from_affine(c, gp[0]);
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        G1Jac o = g1_shfl_xor(m, it == 0 ? 1 : 2);
+        if (it == 2) o = c;
+        g1_add(m, m, o);
+    }
+    if (!live) return;
+    if (q == 0) { PairPt a; pairpt_from_jac(a, m, false); pair_pts[2 * (size_t)g + 1] = a; }
+    if (q == 1) {                                                 // pairings_verify negates its first G1 argument (utils.rs:198-201)
+        G1Jac pj; g1_from_affine(pj, gp[1]);
+        PairPt a; pairpt_from_jac(a, pj, true); pair_pts[2 * (size_t)g] = a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ lincomb, bucket form
@@ -768,10 +802,7 @@ __global__ void __launch_bounds__(64) k_ps_weights(const LcSlot *S, int groups, 
 void launch_validate_points(const uint8_t *d_commitments, const uint8_t *d_proofs, int n_total, int n_per_group, G1Affine *d_pts, int *d_err,
                             hipStream_t st, int stride) {
     if (n_total <= 0) return;
-    static const bool one_wave = [] { const char *e = getenv("KZG355_VALIDATE_FORM"); return e && strcmp(e, "1w") == 0; }();      // experiment knob
-    if (one_wave) hipLaunchKernelGGL(k_validate_points_w1, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group,
-            d_pts, d_err, stride);
-    else hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err,
+    hipLaunchKernelGGL(k_validate_points, dim3((2 * n_total + 255) / 256), dim3(256), 0, st, d_commitments, d_proofs, n_total, n_per_group, d_pts, d_err,
             stride);
 }
 // Test / audit readback of stage 2 (tests/test_gpu_parity.py): per batch  r (32 bytes big-endian, utils.rs:472) | proof_lincomb (48) |
@@ -829,6 +860,14 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
     uint32_t *d_wtabs = reinterpret_cast<uint32_t *>(d_partials + 2 * (size_t)wpg * groups);
     hipLaunchKernelGGL(k_lincomb_terms, dim3(groups * wpg), dim3(64), 0, st, d_pts, d_scal_a, d_scal_b, d_scal_c, n_per_group, d_partials, d_wtabs);
     hipLaunchKernelGGL(k_lincomb_finish, dim3(groups), dim3(64), 0, st, d_partials, n_per_group, d_pair_pts);
+}
+// n_per_group == 1, many groups: 16 checks per wave; d_scratch: lincomb_single_bytes(groups) (the per-wave window tables)
+size_t lincomb_single_bytes(int groups) { return sizeof(uint32_t) * W4_ENTRIES * 3 * NFP * 64 * (size_t)((groups + 15) / 16); }
+void launch_lincomb_single(const G1Affine *d_pts, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int groups, void *d_scratch, PairPt *d_pair_pts,
+                           hipStream_t st) {
+    if (groups <= 0) return;
+    hipLaunchKernelGGL(k_lincomb_single, dim3((groups + 15) / 16), dim3(64), 0, st, d_pts, d_scal_b, d_scal_c, groups, d_pair_pts,
+            reinterpret_cast<uint32_t *>(d_scratch));
 }
 // entries of the global list slab (16-byte aligned count; 0 when the lists fit the LDS)
 static size_t lc_glists_entries(int n_per_group, int groups) {

@@ -338,7 +338,10 @@ int launch_quotient(const uint8_t *d_blobs, const Fr *d_z, DeviceTables t, int n
     if (form == 2) hipLaunchKernelGGL(k_quotient_tree<2>, dim3(n), dim3(1024), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
     else if (form == 6) hipLaunchKernelGGL(k_quotient_tree<6>, dim3(n), dim3(64), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
     else hipLaunchKernelGGL(k_quotient_tree<4>, dim3(n), dim3(256), 0, st, d_blobs, prep, t.roots, d_y, d_q, d_err);
-    hipLaunchKernelGGL(k_quotient_scan, dim3(n < 32 ? n : 32), dim3(1024), 0, st, d_blobs, d_z, t.roots, d_y, d_q, d_err, list, count);
+    // z inside the domain happens with probability 2^-243 per honest blob: the walker of that list is a SMALL fixed grid (one workgroup for few blobs: a
+    // lone proof is latency-bound and every extra 1024-thread, 150 KB-of-LDS workgroup dispatched behind the tree kernel is on its critical path), and
+    // its workgroups leave at once when the list is empty
+    hipLaunchKernelGGL(k_quotient_scan, dim3(n < 512 ? 1 : n < 8192 ? 4 : 32), dim3(1024), 0, st, d_blobs, d_z, t.roots, d_y, d_q, d_err, list, count);
     return 0;
 }
 void launch_fr_from_bytes(const uint8_t *d_in32, int n, Fr *d_out, int *d_err, hipStream_t st) {

@@ -104,6 +104,10 @@ void launch_lincomb(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint3
                     int n_per_group, int groups, G1Jac *d_partials /* lincomb_partials_bytes() */, PairPt *d_pair_pts /* [group][2]: -proof_lincomb, rhs */,
                     hipStream_t st);
 size_t lincomb_partials_bytes(int n_per_group, int groups);
+// n_per_group == 1 with many groups (the *_many forms of the single-proof functions): rhs = C + [z] proof - [y] G, four lanes per check
+void launch_lincomb_single(const G1Affine *d_pts, const uint32_t *d_scal_b, const uint32_t *d_scal_c, int groups, void *d_scratch /* lincomb_single_bytes() */,
+                           PairPt *d_pair_pts, hipStream_t st);
+size_t lincomb_single_bytes(int groups);
 // bucket-method (Pippenger) form of the same sums, for many batches in flight; n_per_group <= 4096 (item indices are 15-bit)
 void launch_lincomb_buckets(const G1Affine *d_pts, const uint32_t *d_scal_a, const uint32_t *d_scal_b, const uint32_t *d_scal_c,
                             int n_per_group, int groups, void *d_scratch /* lincomb_buckets_scratch_bytes() */, PairPt *d_pair_pts, hipStream_t st,

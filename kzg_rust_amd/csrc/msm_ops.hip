@@ -132,13 +132,31 @@ int prove_common(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_b
 }
 
 // n commitments (d_c == null) or n blob proofs against the commitments d_c: enqueue on w->stream ...
-int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, HostFront *hf) {
+int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, HostFront *hf, const uint8_t *d_zs) {
     int rc;
     if ((rc = w->err.ensure(sizeof(int) * n))) return rc;
     if ((rc = w->h_err.ensure(sizeof(int) * n))) return rc;
-    if (d_c && (rc = w->z.ensure(sizeof(Fr) * n))) return rc;
+    if ((d_c || d_zs) && (rc = w->z.ensure(sizeof(Fr) * n))) return rc;
     w->in_flight = true;
     HIPCHK(hipMemsetAsync(w->err.p, 0, sizeof(int) * n, w->stream));
+    if (d_zs) {
+        // n independent compute_kzg_proof calls (kzg.rs:446-457): z_i -> field element (non-canonical: that unit's error, kzg.rs:452), then the quotient
+        // and its MSM as for blob proofs; y_i = p_i(z_i) leaves as 32 big-endian bytes (kzg.rs:455) through w->records / w->h_records
+        if ((rc = w->records.ensure(32 * n)) || (rc = w->h_records.ensure(32 * n))) return rc;
+        launch_fr_from_bytes(d_zs, (int)n, w->z.as<Fr>(), w->err.as<int>(), w->stream);
+        if (is_small(s)) {
+            if ((rc = w->out48.ensure(48 * n)) || (rc = w->h_out.ensure(48 * n))) return rc;
+            tm.begin("small_proof"); launch_small_proof(d_blobs, nullptr, w->z.as<Fr>(), (int)n, s->t, w->out48.as<uint8_t>(), w->records.as<uint8_t>(),
+                    w->err.as<int>(), w->stream); tm.end();
+            HIPCHK(hipMemcpyAsync(w->h_out.p, w->out48.p, 48 * n, hipMemcpyDeviceToHost, w->stream));
+        } else {
+            if ((rc = prove_common(s, w, tm, d_blobs, (int)n))) return rc;
+            launch_fr_to_bytes(w->y.as<Fr>(), (int)n, w->records.as<uint8_t>(), w->stream);
+        }
+        HIPCHK(hipMemcpyAsync(w->h_records.p, w->records.p, 32 * n, hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(hipMemcpyAsync(w->h_err.p, w->err.p, sizeof(int) * n, hipMemcpyDeviceToHost, w->stream));
+        return KZG355_OK;
+    }
     if (is_small(s)) {
         if ((rc = w->out48.ensure(48 * n))) return rc;
         if ((rc = w->h_out.ensure(48 * n))) return rc;
@@ -198,7 +216,7 @@ int msm_op_enqueue(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d
 }
 
 // ... and wait for it: 48-byte outputs / statuses of its n blobs.  Returns the first non-OK status.
-int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n) {
+int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n, uint8_t *ys_out) {
     HIPCHK(hipStreamSynchronize(w->stream));
     w->in_flight = false;
     tm.collect();
@@ -206,14 +224,17 @@ int msm_op_collect(Workspace *w, Timed &tm, uint8_t *out, int *status, size_t n)
     for (size_t i = 0; i < n; i++) {
         int st = status_from_err(w->h_err.as<int>()[i]);
         if (status) status[i] = st;
-        if (st == KZG355_OK) memcpy(out + 48 * i, w->h_out.as<uint8_t>() + 48 * i, 48);
-        else if (first == KZG355_OK) first = st;
+        if (st == KZG355_OK) {
+            memcpy(out + 48 * i, w->h_out.as<uint8_t>() + 48 * i, 48);
+            if (ys_out) memcpy(ys_out + 32 * i, w->h_records.as<uint8_t>() + 32 * i, 32);
+        } else if (first == KZG355_OK) first = st;
     }
     return first;
 }
 
-int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs) {
-    if (!cs || !out) return KZG355_BADARGS;
+int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, const uint8_t *d_c, size_t n, const kzg355_settings *cs, const uint8_t *d_zs,
+                            uint8_t *ys_out) {
+    if (!cs || !out || (d_zs && (d_c || !ys_out))) return KZG355_BADARGS;
     if (n == 0) return KZG355_OK;
     if (n > (size_t)1 << 20) return KZG355_BADARGS;
     if (!d_blobs || ((uintptr_t)d_blobs & 15) || ((uintptr_t)d_c & 3)) return KZG355_BADARGS;
@@ -224,9 +245,9 @@ int msm_op_many_device_impl(uint8_t *out, int *status, const uint8_t *d_blobs, c
     const bool via_host = d_c && device_call_hashes_on_host(g.s, n);      // blob proofs: the challenge hashes the blob (kzg.rs:298-339)
     struct InFlight { std::atomic<int> *n; ~InFlight() { if (n) (*n)--; } } in_flight{nullptr};
     if (via_host) { hf.from_device = true; hf.d_commitments = d_c; hf.n_blobs = n; g.s->calls_in_flight++; in_flight.n = &g.s->calls_in_flight; }
-    int rc = msm_op_enqueue(g.s, g.w, tm, d_blobs, d_c, n, via_host ? &hf : nullptr);
+    int rc = msm_op_enqueue(g.s, g.w, tm, d_blobs, d_c, n, via_host ? &hf : nullptr, d_zs);
     if (rc) return rc;
-    return msm_op_collect(g.w, tm, out, status, n);
+    return msm_op_collect(g.w, tm, out, status, n, ys_out);
 }
 
 }  // namespace kzg355_impl

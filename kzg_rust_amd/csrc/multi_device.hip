@@ -30,7 +30,7 @@ static int load_devices(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_by
         if (rc) return fail(rc);
         rep.push_back(r);
     }
-    if (n_devices == 1 && !getenv("KZG355_FORCE_MULTI")) { *out = rep[0]; return KZG355_OK; }     // (test hook: a one-device "multi" handle)
+    if (n_devices == 1 && !opt.force_multi) { *out = rep[0]; return KZG355_OK; }     // (force_multi: test hook, a one-device "multi" handle)
     MultiDev *m = new MultiDev();
     m->rep = rep;
     bool distinct = true;
@@ -256,7 +256,7 @@ int multi_verify_many(bool *ok, int *status, const uint8_t *blobs, const uint8_t
                       const kzg355_settings *cs) {
     MultiDev *m = cs->multi;
     const size_t D = m->rep.size(), BB = blob_bytes_of(cs);
-    const bool force_sharded = getenv("KZG355_FORCE_SHARDED") != nullptr && npg >= D;         // (test hook)
+    const bool force_sharded = cs->force_sharded && npg >= D;         // (test hook: kzg355_options.force_sharded)
     // enough independent batches (or batches too small to cut): ranges of batches, no exchange
     if (!force_sharded && (groups >= D || npg < 2 * D)) {
         return fan_out(D, groups, [&](size_t d, size_t g0, size_t n) -> int {
@@ -291,17 +291,8 @@ int kzg355_load_trusted_setup(const uint8_t *g1_bytes, size_t n1, const uint8_t 
     kzg355_options o;
     kzg355_options_from_env(&o);
     // KZG355_DEVICES=0,1,...: the handle spans those devices; otherwise KZG355_DEVICE / the current device
-    if (const char *e = getenv("KZG355_DEVICES")) {
-        std::vector<int> devs;
-        for (const char *p = e; *p;) {
-            char *end = nullptr;
-            const long v = strtol(p, &end, 10);
-            if (end == p) break;
-            devs.push_back((int)v);
-            p = *end == ',' ? end + 1 : end;
-        }
-        if (!devs.empty()) return load_devices(g1_bytes, n1, g2_bytes, n2, devs.data(), devs.size(), o, out);
-    }
+    const std::vector<int> devs = env_device_list();
+    if (!devs.empty()) return load_devices(g1_bytes, n1, g2_bytes, n2, devs.data(), devs.size(), o, out);
     return load_on_device(g1_bytes, n1, g2_bytes, n2, -1, o, out);
 }
 int kzg355_settings_device_count(const kzg355_settings *s) { return !s ? 0 : s->multi ? (int)s->multi->rep.size() : 1; }

@@ -108,9 +108,8 @@ int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, 
         s->beside_max_blobs = opt.beside_max_blobs > 0 ? opt.beside_max_blobs : 64 * cus;    // point kernels beside the hash chain up to 16384 blobs
         // two waves per pairing up to 256 batches
         s->pairing_two_wave_upto = opt.pairing_two_wave_upto < 0 ? 0 : opt.pairing_two_wave_upto > 0 ? opt.pairing_two_wave_upto : cus;
-        if (const char *e = getenv("KZG355_QUOTIENT_FORM")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 6) s->quotient_form = v; }
-        // (tuning knob, not an option)
-        if (const char *e = getenv("KZG355_MILLER_SEGMENTS")) { const int v = atoi(e); if (v >= 1 && v <= MILLER_SPLIT_MAX) s->miller_segments = v; }
+        if (opt.quotient_form == 2 || opt.quotient_form == 4 || opt.quotient_form == 6) s->quotient_form = opt.quotient_form;
+        if (opt.miller_segments >= 1 && opt.miller_segments <= MILLER_SPLIT_MAX) s->miller_segments = opt.miller_segments;
         // hard part twelve lanes per check from 4096 batches on
         s->pairing_hard12_from = opt.pairing_hard12_from < 0 ? 0 : opt.pairing_hard12_from > 0 ? opt.pairing_hard12_from : 16 * cus;
         // two-wave hash while every wave has a SIMD to itself (512 workgroups of 64 blobs)
@@ -121,7 +120,8 @@ int load_on_device(const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, 
     if (opt.split_streams >= 1 && opt.split_streams <= 8) s->split_streams = opt.split_streams;
     s->challenge_form = opt.challenge_form;
     s->lincomb_mode = opt.lincomb_form;
-    if (const char *e = getenv("KZG355_SIDE")) s->own_side_streams = strcmp(e, "shared") != 0;
+    s->force_sharded = opt.force_sharded != 0;
+    // (the HIP runtime's own variable, not one of this library's: how many hardware queues the process's streams are multiplexed onto, engine.h)
     if (const char *e = getenv("GPU_MAX_HW_QUEUES")) { const int q = atoi(e); if (q >= 1 && q <= 128) s->hw_queues = q; }
     s->submit_mode = opt.submit_sets >= 0 && opt.submit_sets <= 2 ? opt.submit_sets : 0;
     if (hipMemcpy(g1b.p, g1_bytes, 48 * n1, hipMemcpyHostToDevice) != hipSuccess) return fail(KZG355_DEVICE_ERROR);
@@ -237,6 +237,23 @@ static int device_self_test(kzg355_settings *s) {
     return KZG355_OK;
 }
 
+// The debug switches and the device list of the plain load function: with kzg355_options_from_env above, every read of the environment the library makes.
+bool debug_errors() { static const bool on = getenv("KZG355_DEBUG") != nullptr; return on; }
+bool debug_pipe() { static const bool on = getenv("KZG355_DEBUG_PIPE") != nullptr; return on; }
+std::vector<int> env_device_list() {
+    std::vector<int> devs;
+    if (const char *e = getenv("KZG355_DEVICES")) {
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            devs.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    return devs;
+}
+
 static int hexval(int ch) { return ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1; }
 
 void free_single(kzg355_settings *s) {
@@ -326,6 +343,10 @@ void kzg355_options_from_env(kzg355_options *o) {
     if (const char *e = getenv("KZG355_EXCHANGE")) o->exchange = strcmp(e, "peer") == 0 ? 1 : strcmp(e, "rccl") == 0 ? 2 : 0;
     num("KZG355_VERIFY_ONLY", 0, 1, &o->verify_only);
     if (const char *e = getenv("KZG355_SUBMIT")) o->submit_sets = strcmp(e, "sets") == 0 ? 1 : strcmp(e, "pipeline") == 0 ? 2 : 0;
+    num("KZG355_QUOTIENT_FORM", 2, 6, &o->quotient_form);
+    num("KZG355_MILLER_SEGMENTS", 1, 8, &o->miller_segments);
+    num("KZG355_FORCE_MULTI", 0, 1, &o->force_multi);
+    num("KZG355_FORCE_SHARDED", 0, 1, &o->force_sharded);
 }
 
 int kzg355_load_trusted_setup_file(const char *path, kzg355_settings **out) {

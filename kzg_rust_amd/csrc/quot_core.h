@@ -87,11 +87,15 @@ KZG_HD void quot_group_pass1(Fr inv12[4], Fr &Su, Fr &Sp, const uint32_t pw[4][8
 }
 // a sum back below ~3 r (its value mod r unchanged): the lazy product by R mod r
 KZG_HD void quot_fold(Fr &s) { Fr t; fr_mul_lazy(t, s, fr_one()); s = t; }
-// y = c_N (z S_u - S_p) as the canonical plain integer; S_u, S_p folded sums of the whole blob (< ~50 r)
+// y = c_N (z S_u - S_p) as the canonical plain integer; S_u, S_p folded sums of the whole blob.
+// PRECONDITION (what makes the bias of 2 r below sufficient): S_p < R = 2^261 ~ 68.6 r.  A lazy product a b / R comes out below a b / R + r, so
+// spn = S_p (R mod r) / R < S_p r / R + r < 2 r exactly when S_p < R.  The callers fold every partial sum once before they add them up (quot_fold:
+// each < ~3 r; 16 waves of partial sums: < 50 r), which is inside that bound with room to spare; a caller that adds up more than 22 folded sums
+// must fold again first (or take a bias of 4).
 KZG_HD void quot_y(Fr &y, const Fr &Su, const Fr &Sp, const QuotPrep &pp) {
     Fr t1, t2, spn;
     fr_mul_lazy(t1, Su, pp.zsq[0]);
-    fr_mul_lazy(spn, Sp, fr_one());
+    fr_mul_lazy(spn, Sp, fr_one());                               // < 2 r (see above)
     fr_sub_bias<2>(t2, t1, spn);
     fr_mul(y, t2, pp.cN);
 }

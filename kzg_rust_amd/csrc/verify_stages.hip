@@ -193,7 +193,8 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
             w->stream, s->t.n_fe, s->rhash_lanes_from, host_rhash ? 1 : 0); tm.end();
     const int form = lincomb_form(s, npg, groups);
     const bool buckets = form == LC_FORM_BUCKET;
-    if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
+    if ((rc = w->lc_partials.ensure(form == LC_FORM_WINDOW ? lincomb_partials_bytes(npg, groups) : form == LC_FORM_SINGLE ? lincomb_single_bytes(groups) :
+            lincomb_buckets_scratch_bytes(npg, groups)))) return rc;
     if ((rc = join_points(w, form != LC_FORM_PRESHIFT))) return rc;       // the decoded points (and their shifts) are needed from here on
     if (form == LC_FORM_PRESHIFT) {
         if (!shift_ready) {                                       // entry points without a stage 1 (single proofs, gathered records)
@@ -218,6 +219,9 @@ int run_stage2(kzg355_settings *s, Workspace *w, Timed &tm, const uint8_t *d_rec
             launch_lincomb_buckets(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.p,
                     w->pair_pts.as<PairPt>(), w->stream, stage, s->lc_chain_from);
         }
+    } else if (form == LC_FORM_SINGLE) {
+        tm.begin("lincomb");
+        launch_lincomb_single(d_pts, w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), groups, w->lc_partials.p, w->pair_pts.as<PairPt>(), w->stream);
     } else {
         tm.begin("lincomb");
         launch_lincomb(d_pts, w->scal_a.as<uint32_t>(), w->scal_b.as<uint32_t>(), w->scal_c.as<uint32_t>(), npg, groups, w->lc_partials.as<G1Jac>(),

@@ -30,7 +30,7 @@ void ws_release(kzg355_settings *s, Workspace *w) {
 
 // the handle's shared side stream, created on first use
 bool ensure_side(kzg355_settings *s, Workspace *w) {
-    if (!w->side && s->own_side_streams) {
+    if (!w->side) {
         if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) { w->side = nullptr; (void)hipGetLastError(); }
         else w->owns_side = true;
         if (w->side) return true;                                  // (else: fall back to the handle's shared stream)
@@ -49,7 +49,7 @@ bool ensure_side2(kzg355_settings *s, Workspace *w) {
     // side stream (enqueue_points_beside's one-side-stream form: +0.4 ms on the call's critical path) -- two streams that share a queue run
     // one after the other whatever their calls are, and a call whose main chain waits behind another call's side work loses milliseconds.
     if (!w->side2 && s->calls_in_flight.load() * 3 > s->hw_queues) return false;
-    if (!w->side2 && s->own_side_streams) {
+    if (!w->side2) {
         if (hipStreamCreateWithFlags(&w->side2, hipStreamNonBlocking) != hipSuccess) { w->side2 = nullptr; (void)hipGetLastError(); }
         else w->owns_side2 = true;
         if (w->side2) return true;
@@ -68,6 +68,8 @@ int lincomb_form(const kzg355_settings *s, int npg, int groups) {
     if (s->lincomb_mode == LC_FORM_PRESHIFT) return pre_ok ? LC_FORM_PRESHIFT : LC_FORM_WINDOW;
     if (s->lincomb_mode == LC_FORM_BUCKET) return bucket_ok ? LC_FORM_BUCKET : LC_FORM_WINDOW;
     if (s->lincomb_mode == LC_FORM_WINDOW) return LC_FORM_WINDOW;
+    // many independent single-proof checks (the *_many forms of verify_kzg_proof / verify_blob_kzg_proof): four ladder lanes per check
+    if (npg == 1 && !pre_ok) return LC_FORM_SINGLE;
     // few batches: shift every point under the hash, finish with ~25 additions; many: least issue work (buckets); in between: per-term ladders
     if (pre_ok) return LC_FORM_PRESHIFT;
     return bucket_ok && groups >= 64 ? LC_FORM_BUCKET : LC_FORM_WINDOW;

@@ -381,3 +381,53 @@ class Kzg:
         if _whole_call_failed(rc, st, G):                         # whole-call failure: the per-batch statuses are not to be trusted
             _check(rc, "verify_blob_kzg_proof_batch_many")
         return [bool(ok[i]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("verify") for i in range(G)]
+
+    @staticmethod
+    def verify_kzg_proof_many(commitments, zs, ys, proofs, s):
+        """n independent verify_kzg_proof checks (kzg.rs:1039) in one call.  Returns a list of bool / Error."""
+        cs = [_b(x, KzgCommitment) for x in commitments]
+        zz = [_b(x, Bytes32) for x in zs]
+        yy = [_b(x, Bytes32) for x in ys]
+        ps = [_b(x, KzgProof) for x in proofs]
+        n = len(cs)
+        if not (len(zz) == len(yy) == len(ps) == n):
+            raise BadArgs("length mismatch")
+        ok = (C.c_bool * max(n, 1))()
+        st = (C.c_int * max(n, 1))()
+        rc = lib().kzg355_verify_kzg_proof_many(ok, st, b"".join(cs), b"".join(zz), b"".join(yy), b"".join(ps), n, s.handle)
+        if _whole_call_failed(rc, st, n):
+            _check(rc, "verify_kzg_proof_many")
+        return [bool(ok[i]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("verify") for i in range(n)]
+
+    @staticmethod
+    def verify_blob_kzg_proof_many(blobs, commitments, proofs, s):
+        """n independent verify_blob_kzg_proof checks (kzg.rs:1050) in one call.  Returns a list of bool / Error."""
+        bl = [_blob(x, s) for x in blobs]
+        cs = [_b(x, KzgCommitment) for x in commitments]
+        ps = [_b(x, KzgProof) for x in proofs]
+        n = len(bl)
+        if not (len(cs) == len(ps) == n):
+            raise BadArgs("length mismatch")
+        ok = (C.c_bool * max(n, 1))()
+        st = (C.c_int * max(n, 1))()
+        rc = lib().kzg355_verify_blob_kzg_proof_many(ok, st, b"".join(bl), b"".join(cs), b"".join(ps), n, s.handle)
+        if _whole_call_failed(rc, st, n):
+            _check(rc, "verify_blob_kzg_proof_many")
+        return [bool(ok[i]) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("verify") for i in range(n)]
+
+    @staticmethod
+    def compute_kzg_proof_many(blobs, zs, s):
+        """n independent compute_kzg_proof calls (kzg.rs:1021) in one call.  Returns a list of (KzgProof, Bytes32) / Error."""
+        bl = [_blob(x, s) for x in blobs]
+        zz = [_b(x, Bytes32) for x in zs]
+        n = len(bl)
+        if len(zz) != n:
+            raise BadArgs("length mismatch")
+        out = C.create_string_buffer(48 * max(n, 1))
+        ys = C.create_string_buffer(32 * max(n, 1))
+        st = (C.c_int * max(n, 1))()
+        rc = lib().kzg355_compute_kzg_proof_many(out, ys, st, b"".join(bl), b"".join(zz), n, s.handle)
+        if _whole_call_failed(rc, st, n):
+            _check(rc, "compute_kzg_proof_many")
+        return [(KzgProof(out.raw[48 * i:48 * i + 48]), Bytes32(ys.raw[32 * i:32 * i + 32])) if st[i] == 0 else _ERRORS.get(st[i], InternalError)("proof")
+                for i in range(n)]

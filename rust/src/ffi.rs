@@ -52,6 +52,10 @@ pub struct kzg355_options {
     pub pairing_hard12_from: c_int,
     pub submit_sets: c_int,
     pub host_hash_device_max_blobs: c_int,
+    pub quotient_form: c_int,
+    pub miller_segments: c_int,
+    pub force_multi: c_int,
+    pub force_sharded: c_int,
 }
 
 extern "C" {
@@ -79,6 +83,12 @@ extern "C" {
                                               s: *const kzg355_settings) -> c_int;
     pub fn kzg355_verify_blob_kzg_proof_batch_many(ok: *mut bool, status: *mut c_int, blobs: *const u8, commitments: *const u8, proofs: *const u8,
                                                    n_per_group: usize, groups: usize, s: *const kzg355_settings) -> c_int;
+    pub fn kzg355_verify_kzg_proof_many(ok: *mut bool, status: *mut c_int, commitments: *const u8, zs: *const u8, ys: *const u8, proofs: *const u8, n: usize,
+                                        s: *const kzg355_settings) -> c_int;
+    pub fn kzg355_verify_blob_kzg_proof_many(ok: *mut bool, status: *mut c_int, blobs: *const u8, commitments: *const u8, proofs: *const u8, n: usize,
+                                             s: *const kzg355_settings) -> c_int;
+    pub fn kzg355_compute_kzg_proof_many(proofs_out: *mut u8, ys_out: *mut u8, status: *mut c_int, blobs: *const u8, zs: *const u8, n: usize,
+                                         s: *const kzg355_settings) -> c_int;
 
     pub fn kzg355_settings_device(s: *const kzg355_settings) -> c_int;
     pub fn kzg355_settings_device_count(s: *const kzg355_settings) -> c_int;

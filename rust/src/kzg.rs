@@ -359,6 +359,70 @@ impl Kzg {
         whole_call(rc, &st[..groups], "verify_blob_kzg_proof_batch_many")?;
         Ok((0..groups).map(|g| check(st[g], "verify").map(|_| ok[g])).collect())
     }
+
+    /// `commitments.len()` independent `verify_kzg_proof` checks (one proof per call is what benches/kzg_benches.rs:70-81 times).
+    pub fn verify_kzg_proof_many(
+        commitments: &[KzgCommitment],
+        zs: &[Bytes32],
+        ys: &[Bytes32],
+        proofs: &[KzgProof],
+        s: &KzgSettings,
+    ) -> Result<Vec<Result<bool, Error>>, Error> {
+        let n = commitments.len();
+        if zs.len() != n || ys.len() != n || proofs.len() != n {
+            return Err(Error::BadArgs("length mismatch".into()));
+        }
+        let c: Vec<u8> = commitments.iter().flat_map(|x| x.to_bytes()).collect();
+        let z: Vec<u8> = zs.iter().flat_map(|x| x.bytes).collect();
+        let y: Vec<u8> = ys.iter().flat_map(|x| x.bytes).collect();
+        let p: Vec<u8> = proofs.iter().flat_map(|x| x.to_bytes()).collect();
+        let mut ok = vec![false; n.max(1)];
+        let mut st = vec![0i32; n.max(1)];
+        let rc = unsafe { ffi::kzg355_verify_kzg_proof_many(ok.as_mut_ptr(), st.as_mut_ptr(), c.as_ptr(), z.as_ptr(), y.as_ptr(), p.as_ptr(), n, s.raw) };
+        whole_call(rc, &st[..n], "verify_kzg_proof_many")?;
+        Ok((0..n).map(|i| check(st[i], "verify").map(|_| ok[i])).collect())
+    }
+
+    /// `blobs.len()` independent `verify_blob_kzg_proof` checks.
+    pub fn verify_blob_kzg_proof_many(blobs: &[Blob], commitments: &[KzgCommitment], proofs: &[KzgProof], s: &KzgSettings) -> Result<Vec<Result<bool, Error>>, Error> {
+        let n = blobs.len();
+        if commitments.len() != n || proofs.len() != n {
+            return Err(Error::BadArgs("length mismatch".into()));
+        }
+        let staged = stage_blobs(blobs);
+        let c: Vec<u8> = commitments.iter().flat_map(|x| x.to_bytes()).collect();
+        let p: Vec<u8> = proofs.iter().flat_map(|x| x.to_bytes()).collect();
+        let mut ok = vec![false; n.max(1)];
+        let mut st = vec![0i32; n.max(1)];
+        let rc = unsafe { ffi::kzg355_verify_blob_kzg_proof_many(ok.as_mut_ptr(), st.as_mut_ptr(), staged.as_ptr(), c.as_ptr(), p.as_ptr(), n, s.raw) };
+        whole_call(rc, &st[..n], "verify_blob_kzg_proof_many")?;
+        Ok((0..n).map(|i| check(st[i], "verify").map(|_| ok[i])).collect())
+    }
+
+    /// `blobs.len()` independent `compute_kzg_proof` calls: proof and y = p(z) per blob at the caller's points.
+    pub fn compute_kzg_proof_many(blobs: &[Blob], zs: &[Bytes32], s: &KzgSettings) -> Result<Vec<Result<(KzgProof, Bytes32), Error>>, Error> {
+        let n = blobs.len();
+        if zs.len() != n {
+            return Err(Error::BadArgs("length mismatch".into()));
+        }
+        let staged = stage_blobs(blobs);
+        let z: Vec<u8> = zs.iter().flat_map(|x| x.bytes).collect();
+        let mut out = vec![0u8; BYTES_PER_PROOF * n.max(1)];
+        let mut ys = vec![0u8; 32 * n.max(1)];
+        let mut st = vec![0i32; n.max(1)];
+        let rc = unsafe { ffi::kzg355_compute_kzg_proof_many(out.as_mut_ptr(), ys.as_mut_ptr(), st.as_mut_ptr(), staged.as_ptr(), z.as_ptr(), n, s.raw) };
+        whole_call(rc, &st[..n], "compute_kzg_proof_many")?;
+        Ok((0..n)
+            .map(|i| {
+                check(st[i], "proof").map(|_| {
+                    (
+                        KzgProof::from(<[u8; BYTES_PER_PROOF]>::try_from(&out[48 * i..48 * i + 48]).unwrap()),
+                        Bytes32::from(<[u8; 32]>::try_from(&ys[32 * i..32 * i + 32]).unwrap()),
+                    )
+                })
+            })
+            .collect())
+    }
 }
 
 /// `&[Blob]` is a slice of boxes: the blobs are not contiguous in memory, the ABI wants one buffer.

@@ -99,10 +99,9 @@ def test_rccl_all_gather_on_a_one_device_communicator(kz, setup_bytes, data):
     device the collective is a local copy, but every call of the production path is made."""
     s1, B, cs, ps = data
     try:
-        s = _load(kz, setup_bytes, [0], KZG355_FORCE_MULTI="1", KZG355_EXCHANGE="rccl")
+        s = _load(kz, setup_bytes, [0], KZG355_FORCE_MULTI="1", KZG355_FORCE_SHARDED="1", KZG355_EXCHANGE="rccl")      # (both test hooks are kzg355_options fields)
     except kz.NoDevice:
         pytest.skip("librccl could not be loaded / initialised on this box")
-    os.environ["KZG355_FORCE_SHARDED"] = "1"
     try:
         kind, ag0, _ = s.exchange_stats()
         assert kind == 1 and s.device_count == 1
@@ -113,7 +112,6 @@ def test_rccl_all_gather_on_a_one_device_communicator(kz, setup_bytes, data):
         groups = [(B[4 * g:4 * g + 4], cs[4 * g:4 * g + 4], ps[4 * g:4 * g + 4]) for g in range(3)]
         assert kz.Kzg.verify_blob_kzg_proof_batch_many(groups, s) == [True, True, True]
     finally:
-        del os.environ["KZG355_FORCE_SHARDED"]
         s.free()
 
 
