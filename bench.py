@@ -156,25 +156,49 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on these hosts
     env.setdefault("OMP_NUM_THREADS", "8")
+    import signal
     child = subprocess.Popen(launcher_command(n, argv, port), stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+
+    # a launcher that is interrupted or terminated (a harness timeout sends SIGTERM) must not leave torchrun and its N GPU ranks behind
+    # holding the cards: the signal is FORWARDED to the child (torchrun ends its ranks), the relay loop then sees EOF, and whatever ends the loop the
+    # finally clause does not return while the child is alive.
+    def forward(signum, frame):
+        try:
+            child.send_signal(signum)
+        except Exception:
+            pass
+    old_handlers = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
     lines = 0
-    for ln in child.stdout:
-        is_line = False
-        if ln.startswith("{"):
+    try:
+        for ln in child.stdout:
+            is_line = False
+            if ln.startswith("{"):
+                try:
+                    is_line = "metric" in json.loads(ln)
+                except ValueError:
+                    is_line = False
+            if is_line:
+                lines += 1
+                sys.stdout.write(ln); sys.stdout.flush()
+            else:
+                sys.stderr.write(ln); sys.stderr.flush()
+        rc = child.wait()
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+        if child.poll() is None:
+            child.terminate()
             try:
-                is_line = "metric" in json.loads(ln)
-            except ValueError:
-                is_line = False
-        if is_line:
-            lines += 1
-            sys.stdout.write(ln); sys.stdout.flush()
-        else:
-            sys.stderr.write(ln); sys.stderr.flush()
-    rc = child.wait()
+                child.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                child.kill(); child.wait()
     if rc == 0 and lines != 1:
         sys.stderr.write(f"bench.py launcher: expected one JSON line from rank 0, saw {lines}\n")
         return 1
     return rc if rc >= 0 else 128 - rc                          # killed by a signal: shell convention
+
+
+T_PROCESS_START = time.perf_counter()
 
 
 def main():
@@ -204,6 +228,10 @@ def main():
                          "allgather_split = the same all-gather with stage 2 split by batch")
     ap.add_argument("--no-parity-gate", action="store_true", help="N > 1: skip the byte-exact check of the sharded path on the real ranks before the timed steps")
     ap.add_argument("--no-in-library-leg", action="store_true", help="N > 1: skip the timing of the library's own multi-device handle (kzg355_load_trusted_setup_devices) on rank 0")
+    ap.add_argument("--max-seconds", type=float, default=480.0,
+                    help="wall-clock budget of the whole run from process start (the driver allows 600 s): optional legs are DROPPED, not cut short, once the time "
+                         "left does not cover them -- N > 1: first the in-library leg, then the exchange forms beyond the first (north_star's all-gather always "
+                         "runs); N = 1: the CPU all-threads trials, the mixed / mid-size legs.  config.skipped_for_time names what was dropped")
     ap.add_argument("--sweep", action="store_true",
                     help="criterion sweep: verify_blob_kzg_proof_batch for n in {1,..,64} and the five single-op benches, single calls on host inputs")
     args = ap.parse_args()
@@ -227,6 +255,7 @@ def main():
         if rank == 0:
             emit({"metric": "echo", "argv": sys.argv[1:], "world": world, "gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                   "exchange": args.exchange, "master_addr": os.environ.get("MASTER_ADDR")})
+        time.sleep(float(os.environ.get("KZG355_BENCH_ECHO_SLEEP", "0")))      # (test hook: ranks that stay up long enough to be interrupted)
         raise SystemExit(int(os.environ.get("KZG355_BENCH_ECHO_RC", "0")) if rank == world - 1 else 0)
     # Rehearsal hook (never set by the driver): KZG355_BENCH_FORCE_DIST=1 with one rank under torch.distributed.run makes the N = 1 run take the N > 1 code path --
     # process group on the real backend (nccl = RCCL), parity gate, both exchange forms through their collectives, the in-library leg -- on the one-GPU box:
@@ -291,6 +320,10 @@ def main():
         return
 
     K, W = max(1, args.steps), max(0, args.warmup)
+    skipped = []                                   # legs dropped for --max-seconds (config.skipped_for_time)
+
+    def time_left():
+        return args.max_seconds - (time.perf_counter() - T_PROCESS_START)
     if args.concurrent is None:
         # verify: 8192 batches = 524,288 blobs = 69 GB of the card's 288 GB per step, one launch set (the larger the set the better the
         # kernels run: 2048 batches 3.13 M blobs/s, 4096 3.44 M, 8192 3.63 M); MSM-bound ops and the PCIe-inclusive variant: 256 batches
@@ -465,7 +498,23 @@ def main():
 
     sharded = multi or args.sharded_path
     modes = ["allgather", "allgather_split", "alltoall"] if (sharded and args.exchange == "both" and args.op == "verify") else [mode_now[0]]
-    runs = {m: timed_region(m) for m in modes}              # (the same K and W for each form, back to back)
+    # (the same K and W for each form, back to back.  --max-seconds: a further form needs what the last one took, and the line, the parity of the exit and --
+    # N > 1 -- the in-library leg's 20 s minimum still have to fit behind it; all ranks take the same decision from rank 0's clock)
+    runs = {}
+    for m in modes:
+        if runs:
+            last = list(runs.values())[-1]["wall_s"]
+            go = time_left() > 1.3 * last + 45.0
+            if multi:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+                dist.broadcast(flag, src=0)
+                go = bool(int(flag.item()))
+            if not go:
+                skipped.append(f"exchange form {m}")
+                continue
+        t_form = time.perf_counter()
+        runs[m] = timed_region(m)
+        runs[m]["wall_s"] = time.perf_counter() - t_form
     best = max(runs.values(), key=lambda r: r["blobs_per_s"])
     dt, step_ms, power, exchange_stats, stats = best["dt"], best["step_ms"], best["power"], best["exchange_stats"], best["stats"]
     value_exchange = best["mode"] if sharded else None
@@ -523,7 +572,21 @@ def main():
             mid_size = mid_size_leg(L, s, t_blobs, t_c, t_p, n_local)
     cpu_baseline = None
     if rank == 0 and not multi and not args.no_cpu_baseline:
-        cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local)
+        cpu_baseline = time_cpu_baseline(args.op, commitments[:48 * n_local], proofs[:48 * n_local], host, n_local,
+                                         match_threads=host_inputs.get("single_call_host_threads") if host_inputs else None,
+                                         all_threads=time_left() > 200.0)
+        if not cpu_baseline.get("all_cores"):
+            skipped.append("CPU all-threads trials")
+
+    coexist = None
+    if rank == 0 and not multi and args.op == "verify" and not args.host_inputs and not args.no_msm_legs and not args.sharded_path and pipeline == 1 and Cc >= 1024:
+        # what a drop-in KzgSettings serves -- verification AND commitments from ONE handle, nothing freed in between.  `s` is a default
+        # handle: the untimed setup's commitments made it size its own table (from half of the HBM free at that moment), and the step's 69 GB of blobs are
+        # still resident beside it.
+        if time_left() > 150.0:
+            coexist = coexist_leg(L, s, t_blobs, t_c, t_p, commitments, n_local, min(n_blobs, 16384))
+        else:
+            skipped.append("default-table / mixed leg")
 
     msm_form_at_end = s.msm_form
     msm_legs = None
@@ -541,7 +604,16 @@ def main():
         s = None
 
     in_library = None
-    if multi and args.op == "verify" and not args.no_in_library_leg:
+    run_in_library = multi and args.op == "verify" and not args.no_in_library_leg
+    if run_in_library:
+        # the first leg to go when time is short (it loads N handles and makes 256 commitments and proofs before it times anything: ~60-100 s on 8 devices)
+        go = time_left() > float(os.environ.get("KZG355_BENCH_IN_LIBRARY_NEEDS", "150"))
+        flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.broadcast(flag, src=0)
+        if not int(flag.item()):
+            run_in_library = False
+            skipped.append("in-library leg")
+    if run_in_library:
         # The multi-GPU path a Rust / C caller actually gets: ONE handle over all N devices inside rank 0's process.  The other ranks
         # give their GPUs back first and wait on a HOST-side barrier (gloo) -- an RCCL barrier would keep a kernel spinning on every card.
         t_blobs = t_c = t_p = None
@@ -565,7 +637,7 @@ def main():
                     box["out"] = {"in_library_error": repr(e)[:300]}
             th = threading.Thread(target=leg, daemon=True)
             th.start()
-            th.join(timeout=float(os.environ.get("KZG355_BENCH_IN_LIBRARY_TIMEOUT", "240")))
+            th.join(timeout=min(float(os.environ.get("KZG355_BENCH_IN_LIBRARY_TIMEOUT", "240")), max(20.0, time_left() - 15.0)))
             hung = th.is_alive()
             in_library = {"in_library_error": "timed out (the leg is still running; its thread was abandoned)"} if hung else box.get("out")
         park()
@@ -576,7 +648,9 @@ def main():
             "value": value, "unit": "blobs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
-            "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch" if args.op == "verify" else
+            "config": {"workload": ("kzg_mainnet verify_blob_kzg_proof_batch, 64 random blobs per GPU per batch, "
+                                    + ("host buffers (PCIe H2D inside the timed region)" if args.host_inputs else "device-resident inputs (blobs in HBM when the timed region starts)")
+                                    if args.op == "verify" else
                                     f"kzg_mainnet {'blob_to_kzg_commitment' if args.op == 'commit' else 'compute_blob_kzg_proof'}, independent blobs")
                                    + ("" if not multi else f", one batch of {64 * world} blobs sharded over {world} GPUs, "
                                       + {"alltoall": "all-to-all of the 160-B records + decoded points (stage 2 split by batch)",
@@ -616,7 +690,9 @@ def main():
             line["config"].update(parity)
         if in_library:
             line["config"].update(in_library)
-        flatten_scalars(line, host_inputs, mid_size, power, msm_legs)
+        line["config"]["skipped_for_time"] = "; ".join(skipped) if skipped else "nothing"
+        line["config"]["wall_s"] = round(time.perf_counter() - T_PROCESS_START, 1)      # this process, start to line (the launcher of an N > 1 run adds its own start-up)
+        flatten_scalars(line, host_inputs, mid_size, power, msm_legs, coexist, multi=multi)
         emit(line)
     if s is not None:
         s.free()
@@ -624,7 +700,9 @@ def main():
         dist.destroy_process_group()
         if rank == 0 and in_library and "timed out" in str(in_library.get("in_library_error", "")):
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)                                  # the abandoned in-library thread is stuck in a device call: no orderly interpreter shutdown
+            # the abandoned in-library thread is stuck in a device call: no orderly interpreter shutdown.  NON-ZERO: a deadlock inside the library's
+            # own RCCL / peer-copy path is a failure the launcher, CI and the driver must see -- the line above still carries every measurement that finished
+            os._exit(6)
 
 
 def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, backend):
@@ -665,7 +743,8 @@ def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, ba
         if ok != [False] or st != [0]:
             problems.append(f"{mode}: swapped twin gave {ok} / {st}")
     out = {}
-    if rank == 0:
+    try:
+      if rank == 0:
         if gathered is None or gathered.numel() != 160 * n:
             problems.append("no gathered records captured")
         else:
@@ -689,6 +768,10 @@ def parity_gate(kz, L, s, engine, dev, torch, dist, random_blob, rank, world, ba
             out = {"parity_gate": "passed" if not problems else "FAILED: " + "; ".join(problems), "parity_gate_blobs": n,
                    "parity_gate_r": r_sh.hex(), "parity_gate_against": ("tests/golden/batch512.json (oracle-derived r, proof_lincomb, rhs) and " if n == fx["n"] else "")
                    + "the single-device run of the same batch on rank 0: records, r, proof_lincomb, rhs byte-exact; verdicts true / false in all three exchange forms"}
+    except Exception as e:  # noqa: BLE001
+        # whatever rank 0's own comparison raises (an unexpected status out of batch_intermediates, a device error) is a PROBLEM of the gate, not an
+        # exception of one rank: the others are already waiting in the all-reduce below and every rank must leave together with the one-line report
+        problems.append(f"rank-0 comparison raised {e!r}")
     flag = torch.tensor([1 if problems else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()):
@@ -847,15 +930,69 @@ def run_msm_legs(kz, L, torch, dev, g1, g2, t_blobs, t_c, commitments, proofs, n
     return legs
 
 
-def flatten_scalars(line, host_inputs, mid_size, power, msm_legs):
-    """The driver's record of this line keeps SCALARS under config / roofline / cpu_baseline and drops nested objects and extra top-level keys
-    (VERDICT r4): every number BASELINE.md quotes is therefore also a flat scalar.  The nested objects stay for readers of the raw line."""
+# What the driver's record of the line keeps: the first ~20 SCALARS of `config`, `roofline` and `cpu_baseline`, in insertion order; nested objects and extra
+# top-level keys are dropped.  So the three objects are REBUILT in priority order just before the line is printed: north_star's own
+# numbers first, low-value scalars (minima, units, notes, shapes a reader can derive) under a nested `detail`, everything else behind.
+CONFIG_PRIORITY_N1 = [
+    "workload", "batch_size", "batches_per_step", "inputs",
+    "single_call_ms", "single_call_ms_device_hash", "single_call_host_threads", "host_stream_blobs_per_s", "latency_ms_single_batch",
+    "commit_blobs_per_s", "commit_msm_bits", "commit_g1_sweep_hbm_frac", "commit_traffic_over_algorithmic", "commit_gather_frac",
+    "proof_blobs_per_s", "proof_g1_sweep_hbm_frac", "sclk_mhz_median",
+    "commit_default_blobs_per_s", "commit_default_table_gb", "mixed_verify_blobs_per_s", "mixed_commit_blobs_per_s",
+    # ... and what no longer fits the kept 20, most useful first
+    "proof_traffic_over_algorithmic", "proof_gather_frac", "mid_size_blobs_per_s", "mid_size_one_set_blobs_per_s", "single_call_blobs_per_s", "host_stream_h2d_gbps",
+    "verify_kzg_proof_many_per_s", "skipped_for_time", "socket_power_w_median", "commit_table_gb", "commit_msm_frac_of_mix_floor", "proof_quotient_ms",
+    "proof_quotient_frac_of_mix_floor"]
+CONFIG_PRIORITY_MULTI = [
+    "workload", "batch_size", "batches_per_step", "inputs", "value_exchange",
+    "allgather_blobs_per_s", "allgather_split_blobs_per_s", "alltoall_blobs_per_s", "parity_gate",
+    "stage1_ms_allgather", "exchange_ms_allgather", "stage2_ms_allgather", "merge_ms_allgather", "exchange_ms_alltoall", "stage2_ms_allgather_split",
+    "in_library_single_call_ms", "in_library_blobs_per_s", "in_library_exchange", "skipped_for_time", "sclk_mhz_median", "rehearsal",
+    "allgather_ms_per_step", "allgather_split_ms_per_step", "alltoall_ms_per_step", "latency_ms_single_batch", "in_library_error"]
+CONFIG_DETAIL = ["blobs_per_step", "field_elements_per_blob", "sets_in_flight", "msm_form", "latency_ms_single_batch_min", "single_call_ms_min", "commit_ms_per_launch",
+                 "proof_ms_per_launch", "commit_blobs_per_launch", "parity_gate_blobs", "parity_gate_r", "parity_gate_against", "in_library_note",
+                 "in_library_single_call_ms_min", "in_library_devices", "in_library_load_s", "in_library_single_call_blobs", "in_library_many_batches"]
+ROOFLINE_PRIORITY = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                     "path_frac_of_hbm_peak", "alu_path_frac_of_nominal", "alu_path_frac_of_mix_floor", "challenge_ms", "eval_ms", "validate_ms", "lincomb_ms", "pairing_ms",
+                     "measured_stream_copy_gbps", "path_bytes_per_blob", "alu_path_wave_insts_per_blob", "lincomb_horner_ms", "launches"]
+ROOFLINE_DETAIL = ["traffic_unit", "traffic_source", "kernel_timing", "note"]
+CPU_PRIORITY = ["value", "unit", "cores", "kind", "sample", "threads_matched_value", "threads_matched_threads", "all_cores_value", "all_cores_threads", "primitives",
+                "portable_c_value", "host_cpus", "cpu_model"]
+
+
+def _is_scalar(v):
+    return v is None or isinstance(v, (bool, int, float, str))
+
+
+def reorder(d, priority, detail=()):
+    """`d` rebuilt: the priority keys that are present (scalars) first, in that order; then the remaining scalars as they were; `detail` keys moved into a nested
+    "detail" object; nested objects last.  Nothing is lost -- readers of the raw line find every key; the driver's truncated record finds the right ones."""
+    out = {}
+    for k in priority:
+        if k in d and _is_scalar(d[k]):
+            out[k] = d[k]
+    det = {k: d[k] for k in detail if k in d and k not in out}
+    for k, v in d.items():
+        if k not in out and k not in det and _is_scalar(v):
+            out[k] = v
+    if det:
+        out["detail"] = det
+    for k, v in d.items():
+        if k not in out and k not in det:
+            out[k] = v
+    return out
+
+
+def flatten_scalars(line, host_inputs, mid_size, power, msm_legs, coexist=None, multi=False):
+    """Every number BASELINE.md quotes becomes a flat scalar of config / roofline / cpu_baseline, then the three objects are put in the order the driver's
+    record needs (see CONFIG_PRIORITY_* above; tests/test_bench_launcher.py asserts the first twenty).  The nested objects stay for readers of the raw line."""
     cfg, roof, cpu = line["config"], line.get("roofline"), line.get("cpu_baseline")
     if host_inputs:
         cfg["single_call_ms"] = host_inputs["single_call_ms"]                      # ONE verify_blob_kzg_proof_batch(n = 64) on host slices (benches/kzg_benches.rs:113-120)
         cfg["single_call_ms_min"] = host_inputs["single_call_ms_min"]
         cfg["single_call_blobs_per_s"] = host_inputs["single_call_blobs_per_s"]
         cfg["single_call_ms_device_hash"] = host_inputs["single_call_ms_device_hash"]
+        cfg["single_call_host_threads"] = host_inputs.get("single_call_host_threads")      # host threads that hashed for that call (the handle's workers + the caller)
         cfg["host_stream_blobs_per_s"] = host_inputs["stream_blobs_per_s"]         # pageable host memory -> HBM inside the call
         cfg["host_stream_h2d_gbps"] = host_inputs["stream_h2d_gbps"]
     if mid_size:
@@ -879,9 +1016,17 @@ def flatten_scalars(line, host_inputs, mid_size, power, msm_legs):
         cfg["commit_msm_frac_of_mix_floor"] = msm_legs["commit"].get("msm_frac_of_mix_floor")
         cfg["proof_quotient_frac_of_mix_floor"] = msm_legs["proof"].get("quotient_frac_of_mix_floor")
         cfg["msm_legs"] = msm_legs
+    if coexist:
+        # the table a DEFAULT handle sizes for itself and verification + commitments served by ONE handle with nothing freed in between
+        cfg["commit_default_blobs_per_s"] = coexist.get("commit_default_blobs_per_s")
+        cfg["commit_default_table_gb"] = coexist.get("commit_default_table_gb")
+        cfg["mixed_verify_blobs_per_s"] = coexist.get("mixed_verify_blobs_per_s")
+        cfg["mixed_commit_blobs_per_s"] = coexist.get("mixed_commit_blobs_per_s")
+        cfg["coexistence"] = coexist
     if roof:
         per = roof.get("per_kernel") or {}
-        for fam, key in (("eval", "eval"), ("challenge", "challenge"), ("validate_points", "validate"), ("lincomb", "lincomb"), ("pairing", "pairing")):
+        for fam, key in (("eval", "eval"), ("challenge", "challenge"), ("validate_points", "validate"), ("lincomb", "lincomb"), ("pairing", "pairing"),
+                         ("lincomb_horner", "lincomb_horner"), ("rpowers", "rpowers")):
             if fam in per:
                 roof[f"{key}_ms"] = per[fam]["avg_launch_ms"]
                 roof[f"{key}_frac"] = per[fam]["frac"]
@@ -895,9 +1040,13 @@ def flatten_scalars(line, host_inputs, mid_size, power, msm_legs):
             if "frac_of_mix_floor" in d:
                 roof[f"alu_{fam}_frac_of_mix_floor"] = d["frac_of_mix_floor"]
             roof[f"alu_{fam}_frac_of_nominal"] = d["frac_of_nominal"]
-    if cpu and cpu.get("all_cores"):
-        cpu["all_cores_value"] = cpu["all_cores"]["value"]
-        cpu["all_cores_threads"] = cpu["all_cores"]["threads"]
+        line["roofline"] = reorder(roof, ROOFLINE_PRIORITY, ROOFLINE_DETAIL)
+    if cpu:
+        if cpu.get("all_cores"):
+            cpu["all_cores_value"] = cpu["all_cores"]["value"]
+            cpu["all_cores_threads"] = cpu["all_cores"]["threads"]
+        line["cpu_baseline"] = reorder(cpu, CPU_PRIORITY)
+    line["config"] = reorder(cfg, CONFIG_PRIORITY_MULTI if multi else CONFIG_PRIORITY_N1, CONFIG_DETAIL)
 
 
 def stream_copy_peak(torch, dev):
@@ -956,12 +1105,54 @@ def host_leg(L, s, t_blobs, commitments, proofs, n_local, groups):
     best = max(rates)
     return {"single_call_ms": round(statistics.median(lat), 3), "single_call_ms_min": round(min(lat), 3),
             "single_call_blobs_per_s": round(n_local / (statistics.median(lat) / 1e3), 1),
+            "single_call_host_threads": s.host_threads if hashed_on_host else 1,
             "single_call_route": "Fiat-Shamir challenges and the batch challenge hashed on host threads while the copies and point kernels run" if hashed_on_host else "device hash",
             "single_call_ms_device_hash": round(statistics.median(lat_dev), 3),
             "stream_blobs_per_s": round(statistics.median(rates), 1), "stream_blobs_per_s_best": round(best, 1),
             "stream_h2d_gbps": round(statistics.median(rates) * (BLOB + 96) / 1e9, 2), "stream_blobs_per_call": nb,
             "note": "pageable caller memory -> HBM inside the call (the runtime locks the caller's pages and DMAs from them, 1 GiB chunks over 3 streams); never `value`.  "
                     "single_call = one verify_blob_kzg_proof_batch(n = 64) on host slices, the reference bench's own shape (benches/kzg_benches.rs:113-120)"}
+
+
+def coexist_leg(L, s, t_blobs, t_c, t_p, commitments, n_local, n_commit, g=1024, rounds=6):
+    """ONE default handle serving both paths with everything resident (the verify step's 69 GB of blobs, the table the handle sized for itself):
+      * commit_default: kzg355_blob_to_kzg_commitment_many_device over n_commit blobs per launch on the DEFAULT table (a handle left to itself takes the
+        widest form that fits half of the free HBM: 15-bit windows, 68.9 GB on an empty card; config.commit_* further down is the explicit 16-bit / 143.5 GB form);
+      * mixed: `rounds` times a 1024-batch verify launch set, then an n_commit-blob commitment launch, alternating on the same handle without freeing
+        anything; each kind's rate over the time spent in its own calls, and the combined wall.  Reference: blob_to_kzg_commitment (kzg.rs:401-406) and
+        verify_blob_kzg_proof_batch (kzg.rs:637-693) take the same &KzgSettings."""
+    bits, wins, glv, table_bytes = s.msm_shape()
+    out48 = C.create_string_buffer(48 * n_commit)
+    st = (C.c_int * n_commit)()
+    ok = (C.c_bool * g)(); stg = (C.c_int * g)()
+
+    def commit():
+        rc = L.kzg355_blob_to_kzg_commitment_many_device(out48, st, t_blobs.data_ptr(), n_commit, s.handle)
+        assert rc == 0 and out48.raw[:48 * n_commit] == commitments[:48 * n_commit]
+
+    def verify():
+        rc = L.kzg355_verify_blob_kzg_proof_batch_many_device(ok, stg, t_blobs.data_ptr(), t_c.data_ptr(), t_p.data_ptr(), n_local, g, s.handle)
+        assert rc == 0 and bytes(ok)[:g] == b"\x01" * g
+
+    commit(); commit()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        commit()
+    default_rate = 4 * n_commit / (time.perf_counter() - t0)
+    verify(); commit()
+    tv = tc = 0.0
+    t_all = time.perf_counter()
+    for _ in range(rounds):
+        t0 = time.perf_counter(); verify(); tv += time.perf_counter() - t0
+        t0 = time.perf_counter(); commit(); tc += time.perf_counter() - t0
+    wall = time.perf_counter() - t_all
+    return {"commit_default_blobs_per_s": round(default_rate, 1), "commit_default_msm_bits": bits, "commit_default_table_gb": round(table_bytes / 1e9, 1),
+            "commit_default_blobs_per_launch": n_commit,
+            "mixed_verify_blobs_per_s": round(rounds * g * n_local / tv, 1), "mixed_commit_blobs_per_s": round(rounds * n_commit / tc, 1),
+            "mixed_rounds": rounds, "mixed_verify_batches_per_set": g, "mixed_wall_s": round(wall, 3),
+            "mixed_share_of_wall_verify": round(tv / wall, 3),
+            "note": "one default handle, nothing freed between the calls: the verify step's inputs and workspaces (~80 GB) stay resident beside the handle's own "
+                    "table; verify sets of 1024 batches and commitment launches alternate from one host thread"}
 
 
 def mid_size_leg(L, s, t_blobs, t_c, t_p, n_local, g=1024, depth=3, steps=24):
@@ -1140,6 +1331,38 @@ def run_sweep(args, kz, L, s, dev, random_blob):
     for name in gpu_ops:
         assert gpu_ops[name]() is not False
         single[name] = {"gpu": timeit(gpu_ops[name], 15), "cpu_port_1_thread": timeit(cpu_ops[name], 5, warm=1)}
+    # the *_many forms of the single-proof functions (one verify_kzg_proof per call is a 1.9 ms latency-bound chain on a GPU; the reference's
+    # bench shape, benches/kzg_benches.rs:58-91, has no batched counterpart): units per second of ONE call over many units, next to the CPU port's per-call rate
+    zs = [kz.Bytes32(bytes(31) + bytes([5 + i])) for i in range(n_max)]
+    pys = kz.Kzg.compute_kzg_proof_many(B, zs, s)
+    n_checks = 16384
+    reps = n_checks // n_max
+    cm = b"".join(cb) * reps; zm = b"".join(z_.to_bytes() for z_ in zs) * reps
+    ym = b"".join(y_.to_bytes() for _, y_ in pys) * reps; pm = b"".join(p_.to_bytes() for p_, _ in pys) * reps
+    okm = (C.c_bool * n_checks)(); stm = (C.c_int * n_checks)()
+
+    def many_verify():
+        rc = L.kzg355_verify_kzg_proof_many(okm, stm, cm, zm, ym, pm, n_checks, s.handle)
+        assert rc == 0 and bytes(okm) == b"\x01" * n_checks
+    flat_all = b"".join(blobs)
+    okb = (C.c_bool * n_max)(); stb = (C.c_int * n_max)()
+    outp = C.create_string_buffer(48 * n_max); outy = C.create_string_buffer(32 * n_max)
+    zflat = b"".join(z_.to_bytes() for z_ in zs)
+
+    def many_verify_blob():
+        rc = L.kzg355_verify_blob_kzg_proof_many(okb, stb, flat_all, b"".join(cb), b"".join(pb), n_max, s.handle)
+        assert rc == 0 and bytes(okb) == b"\x01" * n_max
+
+    def many_compute():
+        rc = L.kzg355_compute_kzg_proof_many(outp, outy, stb, flat_all, zflat, n_max, s.handle)
+        assert rc == 0 and outp.raw == b"".join(p_.to_bytes() for p_, _ in pys)
+    many = {}
+    for name, fn, units, cpu_name in (("verify_kzg_proof_many", many_verify, n_checks, "verify_kzg_proof"), ("verify_blob_kzg_proof_many", many_verify_blob, n_max, "verify_blob_kzg_proof"),
+                                      ("compute_kzg_proof_many", many_compute, n_max, "compute_kzg_proof")):
+        g = timeit(fn, 7)
+        cpu_ms = single[cpu_name]["cpu_port_1_thread"]["median_ms"]
+        many[name] = {"units_per_call": units, "gpu": dict(g, units_per_s=round(units / (g["median_ms"] / 1e3), 1)),
+                      "cpu_port_1_thread_units_per_s": round(1e3 / cpu_ms, 1), "gpu_single_call_units_per_s": round(1e3 / single[cpu_name]["gpu"]["median_ms"], 1)}
     sweep = {}
     flat = b"".join(blobs)
     ok1 = C.c_bool()
@@ -1159,7 +1382,11 @@ def run_sweep(args, kz, L, s, dev, random_blob):
             "n_gpus": 1, "steps": 15, "warmup": 2, "ms_per_step": g64["median_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (29-bit) / 64-bit accumulate, u8 bytes", "data": "synthetic",
             "config": {"workload": "benches/kzg_benches.rs:46-126: five single-op benches + verify_blob_kzg_proof_batch/{1,2,4,8,16,32,64}, one call at a time, host buffers",
-                       "single_op": single, "verify_blob_kzg_proof_batch": sweep},
+                       "verify_kzg_proof_many_per_s": many["verify_kzg_proof_many"]["gpu"]["units_per_s"],
+                       "verify_kzg_proof_cpu_port_per_s": many["verify_kzg_proof_many"]["cpu_port_1_thread_units_per_s"],
+                       "verify_blob_kzg_proof_many_per_s": many["verify_blob_kzg_proof_many"]["gpu"]["units_per_s"],
+                       "compute_kzg_proof_many_per_s": many["compute_kzg_proof_many"]["gpu"]["units_per_s"],
+                       "single_op": single, "many_forms": many, "verify_blob_kzg_proof_batch": sweep},
             "roofline": None, "cpu_baseline": {"value": sweep["64"]["cpu_port_1_thread"]["blobs_per_s"], "unit": "blobs/s", "cores": 1, "kind": "port",
                                                "sample": "per-n / per-op figures under config; oracle -O3 -march=native, restatement in portable C, not blst"}}
 
@@ -1175,7 +1402,7 @@ def cpu_model():
     return None
 
 
-def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
+def time_cpu_baseline(op, commitments, proofs, host_blobs, n, match_threads=None, all_threads=True):
     """The CPU oracle (kind "port": the build's restatement of the reference algorithm, NOT blst) on the host cores of
     this box: verify_blob_kzg_proof_batch over the same first 64-blob batch, single thread like the reference."""
     from oracle.oracle import Oracle, build
@@ -1245,9 +1472,15 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
         for t in th: t.join()
         return sum(done) / (time.perf_counter() - t0)
     # the box's CPUs are shared with the other GPUs' jobs: try its per-GPU share and every CPU this process may run on, keep the better
-    trials = {c: run_threads(c) for c in sorted({min(avail, 64), avail})}
-    cores = max(trials, key=trials.get)
-    all_cores = trials[cores]
+    trials = {c: run_threads(c) for c in sorted({min(avail, 64), avail})} if all_threads else {}
+    cores = max(trials, key=trials.get) if trials else None
+    all_cores = trials[cores] if trials else None
+    # the reference-shaped single call (config.single_call_ms) hashes on config.single_call_host_threads host threads beside the GPU; the CPU
+    # figure to hold against it is the port on AS MANY threads (one batch per thread), not one core
+    matched = None
+    if match_threads and match_threads > 1:
+        k = min(int(match_threads), avail)
+        matched = {"value": trials[k] if k in trials else run_threads(k), "threads": k}
     o.free_trusted_setup(so)
     what = {"verify": "verify_blob_kzg_proof_batch(n=64) on the bench's first batch", "commit": "blob_to_kzg_commitment on blobs of the first batch",
             "proof": "compute_blob_kzg_proof on blobs of the first batch"}[op]
@@ -1256,8 +1489,10 @@ def time_cpu_baseline(op, commitments, proofs, host_blobs, n):
                       + (": Montgomery products with mulx / adcx / adox, SHA-256 with the SHA extensions (the portable-C form of the same code: portable_c_value)" if fast else
                          " (portable C: this host has no BMI2 + ADX; blst's asm is likely 1.5-3x faster per core)"),
             "primitives": "mulx/adcx/adox + sha-ni" if fast else "portable C", "portable_c_value": portable,
-            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
-                          "note": "same work, one call per thread, ~5 s per trial; best of the trials"}}
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+            "threads_matched_value": matched["value"] if matched else None, "threads_matched_threads": matched["threads"] if matched else None,
+            "all_cores": {"value": all_cores, "threads": cores, "cpus_available": avail, "trials": {str(k): round(v, 1) for k, v in trials.items()},
+                          "note": "same work, one call per thread, ~5 s per trial; best of the trials"} if trials else None}
 
 
 if __name__ == "__main__":

@@ -308,6 +308,9 @@ const char *kzg355_version(void);
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs);
 /* How many host-buffer calls on this handle had their challenges hashed on the host so far. */
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s);
+/* Host threads that hash for one call on this handle: the handle's workers plus the calling thread (kzg355_options.host_threads; the default is
+ * min(16, cpus / 2)).  A CPU figure quoted next to a host-hashed call should use as many threads (bench.py: cpu_baseline.threads_matched_value). */
+int kzg355_settings_host_threads(const kzg355_settings *s);
 /* The host hash itself, exported for the tests (tests/test_host_sha256.py checks it against hashlib): impl 0 auto, 1 portable C,
  * 2 SHA extensions (KZG355_INTERNAL if the CPU has none).  kzg355_host_challenge_digests writes the n digests of
  * "FSBLOBVERIFY_V1_" | u64be(0) | u64be(blob_bytes / 32) | blob_i | commitment_i. */

@@ -72,6 +72,7 @@ def load():
         "kzg355_debug_batch_intermediates": [u8p, bp, ip, vp, sz, sz, vp],
         "kzg355_kernel_ms_stats": [vp, u8p, C.POINTER(C.c_double), C.POINTER(C.c_long)],
         "kzg355_settings_device": [vp],
+        "kzg355_settings_host_threads": [vp],
         "kzg355_settings_msm_form": [vp],
         "kzg355_load_trusted_setup_devices": [u8p, sz, u8p, sz, C.POINTER(C.c_int), sz, C.POINTER(vp)],
         "kzg355_settings_device_count": [vp],
@@ -128,5 +129,5 @@ EXPORTED_SYMBOLS = [
     "kzg355_verify_blob_kzg_proof_batch_many_device_submit", "kzg355_verify_collect", "kzg355_settings_msm_shape", "kzg355_settings_build_msm_table",
     "kzg355_verify_shard_records_points_words_device", "kzg355_verify_records_points_words_device",
     "kzg355_verify_kzg_proof_many", "kzg355_verify_blob_kzg_proof_many", "kzg355_compute_kzg_proof_many", "kzg355_verify_kzg_proof_many_device",
-    "kzg355_compute_kzg_proof_many_device",
+    "kzg355_compute_kzg_proof_many_device", "kzg355_settings_host_threads",
 ]

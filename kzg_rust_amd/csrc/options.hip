@@ -439,6 +439,7 @@ int kzg355_settings_build_msm_table(const kzg355_settings *cs) {
 }
 void kzg355_set_kernel_timing(kzg355_settings *s, int enabled) { if (s) s->timing = enabled != 0; }
 long kzg355_settings_host_hashed_calls(const kzg355_settings *s) { return s ? s->n_host_hashed.load() : 0L; }
+int kzg355_settings_host_threads(const kzg355_settings *s) { return !s ? 0 : s->host_pool ? s->host_pool->workers() + 1 : 1; }
 int kzg355_settings_set_host_hash(kzg355_settings *s, int mode, int max_blobs) {
     if (!s || mode < -1 || mode > 1 || max_blobs < 0) return KZG355_BADARGS;
     // both Fiat-Shamir hashes follow the mode: -1 keeps the per-blob challenges AND the batch challenge r on the device

@@ -251,6 +251,11 @@ class KzgSettings:
     def host_hashed_calls(self):
         return lib().kzg355_settings_host_hashed_calls(self.handle)
 
+    @property
+    def host_threads(self):
+        """host threads that hash for one call on this handle (its workers + the calling thread)"""
+        return lib().kzg355_settings_host_threads(self.handle)
+
     def set_kernel_timing(self, enabled=True):
         lib().kzg355_set_kernel_timing(self.handle, 1 if enabled else 0)
 

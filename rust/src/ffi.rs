@@ -99,5 +99,6 @@ extern "C" {
     pub fn kzg355_settings_exchange_stats(s: *const kzg355_settings, allgathers: *mut c_long, peer_exchanges: *mut c_long) -> c_int;
     pub fn kzg355_settings_set_host_hash(s: *mut kzg355_settings, mode: c_int, max_blobs: c_int) -> c_int;
     pub fn kzg355_settings_host_hashed_calls(s: *const kzg355_settings) -> c_long;
+    pub fn kzg355_settings_host_threads(s: *const kzg355_settings) -> c_int;
     pub fn kzg355_version() -> *const c_char;
 }
