@@ -461,7 +461,8 @@ KZG_HD Fr fr_one() { const uint32_t c[NFR] = FR_ONE_INIT; Fr r; for (int i = 0; 
 KZG_HD void fr_add(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_add<NFR>(r.l, a.l, b.l, FR_MOD); }
 KZG_HD void fr_sub(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mod_sub<NFR>(r.l, a.l, b.l, FR_MOD); }
 KZG_HD void fr_mul(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
-KZG_HD void fr_sqr(Fr &r, const Fr &a) { fr_mul(r, a, a); }
+// (a squaring of its own like Fp's: 45 + 81 limb products instead of 162 -- the twelve z powers per blob of the challenge kernel, the r-power ladders)
+KZG_HD void fr_sqr(Fr &r, const Fr &a) { KZG_FR_CONSTS mont_sqr<NFR>(r.l, a.l, FR_MOD, FR_INVW); }
 // lazy product: operands < ~2.6 r, result < 1.1 r, not canonical (see mont_mul_lazy)
 KZG_HD void fr_mul_lazy(Fr &r, const Fr &a, const Fr &b) { KZG_FR_CONSTS mont_mul_lazy<NFR>(r.l, a.l, b.l, FR_MOD, FR_INVW); }
 // r = a*b + c*d with one reduction (lazy; result < 1.1 r for a*b + c*d < ~5 r^2)

@@ -39,6 +39,7 @@ int hd_fr_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
         case 3: fr_inv_fermat(r, x); break;
         case 4: { be32_to_words(w, a); out[0] = fr_words_canonical(w); return 0; }
         case 5: fr_inv(r, x); break;
+        case 6: fr_sqr(r, x); break;
         default: return 1;
     }
     fr_to_be32(out, r); return 0;

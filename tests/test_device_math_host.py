@@ -79,6 +79,7 @@ def test_fr_arithmetic(hd):
         assert int.from_bytes(out.raw, "big") == (a * b + c * d) % R
     for a in vals:
         assert _fr(hd, 5, a)[1] == (pow(a % R, -1, R) if a % R else 0), hex(a)
+        assert _fr(hd, 6, a)[1] == a * a % R, hex(a)              # the dedicated squaring (mont_sqr<9>)
     for a in vals[:12]:
         if a % R:
             assert _fr(hd, 3, a)[1] == pow(a, -1, R)
