@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkzg355.so")
+# (KZG355_LIBRARY: another build of the same library, for A/B measurements of compiler flags on one box -- tools only; there is still no fallback)
+LIB_PATH = os.environ.get("KZG355_LIBRARY") or os.path.join(_HERE, "libkzg355.so")
 
 
 class KzgLibraryMissing(ImportError):
