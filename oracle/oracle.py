@@ -26,6 +26,12 @@ def build(native=False):
 def _load(native=False, preset="mainnet"):
     name = "liboracle_minimal.so" if preset == "minimal" else "liboracle_native.so" if native else "liboracle.so"
     path = os.path.join(_HERE, name)
+    # tests/test_sanitizers.py: the AddressSanitizer / UndefinedBehaviorSanitizer build of the same two sources (`make asan`), loaded into a Python
+    # that was started with the sanitizer runtime preloaded
+    if os.environ.get("KZG355_ORACLE_ASAN") == "1" and preset != "minimal":
+        path = os.path.join(_HERE, "liboracle_asan.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, "asan"], check=True, stdout=subprocess.DEVNULL)
     if not os.path.exists(path):
         build(native and preset != "minimal")
     lib = C.CDLL(path)

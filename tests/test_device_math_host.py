@@ -21,8 +21,13 @@ def hd():
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
                     ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h", "quot_core.h")]
+    flags = ["-O2"]
+    if os.environ.get("KZG355_HD_PROBE_ASAN") == "1":      # tests/test_sanitizers.py: the same probe under AddressSanitizer + UndefinedBehaviorSanitizer
+        so = os.path.join(NATIVE, "libhd_probe_asan.so")
+        # (-O0 and no -g: the instrumented compile of these headers takes 44 s this way, 2 min 10 s at -O1 and ~10 min with debug info; the run is a minute either way)
+        flags = ["-O0", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
+        subprocess.run(["g++"] + flags + ["-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
 
 
