@@ -284,7 +284,8 @@ inline bool is_small(const kzg355_settings *s) { return s->t.n_fe != N_FE; }
 inline size_t blob_bytes_of(const kzg355_settings *s) { return (size_t)32 * s->t.n_fe; }
 
 // which form the batch linear combination takes (KZG355_LINCOMB pins it: 1 window, 2 bucket, 3 pre-shifted)
-enum { LC_FORM_WINDOW = 1, LC_FORM_BUCKET = 2, LC_FORM_PRESHIFT = 3, LC_FORM_SINGLE = 4 /* one record per batch, many batches: never pinned, chosen by shape */ };
+enum { LC_FORM_WINDOW = 1, LC_FORM_BUCKET = 2, LC_FORM_PRESHIFT = 3,
+        LC_FORM_SINGLE = 4 /* one record per batch, many batches: never pinned, chosen by shape */ };
 
 // ---- stage drivers (all asynchronous on w->stream) -------------------------------------------------
 // Host-hashed challenges of a small host-buffer call (host_sha256.h): a job on the handle's host threads is writing the digests of
@@ -319,7 +320,8 @@ struct HostFront {
 //                     for host memory bandwidth; kept for hosts where page locking is expensive.
 // Results are collected in chunk order; a failure waits for everything in flight before the workspaces go back to the pool.
 struct HostCall {
-    int kind;                        // 0 verify, 1 commit, 2 blob proof, 3 proof at a given z per blob (compute_kzg_proof: `commitments` is null, zs / ys_out set)
+    // 0 verify, 1 commit, 2 blob proof, 3 proof at a given z per blob (compute_kzg_proof: `commitments` is null, zs / ys_out set)
+    int kind;
     const uint8_t *blobs, *commitments, *proofs;
     size_t npg;                      // blobs per unit
     bool *ok; uint8_t *out48; int *status;

@@ -429,7 +429,8 @@ int kzg355_verify_kzg_proof_many(bool *ok, int *status, const uint8_t *commitmen
         MultiDev *m = cs->multi;
         return fan_out(m->rep.size(), n, [&](size_t d, size_t i0, size_t cnt) -> int {
             if (hipSetDevice(m->rep[d]->device) != hipSuccess) return KZG355_NO_DEVICE;
-            return verify_proofs_on_one_device(ok + i0, status ? status + i0 : nullptr, commitments + 48 * i0, zs + 32 * i0, ys + 32 * i0, proofs + 48 * i0, cnt,
+            return verify_proofs_on_one_device(ok + i0, status ? status + i0 : nullptr, commitments + 48 * i0, zs + 32 * i0, ys + 32 * i0, proofs + 48 * i0,
+                    cnt,
                     m->rep[d]);
         });
     }

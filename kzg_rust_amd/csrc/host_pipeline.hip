@@ -67,7 +67,8 @@ int host_pipeline(const HostCall &hc, size_t units, const kzg355_settings *cs) {
         const size_t u0 = pend[slot].u0, cnt = pend[slot].cnt;
         pend[slot].cnt = 0;
         int rc = hc.kind == 0 ? verify_collect(w, tms[slot], hc.ok + u0, hc.status ? hc.status + u0 : nullptr, (int)cnt)
-                              : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt, hc.ys_out ? hc.ys_out + 32 * u0 : nullptr);
+                              : msm_op_collect(w, tms[slot], hc.out48 + 48 * u0, hc.status ? hc.status + u0 : nullptr, cnt,
+                                      hc.ys_out ? hc.ys_out + 32 * u0 : nullptr);
         if (hc.records_out && hc.kind == 0 && hipMemcpy(hc.records_out + (size_t)RECORD_BYTES * hc.npg * u0, w->records.p, (size_t)RECORD_BYTES * hc.npg * cnt,
                 hipMemcpyDeviceToHost) != hipSuccess) return KZG355_DEVICE_ERROR;
         if (rc == KZG355_NO_DEVICE || rc == KZG355_NO_MEMORY || rc == KZG355_DEVICE_ERROR) return rc;
