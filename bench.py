@@ -1344,21 +1344,25 @@ def run_sweep(args, kz, L, s, dev, random_blob):
     def many_verify():
         rc = L.kzg355_verify_kzg_proof_many(okm, stm, cm, zm, ym, pm, n_checks, s.handle)
         assert rc == 0 and bytes(okm) == b"\x01" * n_checks
-    flat_all = b"".join(blobs)
-    okb = (C.c_bool * n_max)(); stb = (C.c_int * n_max)()
-    outp = C.create_string_buffer(48 * n_max); outy = C.create_string_buffer(32 * n_max)
-    zflat = b"".join(z_.to_bytes() for z_ in zs)
+    n_units = 1024                                                # blob forms: the 64 blobs tiled to 1024 units (128 MiB of host memory per call)
+    tile = n_units // n_max
+    flat_all = b"".join(blobs) * tile
+    cflat, pflat = b"".join(cb) * tile, b"".join(pb) * tile
+    okb = (C.c_bool * n_units)(); stb = (C.c_int * n_units)()
+    outp = C.create_string_buffer(48 * n_units); outy = C.create_string_buffer(32 * n_units)
+    zflat = b"".join(z_.to_bytes() for z_ in zs) * tile
+    want_p = b"".join(p_.to_bytes() for p_, _ in pys) * tile
 
     def many_verify_blob():
-        rc = L.kzg355_verify_blob_kzg_proof_many(okb, stb, flat_all, b"".join(cb), b"".join(pb), n_max, s.handle)
-        assert rc == 0 and bytes(okb) == b"\x01" * n_max
+        rc = L.kzg355_verify_blob_kzg_proof_many(okb, stb, flat_all, cflat, pflat, n_units, s.handle)
+        assert rc == 0 and bytes(okb) == b"\x01" * n_units
 
     def many_compute():
-        rc = L.kzg355_compute_kzg_proof_many(outp, outy, stb, flat_all, zflat, n_max, s.handle)
-        assert rc == 0 and outp.raw == b"".join(p_.to_bytes() for p_, _ in pys)
+        rc = L.kzg355_compute_kzg_proof_many(outp, outy, stb, flat_all, zflat, n_units, s.handle)
+        assert rc == 0 and outp.raw == want_p
     many = {}
-    for name, fn, units, cpu_name in (("verify_kzg_proof_many", many_verify, n_checks, "verify_kzg_proof"), ("verify_blob_kzg_proof_many", many_verify_blob, n_max, "verify_blob_kzg_proof"),
-                                      ("compute_kzg_proof_many", many_compute, n_max, "compute_kzg_proof")):
+    for name, fn, units, cpu_name in (("verify_kzg_proof_many", many_verify, n_checks, "verify_kzg_proof"), ("verify_blob_kzg_proof_many", many_verify_blob, n_units, "verify_blob_kzg_proof"),
+                                      ("compute_kzg_proof_many", many_compute, n_units, "compute_kzg_proof")):
         g = timeit(fn, 7)
         cpu_ms = single[cpu_name]["cpu_port_1_thread"]["median_ms"]
         many[name] = {"units_per_call": units, "gpu": dict(g, units_per_s=round(units / (g["median_ms"] / 1e3), 1)),
