@@ -483,31 +483,7 @@ KZG_HD void coop_fp_lincomb(CoopMem &m, Fp *dst, int n, const int8_t (*tab)[COOP
 }
 // V: 24 Fp of scratch (two Fp12 slots the program does not hold anything in at this point)
 KZG_HD void coop_fp6_inv(CoopMem &m, Fp12W &x, Fp *V) {
-    // the Fp2 product of operands at V[x], V[x + 1] and V[y], V[y + 1]: products x0 y0, x1 y1, x0 y1, x1 y0 on four lanes; with them at
-    // red[4k .. 4k + 3] the result is (r0 - r1, r2 + r3)
-#define KZG_FP2P_A(x, y) x, x + 1, x, x + 1
-#define KZG_FP2P_B(x, y) y, y + 1, y + 1, y
-    // V[0..5] = a0, a1, a2 (c0, c1 each); V[6..11] = A, B, C; V[12..13] = D; V[14] = 1 / (D0^2 + D1^2); V[15..16] = 1 / D
-    static const uint8_t s1a[24] = {KZG_FP2P_A(0, 0), KZG_FP2P_A(2, 4), KZG_FP2P_A(4, 4), KZG_FP2P_A(0, 2), KZG_FP2P_A(2, 2), KZG_FP2P_A(0, 4)};
-    static const uint8_t s1b[24] = {KZG_FP2P_B(0, 0), KZG_FP2P_B(2, 4), KZG_FP2P_B(4, 4), KZG_FP2P_B(0, 2), KZG_FP2P_B(2, 2), KZG_FP2P_B(0, 4)};
-    static const uint8_t s3a[12] = {KZG_FP2P_A(0, 6), KZG_FP2P_A(4, 8), KZG_FP2P_A(2, 10)};
-    static const uint8_t s3b[12] = {KZG_FP2P_B(0, 6), KZG_FP2P_B(4, 8), KZG_FP2P_B(2, 10)};
-    static const uint8_t s5a[2] = {12, 13}, s5b[2] = {12, 13};
-    static const uint8_t s7a[2] = {12, 13}, s7b[2] = {14, 14};
-    static const uint8_t s8a[12] = {KZG_FP2P_A(6, 15), KZG_FP2P_A(8, 15), KZG_FP2P_A(10, 15)};
-    static const uint8_t s8b[12] = {KZG_FP2P_B(6, 15), KZG_FP2P_B(8, 15), KZG_FP2P_B(10, 15)};
-#undef KZG_FP2P_A
-#undef KZG_FP2P_B
-    // rows are 1-based indices into red, signed.  With P_k = (r[4k] - r[4k+1], r[4k+2] + r[4k+3]) and xi (m0, m1) = (m0 - m1, m0 + m1):
-    // a_j = (lo + hi, hi) from w^(2j), w^(2j+6)
-    static const int8_t l0[6][COOP_LIN_W] = {{1, 2}, {2}, {3, 4}, {4}, {5, 6}, {6}};
-    static const int8_t l2[6][COOP_LIN_W] = {{1, -2, -5, 6, 7, 8}, {3, 4, -5, 6, -7, -8},                            // A = P0 - xi P1
-                                             {9, -10, -11, -12, -13, 14}, {9, -10, 11, 12, -15, -16},                // B = xi P2 - P3
-                                             {17, -18, -21, 22}, {19, 20, -23, -24}};                                // C = P4 - P5
-    static const int8_t l4[2][COOP_LIN_W] = {{1, -2, 5, -6, 9, -10, -7, -8, -11, -12}, {3, 4, 5, -6, 9, -10, 7, 8, 11, 12}};   // D = Q0 + xi (Q1 + Q2)
-    static const int8_t l7[2][COOP_LIN_W] = {{1}, {-2}};                                                               // 1 / D = (D0, -D1) / (D0^2 + D1^2)
-    static const int8_t l9[12][COOP_LIN_W] = {{1, -2, -3, -4}, {0}, {5, -6, -7, -8}, {0}, {9, -10, -11, -12}, {0},     // w^(2j): r0 - r1
-                                              {3, 4}, {0}, {7, 8}, {0}, {11, 12}, {0}};                                // w^(2j+6): r1
+#include "fp6inv_tables.inc"
     COOP_LANES(lane) {      // lazy -> canonical: (lo_0, hi_0, lo_1, hi_1, lo_2, hi_2) = coefficients 0, 6, 2, 8, 4, 10
         if (lane < 6) { Fp c; fp_norm_lz(c, x.c[2 * (lane >> 1) + 6 * (lane & 1)]); fp_canon64(c, c); m.red[lane] = c; }
     }

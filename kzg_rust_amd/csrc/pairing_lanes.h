@@ -39,7 +39,7 @@
 namespace kzg {
 
 constexpr int L12_BATCHES = 5;                         // checks per wave (lanes 60 .. 63 idle)
-struct L12Mem { Fp12W s[4]; Fp x[12]; };               // per check: slots F, T0, T1, T2 of the hard part's program, and one exchange row
+struct L12Mem { Fp12W s[4]; };                         // per check: slots F, T0, T1, T2 of the hard part's program
 
 // r = ma * a + mb * b, limbs normalised (ma, mb <= 4; operands within the invariant)
 KZG_HD void l12_lin(Fp &r, const Fp &a, uint32_t ma, const Fp &b, uint32_t mb) {
@@ -115,46 +115,60 @@ KZG_HD void l12_cyc_sqr(Fp12W &dst, const Fp12W &a) {
     L12_LANES(k) { dst.c[k] = outv[L12_AT(k)]; }
     L12_SYNC();
 }
-// dst = a * b.  Lane k: d_k = sum_{i <= k} a_i b_{k-i} and e_k = d_{k+12} = sum_{i > k} a_i b_{k+12-i}, each reduced once (carry sweeps between
-// the products keep the 64-bit columns in range); the e's go through the exchange row, and the fold w^12 = 2 w^6 - 2 is
-//     k <= 5:  c_k = d_k - 2 e_k - 4 e_{k+6}          k >= 6:  c_k = d_k + 2 e_k + 2 e_{k-6}.          dst may alias a or b.
-KZG_HD void l12_mul(Fp12W &dst, const Fp12W &a, const Fp12W &b, Fp *xrow) {
-    Fp dk[L12_LOCALS], ek[L12_LOCALS];
+// ---- full products without an exchange (round 6; the exchange form it replaced: 23 lockstep limb products, two reductions, one exchange row).
+// c = a * b with the fold applied to the OPERAND: coefficient k of (w^j a) after w^12 = 2 w^6 - 2
+// (so w^18 = 2 w^12 - 4 w^6 ... = 2 w^(s-12) - 4 w^(s-18) for s >= 18) is a combination of at most TWO coefficients of a with small weights,
+//     k <= 5:   j <= k:  a_{k-j}                                   j > k:  -2 a_{k+12-j}   (and -4 a_{k+18-j} when j >= k + 7)
+//     k >= 6:   j <= k:  a_{k-j}  (+ 2 a_{k+6-j} when j >= k - 5)  j > k:   2 a_{k+6-j}    (+ 2 a_{k+12-j} when k <= 10),
+// so lane k forms  c_k = sum_j b_j A^(j)_k  with ONE accumulator and ONE Montgomery reduction: 12 limb products for a full product (6 for a line or an
+// even-only operand) instead of 23 in lockstep + two reductions + an exchange row, and nothing to fold afterwards.
+struct L12Fold { int ix, iy, wx, wy; };
+KZG_HD L12Fold l12_fold(int k, int j) {
+    L12Fold f; f.wy = 0;
+    if (k <= 5) {
+        if (j <= k) { f.ix = k - j; f.wx = 1; } else { f.ix = k + 12 - j; f.wx = -2; }
+        f.iy = f.ix;
+        if (j >= k + 7) { f.iy = k + 18 - j; f.wy = -4; }
+    } else {
+        if (j <= k) { f.ix = k - j; f.wx = 1; f.iy = f.ix; if (j >= k - 5) { f.iy = k + 6 - j; f.wy = 2; } }
+        else { f.ix = k + 6 - j; f.wx = 2; f.iy = f.ix; if (k <= 10) { f.iy = k + 12 - j; f.wy = 2; } }
+    }
+    return f;
+}
+// A = wx X + wy Y (+ 16 p when a weight is negative: X, Y <= 2p, so the value stays in (0, 22 p]); limbs normalised below the top one
+KZG_HD void l12_fold_operand(Fp &A, const Fp12W &a, int k, int j) {
+    const uint32_t m16[NFP] = FP_MOD16_INIT;
+    const L12Fold f = l12_fold(k, j);
+    const Fp &X = a.c[f.ix], &Y = a.c[f.iy];
+    const bool neg = f.wx < 0;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NFP; i++) {
+        const int64_t t = (int64_t)(neg ? m16[i] : 0u) + (int64_t)f.wx * (int64_t)(int32_t)X.l[i] + (int64_t)f.wy * (int64_t)(int32_t)Y.l[i] + c;
+        if (i < NFP - 1) { c = t >> LB; A.l[i] = (uint32_t)t & LMASK; } else A.l[i] = (uint32_t)t;
+    }
+}
+// dst = a * b over the coefficients of b in jmask (FULL_MASK; EVEN_MASK; LINE_MASK for an evaluated line, whose other coefficients are never read).
+// Coefficients of a, b within [0, 2p]; result below p (1 + 2^-13), limbs normalised.  dst may alias a or b.
+KZG_HD void l12_mulf(Fp12W &dst, const Fp12W &a, const Fp12W &b, uint32_t jmask) {
+    Fp outv[L12_LOCALS];
     L12_LANES(k) {
         uint64_t acc[2 * NFP];
         wide_zero(acc);
+        int n = 0;
 #pragma unroll 1
-        for (int i = 0; i < 12; i++) {
-            if (i <= k) wide_mac(acc, a.c[i].l, b.c[k - i].l);
-            if (i % 3 == 2) wide_carry(acc);                        // (at most three products since the last sweep, whatever the lane)
-        }
-        Fp d; wide_reduce(d, acc);
-        wide_zero(acc);
-#pragma unroll 1
-        for (int i = 1; i < 12; i++) {
-            if (i > k) wide_mac(acc, a.c[i].l, b.c[k + 12 - i].l);
-            if (i % 3 == 2) wide_carry(acc);
+        for (int j = 0; j < 12; j++) {
+            if (!((jmask >> j) & 1u)) continue;                     // (uniform)
+            Fp A; l12_fold_operand(A, a, k, j);
+            wide_mac(acc, A.l, b.c[j].l);
+            if (++n == 3) { wide_carry(acc); n = 0; }               // three products of normalised limbs between sweeps keep the columns below 2^64
         }
         wide_carry(acc);
-        Fp e; wide_reduce(e, acc);                                  // (k = 11: nothing to add, e = 0)
-        dk[L12_AT(k)] = d; ek[L12_AT(k)] = e;
+        Fp r; wide_reduce(r, acc);                                  // T <= 12 * 22p * 2p < 2^20 p^2
+        outv[L12_AT(k)] = r;
     }
     L12_SYNC();
-    L12_LANES(k) { xrow[k] = ek[L12_AT(k)]; }
-    L12_SYNC();
-    L12_LANES(k) {
-        const uint32_t m8[NFP] = FP_MOD8_INIT;
-        const Fp z = fp_zero();
-        const Fp d = dk[L12_AT(k)], e = ek[L12_AT(k)];
-        Fp o, t;
-        if (k <= 5) { l12_lin(t, e, 2, xrow[k + 6], 4); fp_sub_lz(o, d, t, m8); }      // d - 2 e_k - 4 e_{k+6} + 8p          <= 9.1 p
-        else { l12_lin(t, e, 2, xrow[k - 6], 2); fp_add_lz(o, d, t); }                 // d + 2 e_k + 2 e_{k-6}               <= 5.2 p
-        (void)z;
-        l12_below_2p(o);
-        dk[L12_AT(k)] = o;
-    }
-    L12_SYNC();
-    L12_LANES(k) { dst.c[k] = dk[L12_AT(k)]; }
+    L12_LANES(k) { dst.c[k] = outv[L12_AT(k)]; }
     L12_SYNC();
 }
 KZG_HD void l12_copy(Fp12W &dst, const Fp12W &a) {
@@ -213,10 +227,9 @@ KZG_HD void l12_run(L12Mem &m, const CoopInsn *prog, int pc0, int pc1, const Fro
         const Fp12W &a = m.s[in.a];
         switch (in.op) {
             case OP_CYC_SQR: l12_cyc_sqr(dst, a); break;
-            case OP_MUL: l12_mul(dst, a, m.s[in.b], m.x); break;
+            case OP_MUL: l12_mulf(dst, a, m.s[in.b], FULL_MASK); break;
             case OP_CONJ: l12_conj(dst, a); break;
-            case OP_FROB1: l12_frob(dst, a, ft.a1, ft.b1); break;
-            case OP_FROB2: l12_frob(dst, a, ft.a2, nullptr); break;
+            case OP_FROB1: case OP_FROB2: l12_frob(dst, a, in.op == OP_FROB1 ? ft.a1 : ft.a2, in.op == OP_FROB1 ? ft.b1 : nullptr); break;
             default: l12_copy(dst, a); break;
         }
     }

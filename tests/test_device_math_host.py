@@ -20,7 +20,7 @@ def hd():
     src = os.path.join(NATIVE, "hd_probe.cpp")
     so = os.path.join(NATIVE, "libhd_probe.so")
     deps = [src] + [os.path.join(HERE, "..", "kzg_rust_amd", "csrc", f) for f in
-                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h", "quot_core.h")]
+                    ("field.h", "tower.h", "g1.h", "pairing.h", "pairing_coop.h", "pairing_lanes.h", "modinv.h", "sha256.h", "consts_gen.h", "eval_core.h", "quot_core.h", "fp6inv_tables.inc")]
     flags = ["-O2"]
     if os.environ.get("KZG355_HD_PROBE_ASAN") == "1":      # tests/test_sanitizers.py: the same probe under AddressSanitizer + UndefinedBehaviorSanitizer
         so = os.path.join(NATIVE, "libhd_probe_asan.so")
