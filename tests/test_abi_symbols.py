@@ -117,6 +117,30 @@ def test_options_struct_defaults_env_overrides_and_layout(lib, monkeypatch):
     assert o.msm_bits == 8
     lib.kzg355_options_default(C.byref(o))                       # the explicit form never reads the environment
     assert (o.msm_bits, o.host_hash, o.self_test) == (0, 0, 1)
+    # every KZG355_* override kzg355_options_from_env knows, name by name -> the field it sets (the library's one reader of the environment: options.hip)
+    table = {"KZG355_MSM_EAGER": ("1", "msm_eager", 1), "KZG355_MSM_GLV": ("off", "msm_glv", -1), "KZG355_PAIRING": ("lane", "pairing_lane", 1),
+             "KZG355_HOST_THREADS": ("5", "host_threads", 5), "KZG355_HOST_SHA": ("portable", "host_sha", 1), "KZG355_HOST_RHASH": ("off", "host_rhash", -1),
+             "KZG355_HOST_RHASH_MAX": ("33", "host_rhash_max_records", 33), "KZG355_HOST_HASH_DEVICE_MAX": ("0", "host_hash_device_max_blobs", -1),
+             "KZG355_CHUNK_MB": ("7", "chunk_mb", 7), "KZG355_CHUNKS_IN_FLIGHT": ("2", "chunks_in_flight", 2), "KZG355_STAGING": ("ring", "staging_ring", 1),
+             "KZG355_PAIRING_HARD12_FROM": ("0", "pairing_hard12_from", -1), "KZG355_LC_CHAIN_FROM": ("9", "lc_chain_from", 9),
+             "KZG355_RHASH_LANES_FROM": ("11", "rhash_lanes_from", 11), "KZG355_CHALLENGE": ("2w", "challenge_form", 2), "KZG355_VERIFY_ONLY": ("1", "verify_only", 1),
+             "KZG355_SUBMIT": ("pipeline", "submit_sets", 2), "KZG355_QUOTIENT_FORM": ("6", "quotient_form", 6), "KZG355_MILLER_SEGMENTS": ("3", "miller_segments", 3),
+             "KZG355_FORCE_MULTI": ("1", "force_multi", 1), "KZG355_FORCE_SHARDED": ("1", "force_sharded", 1), "KZG355_MSM": ("wide", "msm_require_wide", 1)}
+    for k in list(os.environ):
+        if k.startswith("KZG355_"):
+            monkeypatch.delenv(k)
+    for name, (value, field, want) in table.items():
+        monkeypatch.setenv(name, value)
+        lib.kzg355_options_from_env(C.byref(o))
+        assert getattr(o, field) == want, (name, field, getattr(o, field))
+        monkeypatch.delenv(name)
+        lib.kzg355_options_from_env(C.byref(o))
+        assert getattr(o, field) == (1 if field == "self_test" else -1 if field == "device" else 0), name
+    # ... and nothing in the library reads the environment outside options.hip
+    csrc = os.path.join(ROOT, "kzg_rust_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")) and f != "options.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_load_ex_checks_counts_before_any_device_work(lib):

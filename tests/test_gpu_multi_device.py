@@ -74,6 +74,12 @@ def test_two_replicas_shard_one_batch(kz, setup_bytes, data):
 
 def test_two_replicas_fan_out_independent_units(kz, setup_bytes, data):
     s1, B, cs, ps = data
+    sd = _load(kz, setup_bytes, None, KZG355_DEVICES="0,0")      # the plain load function with the device list from the environment
+    try:
+        assert sd.device_count == 2
+        assert kz.Kzg.verify_blob_kzg_proof_batch(B[:8], cs[:8], ps[:8], sd) is True
+    finally:
+        sd.free()
     s = _load(kz, setup_bytes, [0, 0])
     try:
         groups = [(B[6 * g:6 * g + 6], cs[6 * g:6 * g + 6], ps[6 * g:6 * g + 6]) for g in range(4)]
