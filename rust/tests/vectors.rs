@@ -150,3 +150,39 @@ fn many_extensions_agree_with_single_calls() {
     let per_blob = Kzg::verify_blob_kzg_proof_batch_many(&valid, &cs, &ps, 1, &s).unwrap();
     assert!(per_blob.into_iter().all(|r| r.unwrap()));
 }
+
+/// The single-proof functions through their `*_many` forms: every parsable `verify_kzg_proof` vector in ONE call, every parsable
+/// `compute_kzg_proof` vector in ONE call -- a unit's `Err` is that vector's null output (pass rule of src/lib.rs:189-201 per unit).
+#[test]
+fn single_proof_vectors_through_the_many_forms() {
+    let s = settings();
+    let (mut cs, mut zs, mut ys, mut ps, mut want) = (vec![], vec![], vec![], vec![], vec![]);
+    for (f, t) in cases::<Case<VerifyIn, bool>>("verify_kzg_proof", 92) {
+        let (Ok(c), Ok(z), Ok(y), Ok(p)) = (b48(&t.input.commitment), Bytes32::from_hex(&t.input.z), Bytes32::from_hex(&t.input.y), b48(&t.input.proof)) else {
+            assert!(t.output.is_none(), "{:?}", f);
+            continue;
+        };
+        cs.push(KzgCommitment(c)); zs.push(z); ys.push(y); ps.push(KzgProof(p)); want.push((f, t.output));
+    }
+    let got = Kzg::verify_kzg_proof_many(&cs, &zs, &ys, &ps, &s).unwrap();
+    assert_eq!(got.len(), want.len());
+    for (r, (f, w)) in got.into_iter().zip(want) {
+        match r { Ok(v) => assert_eq!(Some(v), w, "{:?}", f), Err(_) => assert!(w.is_none(), "{:?}", f) }
+    }
+    let (mut blobs, mut zs, mut want) = (vec![], vec![], vec![]);
+    for (f, t) in cases::<Case<ProofIn, (String, String)>>("compute_kzg_proof", 46) {
+        let (Ok(blob), Ok(z)) = (Blob::from_hex(&t.input.blob), Bytes32::from_hex(&t.input.z)) else { assert!(t.output.is_none(), "{:?}", f); continue; };
+        blobs.push(blob); zs.push(z); want.push((f, t.output));
+    }
+    let got = Kzg::compute_kzg_proof_many(&blobs, &zs, &s).unwrap();
+    for (r, (f, w)) in got.into_iter().zip(want) {
+        match r {
+            Ok((proof, y)) => {
+                let (want_proof, want_y) = w.as_ref().unwrap();
+                assert_eq!(proof.to_bytes(), *b48(want_proof).unwrap(), "{:?}", f);
+                assert_eq!(*y, *Bytes32::from_hex(want_y).unwrap(), "{:?}", f);
+            }
+            Err(_) => assert!(w.is_none(), "{:?}", f),
+        }
+    }
+}
