@@ -72,6 +72,31 @@ int main(int argc, char **argv) {
             if (bad) { std::cout << "parse" << std::endl; continue; }
             auto r = Kzg::verify_blob_kzg_proof_batch(bl, cs, ps, s);
             if (r.is_err()) err(r.error()); else std::cout << "ok " << (r.value() ? "true" : "false") << std::endl;
+        } else if (fn == "verify_kzg_proof_many" || fn == "compute_kzg_proof_many") {
+            // the *_many forms of the single-proof functions: comma-separated lists, one answer per unit: "many t f e ..." / "many <proof>:<y> e ..."
+            if (fn == "verify_kzg_proof_many") {
+                std::vector<KzgCommitment> cs; std::vector<Bytes32> zs, ys; std::vector<KzgProof> ps; bool bad = false;
+                for (auto &x : split(a[0], ',')) { auto c = KzgCommitment::from_hex(x); if (c.is_err()) bad = true; else cs.push_back(c.value()); }
+                for (auto &x : split(a[1], ',')) { auto z = Bytes32::from_hex(x); if (z.is_err()) bad = true; else zs.push_back(z.value()); }
+                for (auto &x : split(a[2], ',')) { auto y = Bytes32::from_hex(x); if (y.is_err()) bad = true; else ys.push_back(y.value()); }
+                for (auto &x : split(a[3], ',')) { auto q = KzgProof::from_hex(x); if (q.is_err()) bad = true; else ps.push_back(q.value()); }
+                if (bad) { std::cout << "parse" << std::endl; continue; }
+                auto r = Kzg::verify_kzg_proof_many(cs, zs, ys, ps, s);
+                if (r.is_err()) { err(r.error()); continue; }
+                std::cout << "many";
+                for (auto &u : r.value()) std::cout << " " << (u.is_err() ? "e" : u.value() ? "t" : "f");
+                std::cout << std::endl;
+            } else {
+                std::vector<Blob> bl; std::vector<Bytes32> zs; bool bad = false;
+                for (auto &x : split(a[0], ',')) { auto b = load_blob(x); if (b.is_err()) bad = true; else bl.push_back(b.value()); }
+                for (auto &x : split(a[1], ',')) { auto z = Bytes32::from_hex(x); if (z.is_err()) bad = true; else zs.push_back(z.value()); }
+                if (bad) { std::cout << "parse" << std::endl; continue; }
+                auto r = Kzg::compute_kzg_proof_many(bl, zs, s);
+                if (r.is_err()) { err(r.error()); continue; }
+                std::cout << "many";
+                for (auto &u : r.value()) { if (u.is_err()) std::cout << " e"; else std::cout << " " << hex(u.value().first.bytes) << ":" << hex(u.value().second.bytes); }
+                std::cout << std::endl;
+            }
         } else std::cout << "unknown" << std::endl;
     }
     return 0;

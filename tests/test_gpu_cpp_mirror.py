@@ -75,3 +75,37 @@ def test_reference_vectors_through_cpp_mirror(fn, runner, golden_vectors):
         if not good:
             failures.append(f"{case['name']}: {ans[:120]} expected {exp!r}")
     assert not failures, "\n".join(failures)
+
+
+def _parses(hexes_and_sizes):
+    for h, n in hexes_and_sizes:
+        t = h[2:] if h.startswith("0x") else h
+        try:
+            if len(bytes.fromhex(t)) != n:
+                return False
+        except ValueError:
+            return False
+    return True
+
+
+def test_single_proof_vectors_through_the_many_forms_of_the_cpp_mirror(runner, golden_vectors):
+    """kzg355::Kzg::verify_kzg_proof_many / compute_kzg_proof_many (include/kzg355.hpp): every vector whose inputs parse, in ONE call each; a unit's Err is
+    that vector's null output (src/lib.rs:189-201 per unit)."""
+    cases = [c for c in golden_vectors["verify_kzg_proof"]
+             if _parses([(c["input"]["commitment"], 48), (c["input"]["z"], 32), (c["input"]["y"], 32), (c["input"]["proof"], 48)])]
+    assert len(cases) >= 64
+    ans = _ask(runner, "verify_kzg_proof_many " + " ".join(",".join(c["input"][k] for c in cases) for k in ("commitment", "z", "y", "proof")))
+    assert ans.startswith("many "), ans[:200]
+    units = ans.split()[1:]
+    assert len(units) == len(cases)
+    bad = [c["name"] for c, u in zip(cases, units) if u != ("e" if c["output"] is None else "t" if c["output"] else "f")]
+    assert not bad, bad
+    cases = [c for c in golden_vectors["compute_kzg_proof"]
+             if "blob" in c["input"]["blob"] and os.path.getsize(_blob_arg(c["input"]["blob"])) == 131072 and _parses([(c["input"]["z"], 32)])]
+    assert len(cases) >= 30
+    ans = _ask(runner, "compute_kzg_proof_many " + ",".join(_blob_arg(c["input"]["blob"]) for c in cases) + " " + ",".join(c["input"]["z"] for c in cases))
+    assert ans.startswith("many "), ans[:200]
+    units = ans.split()[1:]
+    assert len(units) == len(cases)
+    bad = [c["name"] for c, u in zip(cases, units) if u != ("e" if c["output"] is None else f"{c['output'][0][2:]}:{c['output'][1][2:]}")]
+    assert not bad, bad

@@ -111,3 +111,25 @@ def test_quotient_tree_every_lane_shape(msm_cases, form, oracle, oracle_settings
                 assert (pr.to_bytes(), y.to_bytes()) == (wp, wy), (form, hex(zi))
     finally:
         s.free()
+
+
+def test_single_proof_many_forms_fuzz():
+    """tools/fuzz_single_many.py with fixed seeds: 1500 mutated (C, z, y, proof) tuples through kzg355_verify_kzg_proof_many in one call, in calls of 40 and on
+    device-resident records, and 96 (blob, z) pairs -- random, inside the domain, non-canonical -- through kzg355_compute_kzg_proof_many: every unit's
+    Ok(true) / Ok(false) / Err and every proof / y byte agree with the oracle."""
+    import kzg_rust_amd as kz
+    import fuzz_single_many as fs
+    import fuzz_verify as fv
+    s = fv.load_product(kz)
+    o, so = fs.make_oracle()
+    try:
+        blobs, tuples = fs.honest_tuples(o, so, n_blobs=4, per_blob=16)
+        cases = fs.make_verify_cases(1500, tuples, seed=0x4844_0008)
+        want = fs.oracle_verify(o, so, cases)
+        assert want.count(True) > 150 and want.count(False) > 400 and want.count(None) > 300, (want.count(True), want.count(False), want.count(None))
+        assert fs.run_verify_routes(kz, s, cases, want) == (0, 0, 0)
+        bad, n_err = fs.run_compute(kz, s, o, so, blobs, 96, seed=0x4844_0009)
+        assert bad == 0 and 2 <= n_err <= 30, (bad, n_err)
+    finally:
+        o.free_trusted_setup(so)
+        s.free()
