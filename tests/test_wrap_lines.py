@@ -79,3 +79,12 @@ def test_the_host_sources_are_at_rest_and_within_160_columns(tmp_path):
         p.write_text(src)
         subprocess.run([sys.executable, TOOL, str(p)], check=True, capture_output=True)
         assert p.read_text() == src, f"{name} changes under tools/wrap_lines.py"
+
+
+def test_design_md_is_within_its_limits():
+    """DESIGN.md is the current design only (history lives in EXPERIMENTS.md): at most 40 KB and every line within 160 BYTES (prose re-flowed by tools/wrap_md.py)"""
+    raw = open(os.path.join(ROOT, "DESIGN.md"), "rb").read()
+    assert len(raw) <= 40 * 1024, len(raw)
+    over = [i + 1 for i, ln in enumerate(raw.split(b"\n")) if len(ln) > 160]
+    assert not over, over
+    assert os.path.exists(os.path.join(ROOT, "EXPERIMENTS.md"))
