@@ -82,7 +82,9 @@ def main():
     import kzg_rust_amd as kz
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     forms = [int(a) for a in sys.argv[2:]] or list(FORMS)
-    blobs = make_blobs(N)
+    seed = int(os.environ.get("KZG355_FUZZ_SEED", "0x4844"), 0)                 # another seed = another run (profiles/r06/msm_fuzz_seed2.txt)
+    blobs = make_blobs(N, seed)
+    print(f"seed {seed:#x}", flush=True)
     t0 = time.time()
     want_c, want_p = oracle_outputs(blobs)
     print(f"oracle: {N} commitments + {N} proofs in {time.time() - t0:.1f} s", flush=True)

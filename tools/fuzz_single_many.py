@@ -152,12 +152,13 @@ def main():
     o, so = make_oracle()
     t0 = time.time()
     blobs, tuples = honest_tuples(o, so)
-    cases = make_verify_cases(n, tuples)
+    seed = int(os.environ.get("KZG355_FUZZ_SEED", "0x48440006"), 0)
+    cases = make_verify_cases(n, tuples, seed)
     want = oracle_verify(o, so, cases)
     print(f"oracle: {len(tuples)} honest tuples, {n} mutated checks in {time.time() - t0:.1f} s: {want.count(True)} true, {want.count(False)} false, {want.count(None)} Err", flush=True)
     b1, b2, b3 = run_verify_routes(kz, s, cases, want)
     print(f"verify_kzg_proof_many: one call of {n}: {b1} mismatches; calls of 40: {b2} mismatches; device-resident records: {b3} mismatches", flush=True)
-    bc, nerr = run_compute(kz, s, o, so, blobs, m)
+    bc, nerr = run_compute(kz, s, o, so, blobs, m, seed + 1)
     print(f"compute_kzg_proof_many: one call of {m} (blob, z) pairs, {nerr} of them Err by the oracle: {bc} mismatches", flush=True)
     assert b1 == 0 and b2 == 0 and b3 == 0 and bc == 0
     print("every unit of every route agrees with the oracle")

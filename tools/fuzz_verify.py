@@ -144,7 +144,9 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
     s = load_product(kz)
     blobs, cs, ps = honest_pool(kz, s)
-    cases = make_cases(N, blobs, cs, ps)
+    seed = int(os.environ.get("KZG355_FUZZ_SEED", "0x48440004"), 0)             # another seed = another run (profiles/r06/verify_fuzz_seed2.txt)
+    cases = make_cases(N, blobs, cs, ps, seed)
+    print(f"seed {seed:#x}", flush=True)
     t0 = time.time()
     want = oracle_verdicts(cases)
     print(f"oracle: {N} batches in {time.time() - t0:.1f} s: {want.count(True)} true, {want.count(False)} false, {want.count(None)} Err", flush=True)
