@@ -533,7 +533,14 @@ def main():
         def blobs_per_launch_of(fam):
             if args.op != "verify":
                 return Cc * n_local
-            return blobs_events / stats[fam][1] if fam in PER_BATCH_FAMILIES else blobs_events / world / stats[fam][1]
+            # stage 2 covers every rank's records only in the replicated form; in the split forms (all-to-all, split all-gather) a rank takes 1 / world of the batches
+            replicated = fam in PER_BATCH_FAMILIES and (not sharded or value_exchange == "allgather")
+            return blobs_events / stats[fam][1] if replicated else blobs_events / world / stats[fam][1]
+
+        def insts_scale_of(fam):
+            # the committed SQ pass is over 64-blob batches; a sharded batch has 64 x world records, so the kernels whose work is per BATCH (the pairing, the
+            # window sums and chains of the linear combination) do 1 / world of that per record
+            return 1.0 / world if sharded and fam in ("pairing", "lincomb_horner") else 1.0
         blobs_per_launch = blobs_per_launch_of(dom)
         achieved = KERNEL_BYTES_PER_BLOB[dom] * blobs_per_launch / avg_s / 1e9
         traffic, traffic_src = pmc_traffic(dom, blobs_per_launch, None if args.op == "verify" else args.op)
@@ -551,7 +558,7 @@ def main():
                     "path_bytes_per_blob": OP_BYTES_PER_BLOB[args.op],
                     "path_frac_of_hbm_peak": value * OP_BYTES_PER_BLOB[args.op] / (world * HBM_PEAK_GBPS * 1e9),
                     "measured_stream_copy_gbps": stream_copy_peak(torch, dev) if rank == 0 else None,
-                    "alu": alu_roofline(stats, blobs_per_launch_of, value / world) if args.op == "verify" else None,      # (the committed SQ pass is over the verify bench)
+                    "alu": alu_roofline(stats, blobs_per_launch_of, value / world, insts_scale_of) if args.op == "verify" else None,      # (the committed SQ pass is over the verify bench)
                     "note": "integer-issue-bound path (~1e3 integer ops per byte): the HBM fraction is small by construction; roofline.alu is the bound that binds"}
         if args.op != "verify" and s.msm_form >= 10:
             # the memory-side bound of the fixed-base MSM is not streaming bandwidth but RANDOM 128-byte row gathers: one table row per (window, scalar).
@@ -1225,7 +1232,7 @@ def pmc_traffic(kernel_family, blobs_per_launch, tag=None):
     return per_blob * blobs_per_launch, os.path.relpath(f, ROOT)
 
 
-def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
+def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu, insts_scale_of=lambda fam: 1.0):
     """The bound that binds: VALU issue.  Wave-instructions per blob of every kernel family come from the committed SQ counter
     pass (profiles/rNN/sq_*_vK.json, tools/sq_summary.py: SQ_INSTS_VALU at the bench's launch size); the durations are this
     run's live HIP-event averages.  Fractions are quoted against the NOMINAL issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per
@@ -1250,7 +1257,7 @@ def alu_roofline(stats, blobs_per_launch_of, blobs_per_s_per_gpu):
         ds = [per[k] for k in names if k in per]
         if fam in ALTERNATIVE_FORMS:
             ds = ds[:1]
-        insts = sum(d["valu_wave_insts_per_blob"] for d in ds)
+        insts = sum(d["valu_wave_insts_per_blob"] for d in ds) * insts_scale_of(fam)
         wait = ds[0].get("wait_inst_any_frac")
         rate = insts * blobs_per_launch_of(fam) / (tot_ms / cnt / 1e3)
         total_insts += insts
