@@ -72,7 +72,7 @@ OP_METRIC = {"verify": "blobs/sec on verify_blob_kzg_proof_batch (mainnet 4096, 
              "commit": "blobs/sec on blob_to_kzg_commitment (mainnet 4096-point G1 MSM)",
              "proof": "blobs/sec on compute_blob_kzg_proof (mainnet 4096)"}
 KERNEL_NAMES = {"eval": ["k_eval"], "challenge": ["k_challenge_1w", "k_challenge"], "lincomb": ["k_lc_buckets", "k_lc_carry"], "lincomb_prep": ["k_lc_prep"],
-                "lincomb_horner": ["k_lc_wsum", "k_lc_hchain_quad", "k_lc_horner"], "lincomb_shift": ["k_ps_shift"], "pairing": ["k_pairing_coop", "k_pairing_hard12"], "validate_points": ["k_validate_points"], "rpowers": ["k_rhash_lanes", "k_rpowers"],
+                "lincomb_horner": ["k_lc_wsum", "k_lc_hchain_quad", "k_lc_horner"], "lincomb_shift": ["k_ps_shift"], "pairing": ["k_pairing_coop<3>", "k_pairing_hard12"], "validate_points": ["k_validate_points"], "rpowers": ["k_rhash_lanes", "k_rpowers"],
                 "points_from_records": ["k_points_from_records"], "msm_bucket": ["k_msm_bucket<4>", "k_msm_bucket<1>"],
                 "msm_wide": ["k_msm_wide_glv<false>", "k_msm_wide_glv<true>", "k_msm_wide<false>", "k_msm_wide<true>"], "quotient": ["k_quotient_tree<4>", "k_quotient_tree<2>", "k_quotient_tree<6>", "k_quotient_prep", "k_quotient_scan", "k_quotient"], "msm_finalize": ["k_msm_finalize"]}
 ALTERNATIVE_FORMS = ("challenge", "msm_bucket", "msm_wide")     # lists of alternative forms of one kernel, not sequences

@@ -16,7 +16,11 @@ namespace kzg {
 constexpr int PAIRING_WAVES = 4;
 // f_out (or null): stop after instruction n_insn - 1 and hand slot F over (12 coefficients per batch) instead of deciding the verdict: with many
 // batches per launch set the hard part of the final exponentiation runs in k_pairing_hard12, twelve lanes per check.
-__global__ void __launch_bounds__(64 * PAIRING_WAVES) k_pairing_coop(const PairPt *pair_pts, int groups,
+// EU = waves per SIMD the register budget is cut for.  <1>: the kernel as the compiler likes it (196 VGPRs, two waves per SIMD) -- the form of the lone
+// check and of every launch that fits two workgroups per CU.  <3>: 168 VGPRs (22 of them spilled) so that a THIRD workgroup fits beside the 51 KB of LDS
+// each holds: with more than 2048 batches in a launch the extra wave per SIMD hides more of the dependent chains than the spills cost (round 6, one box,
+// 8192 batches: pairing 6.67 -> 6.40 ms; the same cut on k_pairing_hard12: 6.67 -> 6.79, not taken).
+template <int EU> __global__ void __launch_bounds__(64 * PAIRING_WAVES, EU) k_pairing_coop(const PairPt *pair_pts, int groups,
                                                                       const LineW *lines_w, const int *lines_inf, const FrobTables *frob,
                                                                       const CoopInsn *prog, int n_insn, const CoopScheds *scheds, int *ok, Fp *f_out) {
     __shared__ CoopMem mems[PAIRING_WAVES];
@@ -172,8 +176,10 @@ void launch_pairing(const PairPt *d_pair_pts, DeviceTables t, int groups, int *d
     const size_t want = ((size_t)160 * 1024 / per_cu) & ~(size_t)1023;
     if (want > fixed && want - fixed < 64 * 1024) pad = want - fixed;
     else if (want > fixed) pad = 64 * 1024 - 1024;
-    hipLaunchKernelGGL(k_pairing_coop, dim3(wgs), dim3(64 * PAIRING_WAVES), pad, st, d_pair_pts, groups, t.lines_w, t.lines_inf,
-                       t.frob, t.pairing_prog, split ? t.pairing_hard_start : t.pairing_prog_len, t.coop_scheds, d_ok, split ? d_f12 : nullptr);
+    if (per_cu >= 3) hipLaunchKernelGGL(k_pairing_coop<3>, dim3(wgs), dim3(64 * PAIRING_WAVES), pad, st, d_pair_pts, groups, t.lines_w, t.lines_inf,
+                t.frob, t.pairing_prog, split ? t.pairing_hard_start : t.pairing_prog_len, t.coop_scheds, d_ok, split ? d_f12 : nullptr);
+    else hipLaunchKernelGGL(k_pairing_coop<1>, dim3(wgs), dim3(64 * PAIRING_WAVES), pad, st, d_pair_pts, groups, t.lines_w, t.lines_inf,
+                t.frob, t.pairing_prog, split ? t.pairing_hard_start : t.pairing_prog_len, t.coop_scheds, d_ok, split ? d_f12 : nullptr);
     if (split) {
         const int per_wg = HARD12_WAVES * L12_BATCHES;
         hipLaunchKernelGGL(k_pairing_hard12, dim3((groups + per_wg - 1) / per_wg), dim3(64 * HARD12_WAVES), 0, st, d_f12, groups, t.frob, t.pairing_prog,

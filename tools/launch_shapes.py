@@ -20,7 +20,7 @@ def blobs_of_launch(kernel, grid, npg=64):
     per_batch = {                        # work-items per batch of npg blobs
         "k_rhash_lanes": 1, "k_rpowers": 64, "k_lc_prep": 64 * math.ceil((3 * npg + 1) / 64), "k_lc_buckets": 256, "k_lc_horner": 32,
         "k_lc_wsum": 52, "k_lc_hchain_quad": 8, "k_ps_shift": 4 * (2 * npg + 1), "k_ps_buckets": 2 * 4 * 256, "k_ps_weights": 32,
-        "k_lincomb_terms": 64 * math.ceil(2 * (3 * npg + 1) / 64), "k_lincomb_finish": 64, "k_pairing_coop": 64, "k_pairing_coop2": 128, "k_pairing_hard12": 256 / 20,
+        "k_lincomb_terms": 64 * math.ceil(2 * (3 * npg + 1) / 64), "k_lincomb_finish": 64, "k_pairing_coop": 64, "k_pairing_coop<1>": 64, "k_pairing_coop<3>": 64, "k_pairing_coop2": 128, "k_pairing_hard12": 256 / 20,
         "k_pairing": 1, "k_dump_intermediates": 2,
     }
     if kernel in per_blob:
