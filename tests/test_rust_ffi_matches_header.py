@@ -112,3 +112,52 @@ def test_status_constants_agree():
     _, rs_text = rust_functions()
     r_consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub\s+const\s+(KZG355_[A-Z_]+)\s*:\s*c_int\s*=\s*(\d+)\s*;", rs_text)}
     assert len(c_consts) == 9 and r_consts == c_consts
+
+
+def _rust_code_only(text):
+    """the source with comments, string / byte-string / char literals and lifetimes blanked (delimiters inside them do not count)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        if text.startswith("//", i):
+            j = text.find("\n", i); i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            depth, i = 1, i + 2
+            while i < n and depth:
+                if text.startswith("/*", i): depth += 1; i += 2
+                elif text.startswith("*/", i): depth -= 1; i += 2
+                else: i += 1
+        elif text[i] == '"' or (text[i] == "b" and text[i + 1:i + 2] == '"'):
+            i += 1 if text[i] == '"' else 2
+            while i < n and text[i] != '"':
+                i += 2 if text[i] == "\\" else 1
+            i += 1
+        elif text[i] == "r" and re.match(r'r#*"', text[i:]):
+            hashes = re.match(r'r(#*)"', text[i:]).group(1)
+            j = text.find('"' + hashes, i + 2 + len(hashes)); i = n if j < 0 else j + 1 + len(hashes)
+        elif text[i] == "'":
+            m = re.match(r"'(\\.[^']*|[^'\\])'", text[i:])
+            i += len(m.group(0)) if m else 1                     # a char literal, else a lifetime tick
+        else:
+            out.append(text[i]); i += 1
+    return "".join(out)
+
+
+def test_rust_sources_have_balanced_delimiters():
+    """no compiler here: at least every (, [, { of rust/src/*.rs and rust/tests/*.rs closes in order, outside comments and literals"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "rust", "src", "*.rs")) + glob.glob(os.path.join(ROOT, "rust", "tests", "*.rs")))
+    assert len(files) >= 4
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for f in files:
+        stack = []
+        code = _rust_code_only(open(f).read())
+        line = 1
+        for ch in code:
+            if ch == "\n":
+                line += 1
+            elif ch in "([{":
+                stack.append((ch, line))
+            elif ch in pairs:
+                assert stack and stack[-1][0] == pairs[ch], f"{f}:{line}: unmatched {ch!r}" + (f" (open {stack[-1][0]!r} from line {stack[-1][1]})" if stack else "")
+                stack.pop()
+        assert not stack, f"{f}: {stack[-1][0]!r} opened at line {stack[-1][1]} never closes"
